@@ -1,0 +1,195 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures in tests/golden/ from the REAL reference.
+
+Runs only in the build container (needs /root/reference and oracle/_ref, built by
+`make -C oracle ref`).  It executes the unmodified reference executables on tiny grids,
+reads the full-precision restart dumps they write (restart.c:531-770: labelled raw double
+blocks over active zones) and stores inputs + expected outputs as compact .npz files.  It
+also drives the reference's own kernels (fluxes, lr_states, Cons1D_to_Prim1D, cfast)
+through oracle/_ref/libref_<cfg>.so to produce function-level known-answer vectors.
+
+Fixtures are DATA (arrays + the scalar trace of each run); no reference text is stored.
+
+usage: python tests/golden/make_golden.py
+"""
+import ctypes as C
+import os
+import re
+import shutil
+import struct
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference"
+REFBIN = os.path.join(ROOT, "oracle", "_ref")
+
+LABELS = ["DENSITY", "1-MOMENTUM", "2-MOMENTUM", "3-MOMENTUM", "ENERGY"]
+
+
+def read_rst(path, nx, nscal, ion):
+    b = open(path, "rb").read()
+    pos = b.index(b"N_STEP\n") + len(b"N_STEP\n")
+    nstep = struct.unpack_from("<i", b, pos)[0]
+    pos = b.index(b"\nTIME\n", pos) + len(b"\nTIME\n")
+    time = struct.unpack_from("<d", b, pos)[0]
+    pos = b.index(b"\nTIME_STEP\n", pos) + len(b"\nTIME_STEP\n")
+    dt = struct.unpack_from("<d", b, pos)[0]
+    n = nx[0] * nx[1] * nx[2]
+    out = np.zeros((nx[2], nx[1], nx[0], 6))
+    for c, lab in enumerate(LABELS):
+        tag = b"\n" + lab.encode() + b"\n"
+        pos = b.index(tag, pos) + len(tag)
+        out[..., c] = np.frombuffer(b, dtype="<f8", count=n, offset=pos).reshape(nx[2], nx[1], nx[0])
+        pos += 8 * n
+    ef = None
+    if ion:
+        tag = b"\nEDGEFLUX\n"
+        pos = b.index(tag, pos) + len(tag)
+        ne = (nx[0] + 1) * (nx[1] + 1) * (nx[2] + 1)
+        ef = np.frombuffer(b, dtype="<f8", count=ne, offset=pos).reshape(nx[2] + 1, nx[1] + 1, nx[0] + 1).copy()
+        pos += 8 * ne
+    if nscal:
+        tag = b"\nSCALAR 0\n"
+        pos = b.index(tag, pos) + len(tag)
+        out[..., 5] = np.frombuffer(b, dtype="<f8", count=n, offset=pos).reshape(nx[2], nx[1], nx[0])
+    return dict(nstep=nstep, time=time, dt=dt, U=out, edgeflux=ef)
+
+
+def run_reference(cfg, deck, nx, nlim, extra, pid, nscal, ion):
+    exe = os.path.join(REFBIN, "athena_" + cfg)
+    tmp = tempfile.mkdtemp(prefix="golden_")
+    rundir = os.path.join(tmp, "run")
+    args = [exe, "-i", deck, "-d", rundir,
+            f"domain1/Nx1={nx[0]}", f"domain1/Nx2={nx[1]}", f"domain1/Nx3={nx[2]}",
+            f"time/nlim={nlim}"] + extra
+    pr = subprocess.run(args, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, cwd=tmp)
+    if pr.returncode != 0:
+        raise RuntimeError(pr.stdout[-2000:] + pr.stderr[-2000:])
+    niter = [int(m) for m in re.findall(r"Radiation done in (\d+) iterations", pr.stderr)]
+    rsts = sorted(f for f in os.listdir(rundir) if f.endswith(".rst"))
+    first = read_rst(os.path.join(rundir, rsts[0]), nx, nscal, ion)
+    last = read_rst(os.path.join(rundir, rsts[-1]), nx, nscal, ion)
+    shutil.rmtree(tmp)
+    return first, last, niter
+
+
+def save(name, first, last, niter, nx, overrides):
+    d = dict(nx=np.array(nx), U0=first["U"], U=last["U"], nstep=last["nstep"], time=last["time"],
+             dt=last["dt"], dt0=first["dt"], niter=np.array(niter, dtype=np.int64),
+             overrides=np.array(overrides))
+    if last["edgeflux"] is not None:
+        d["edgeflux"] = last["edgeflux"]
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **d)
+    print(f"{name}: nstep={last['nstep']} time={last['time']:.17g} dt={last['dt']:.17g} niter={niter}")
+
+
+def whole_runs():
+    ifront = os.path.join(REF, "tst/ionradiation/athinput.ifront")
+    sphere = os.path.join(REF, "tst/massloss/athinput.ioniz_sphere_hires")
+    blast = os.path.join(REF, "tst/3D-hydro/athinput.blast")
+    # (name, cfg, deck, nx, nlim, extra reference-cmdline, nscal, ion, overrides for OUR decks)
+    for nx, nlims in (((16, 8, 8), (1, 3, 6)), ((8, 12, 16), (4,))):
+        for nlim in nlims:
+            f, l, it = run_reference("ifront", ifront, nx, nlim,
+                                     ["job/maxout=3", "output3/out_fmt=rst", "output3/dt=1e300",
+                                      "output1/dt=1e300", "output2/dt=1e300"], "ifront", 1, True)
+            save(f"ifront_{nx[0]}x{nx[1]}x{nx[2]}_n{nlim}", f, l, it, nx, [])
+    for nx, nlims in (((20, 20, 20), (1, 3)), ((24, 16, 12), (2,))):
+        for nlim in nlims:
+            f, l, it = run_reference("ioniz_sphere", sphere, nx, nlim,
+                                     ["job/num_domains=1", "job/maxout=1", "output1/dt=1e300"],
+                                     "ioniz_sphere", 1, True)
+            save(f"ioniz_sphere_{nx[0]}x{nx[1]}x{nx[2]}_n{nlim}", f, l, it, nx, [])
+    for nx, nlims in (((16, 16, 16), (1, 5)), ((12, 20, 16), (4,))):
+        for nlim in nlims:
+            f, l, it = run_reference("blast", blast, nx, nlim,
+                                     ["job/num_domains=1", "job/maxout=1", "output1/out_fmt=rst",
+                                      "output1/dt=1e300"], "Blast", 0, False)
+            save(f"blast_{nx[0]}x{nx[1]}x{nx[2]}_n{nlim}", f, l, it, nx, [])
+
+
+# ------------------------------------------------------------------------------------
+def dp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def kernel_vectors():
+    rng = np.random.default_rng(20261004)
+    gamma = 1.666666666667
+    for cfg, nscal in (("ifront", 1), ("blast", 0)):
+        L = C.CDLL(os.path.join(REFBIN, f"libref_{cfg}.so"))
+        nv = 5 + nscal
+        assert L.ref_nvar() == nv
+        L.ref_set_gamma.argtypes = [C.c_double]
+        L.ref_set_gamma(gamma)
+        # ---- Riemann states: smooth, strong jumps, supersonic both ways, near-vacuum (HLLE) ----
+        n = 4096
+
+        def state(n, dlo, dhi, vscale, plo, phi):
+            d = np.exp(rng.uniform(np.log(dlo), np.log(dhi), n))
+            v = rng.normal(0.0, vscale, (n, 3))
+            p = np.exp(rng.uniform(np.log(plo), np.log(phi), n))
+            U = np.zeros((n, nv))
+            U[:, 0] = d
+            U[:, 1:4] = d[:, None] * v
+            U[:, 4] = p / (gamma - 1.0) + 0.5 * d * (v ** 2).sum(1)
+            if nscal:
+                U[:, 5] = d * rng.uniform(1e-4, 1.0, n)
+            return U
+
+        Ul = state(n, 0.1, 10.0, 1.0, 0.05, 20.0)
+        Ur = Ul + 0.01 * (state(n, 0.1, 10.0, 1.0, 0.05, 20.0) - Ul)     # near-smooth first quarter
+        Ur[n // 4:] = state(n - n // 4, 0.1, 10.0, 1.0, 0.05, 20.0)       # independent jumps
+        q = n // 8
+        Ul[4 * q:5 * q, 1] += 30.0 * Ul[4 * q:5 * q, 0]; Ur[4 * q:5 * q, 1] += 30.0 * Ur[4 * q:5 * q, 0]
+        Ul[5 * q:6 * q, 1] -= 30.0 * Ul[5 * q:6 * q, 0]; Ur[5 * q:6 * q, 1] -= 30.0 * Ur[5 * q:6 * q, 0]
+        for U in (Ul, Ur):   # keep E consistent after the boosts
+            pass
+        Ul[4 * q:6 * q, 4] = 1.0 / (gamma - 1) + 0.5 * (Ul[4 * q:6 * q, 1:4] ** 2).sum(1) / Ul[4 * q:6 * q, 0]
+        Ur[4 * q:6 * q, 4] = 1.5 / (gamma - 1) + 0.5 * (Ur[4 * q:6 * q, 1:4] ** 2).sum(1) / Ur[4 * q:6 * q, 0]
+        # strong rarefactions: receding flows over a big density/pressure contrast -> HLLE fallback
+        Ul[6 * q:7 * q] = state(q, 1.0, 5.0, 0.1, 1.0, 5.0); Ur[6 * q:7 * q] = state(q, 1e-6, 1e-4, 0.1, 1e-8, 1e-6)
+        Ul[6 * q:7 * q, 1] -= 8.0 * Ul[6 * q:7 * q, 0]; Ur[6 * q:7 * q, 1] += 8.0 * Ur[6 * q:7 * q, 0]
+        Ul[7 * q:, :] = state(n - 7 * q, 1e-3, 1e3, 3.0, 1e-4, 1e2); Ur[7 * q:, :] = state(n - 7 * q, 1e-3, 1e3, 3.0, 1e-4, 1e2)
+        Ul[6 * q:7 * q, 4] = 1.0 / (gamma - 1) + 0.5 * (Ul[6 * q:7 * q, 1:4] ** 2).sum(1) / Ul[6 * q:7 * q, 0]
+        Ur[6 * q:7 * q, 4] = 1e-7 / (gamma - 1) + 0.5 * (Ur[6 * q:7 * q, 1:4] ** 2).sum(1) / Ur[6 * q:7 * q, 0]
+        eta = np.where(rng.uniform(size=n) < 0.5, 0.0, rng.uniform(0.0, 3.0, n))
+        F = np.zeros((n, nv))
+        L.ref_fluxes(n, dp(Ul), dp(Ur), dp(eta), dp(F))
+        W = np.zeros((n, nv)); L.ref_cons_to_prim(n, dp(Ul), dp(W))
+        cf = np.zeros(n); L.ref_cfast(n, dp(Ul), dp(cf))
+        # ---- reconstruction pencils: smooth, shocks, extrema, both flow signs ----
+        m = 2048
+        x = np.linspace(0, 1, m)
+        Wp = np.zeros((m, nv))
+        Wp[:, 0] = 1.0 + 0.5 * np.sin(14 * np.pi * x) + (x > 0.5) * 2.0
+        Wp[:, 1] = 1.5 * np.sin(6 * np.pi * x) + rng.normal(0, 0.05, m)
+        Wp[:, 2] = rng.normal(0, 0.5, m)
+        Wp[:, 3] = np.cos(9 * np.pi * x)
+        Wp[:, 4] = 1.0 + 0.3 * np.cos(22 * np.pi * x) + (x > 0.25) * 3.0 + rng.uniform(0, 0.05, m)
+        Wp[m // 2:m // 2 + 200, 1] += 6.0          # supersonic to the right
+        Wp[m // 4:m // 4 + 200, 1] -= 6.0          # supersonic to the left
+        Wp[100:140, :] = Wp[100, :]                # flat stretch: zero slopes
+        if nscal:
+            Wp[:, 5] = np.clip(0.5 + 0.5 * np.sin(31 * np.pi * x) + rng.normal(0, 0.02, m), 1e-4, 1.0)
+        dtp, dxp = 0.004, 0.01
+        il, iu = 3, m - 4
+        Wl = np.zeros((m, nv)); Wr = np.zeros((m, nv))
+        L.ref_lr_states.argtypes = [C.c_int, C.POINTER(C.c_double), C.c_double, C.c_double, C.c_int, C.c_int,
+                                    C.POINTER(C.c_double), C.POINTER(C.c_double)]
+        L.ref_lr_states(m, dp(Wp), dtp, dxp, il, iu, dp(Wl), dp(Wr))
+        np.savez_compressed(os.path.join(HERE, f"kernels_nscal{nscal}.npz"), gamma=gamma, Ul=Ul, Ur=Ur, eta=eta,
+                            F=F, W=W, cfast=cf, Wp=Wp, dt=dtp, dx=dxp, il=il, iu=iu, Wl=Wl, Wr=Wr)
+        print(f"kernels_nscal{nscal}: {n} Riemann problems, pencil of {m}")
+
+
+if __name__ == "__main__":
+    if not os.path.isdir(REF) or not os.path.isdir(REFBIN):
+        sys.exit("needs /root/reference and oracle/_ref (make -C oracle ref)")
+    whole_runs()
+    kernel_vectors()
