@@ -1,0 +1,480 @@
+// api.hip -- the C-ABI of include/athena_amd.h: owns the device mirror of one Grid, sequences
+// the kernel chains in the order of the reference's main loop (main.c:519-669) and of
+// ion_radtransfer_3d (ionrad_3d.c:862-1047), and carries the scalar control flow (dt, sub-cycle
+// termination) on the host exactly as the reference does.  No CPU arithmetic path exists here.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <float.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <string>
+#include <vector>
+#include "../../include/athena_amd.h"
+#include "grid.h"
+
+using namespace aa;
+
+static thread_local char g_err[1024] = "";
+static int fail(int code, const char *fmt, ...)
+{
+  va_list ap; va_start(ap, fmt); vsnprintf(g_err, sizeof g_err, fmt, ap); va_end(ap);
+  return code;
+}
+#define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) \
+  return fail(-2, "[athena_amd] HIP error %s at %s:%d: %s", #x, __FILE__, __LINE__, hipGetErrorString(e_)); } while (0)
+
+#define MAXCELLCOUNT 20   /* ionrad.h:38 */
+
+struct ProfEntry { std::string name; std::vector<hipEvent_t> ev; double total_ms = 0; long long launches = 0; };
+
+struct aa_grid {
+  aa_params p;
+  DevGrid d;
+  IonPar ion;
+  hipStream_t st = nullptr; bool own_stream = false;
+  Real *pool = nullptr; size_t pool_doubles = 0;
+  DevScalars *sc = nullptr;        // device
+  DevScalars *sc_host = nullptr;   // pinned
+  long long *pin_idx = nullptr; Real *pin_val = nullptr; long long npin = 0;
+  bool grav = false;
+  int rad_dir = 0, nradplane = 0; Real flux_i = 0;
+  double time = 0, dt = 0; int nstep = 0;
+  long long bytes = 0;
+  bool prof = false;
+  std::vector<ProfEntry> pe;
+};
+
+// ---- profiling: an event pair around every kernel-chain stage, on the launch stream ----------
+struct Scope {
+  aa_grid *g; int id; hipEvent_t a = nullptr, b = nullptr;
+  Scope(aa_grid *g_, const char *name) : g(g_), id(-1) {
+    if (!g->prof) return;
+    for (size_t i = 0; i < g->pe.size(); i++) if (g->pe[i].name == name) { id = (int)i; break; }
+    if (id < 0) { g->pe.push_back(ProfEntry()); id = (int)g->pe.size() - 1; g->pe[id].name = name; }
+    hipEventCreate(&a); hipEventCreate(&b); hipEventRecord(a, g->st);
+  }
+  ~Scope() {
+    if (id < 0) return;
+    hipEventRecord(b, g->st);
+    g->pe[id].ev.push_back(a); g->pe[id].ev.push_back(b); g->pe[id].launches++;
+  }
+};
+static void prof_drain(aa_grid *g)
+{
+  hipStreamSynchronize(g->st);
+  for (auto &e : g->pe) {
+    for (size_t i = 0; i + 1 < e.ev.size(); i += 2) {
+      float ms = 0; hipEventElapsedTime(&ms, e.ev[i], e.ev[i + 1]); e.total_ms += ms;
+      hipEventDestroy(e.ev[i]); hipEventDestroy(e.ev[i + 1]);
+    }
+    e.ev.clear();
+  }
+}
+
+extern "C" {
+
+const char *aa_last_error(void) { return g_err; }
+
+int aa_create(const aa_params *p, aa_grid **out)
+{
+  if (!p || !out) return fail(-1, "[aa_create]: null argument");
+  for (int d = 0; d < 3; d++)
+    if (p->Nx[d] <= 1) return fail(-1, "[aa_create]: 3-D only, Nx%d=%d", d + 1, p->Nx[d]);
+  if (p->cour_no > 0.5)   // integrate.c:66-68
+    return fail(-1, "<time>cour_no was set to %g: must be <= 0.5 with 3D integrator", p->cour_no);
+  if (p->ion && p->nscal != 1) return fail(-1, "[aa_create]: ion radiation needs NSCALARS=1");
+  if (p->nscal != 0 && p->nscal != 1) return fail(-1, "[aa_create]: NSCALARS must be 0 or 1");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+    return fail(-3, "[aa_create]: no HIP device visible -- this library has no CPU path");
+  HIPCHK(hipSetDevice(p->device));
+  aa_grid *g = new aa_grid();
+  g->p = *p;
+  DevGrid &d = g->d;
+  memset(&d, 0, sizeof d);
+  d.Nx1 = p->Nx[0]; d.Nx2 = p->Nx[1]; d.Nx3 = p->Nx[2];
+  d.N1 = d.Nx1 + 2*AA_NGHOST; d.N2 = d.Nx2 + 2*AA_NGHOST; d.N3 = d.Nx3 + 2*AA_NGHOST;
+  d.is = d.js = d.ks = AA_NGHOST;
+  d.ie = d.is + d.Nx1 - 1; d.je = d.js + d.Nx2 - 1; d.ke = d.ks + d.Nx3 - 1;
+  d.sJ = d.N1; d.sK = (long)d.N1*d.N2; d.nc = d.sK*d.N3;
+  for (int a = 0; a < 3; a++) d.dx[a] = (p->xmax[a] - p->xmin[a])/(Real)(p->rootNx[a]);   // init_mesh.c:225
+  d.Gamma = p->gamma; d.Gamma_1 = p->gamma - 1.0;
+  // one pool: U 6 | LR 36 | F 18 | eta 3 | dhalf 1 | phi 4 | ion 6 + sign(1) | edgeflux
+  const size_t nc = (size_t)d.nc;
+  const size_t nef = (size_t)(d.Nx1 + 1)*(d.Nx2 + 1)*(d.Nx3 + 1);
+  size_t n = nc*(6 + 36 + 18 + 3 + 1 + 4);
+  if (p->ion) n += nc*7 + nef;
+  g->pool_doubles = n;
+  hipError_t e = hipMalloc(&g->pool, n*sizeof(Real));
+  if (e != hipSuccess) { delete g; return fail(-2, "[aa_create]: hipMalloc of %.2f GB failed: %s", n*8e-9, hipGetErrorString(e)); }
+  g->bytes = (long long)(n*sizeof(Real));
+  hipMemset(g->pool, 0, n*sizeof(Real));
+  Real *q = g->pool;
+  d.U = q; q += 6*nc; d.LR = q; q += 36*nc; d.F = q; q += 18*nc; d.eta = q; q += 3*nc; d.dhalf = q; q += nc;
+  d.phi = q; q += 4*nc;
+  if (p->ion) {
+    d.ph_rate = q; q += nc; d.edot = q; q += nc; d.nHdot = q; q += nc;
+    d.e_init = q; q += nc; d.e_th_init = q; q += nc; d.x_init = q; q += nc;
+    d.sign = (int2*)q; q += nc; d.edgeflux = q; q += nef;
+    IonPar &ip = g->ion;
+    ip.sigma_ph = p->sigma_ph; ip.m_H = p->m_H; ip.mu = p->mu; ip.e_gamma = p->e_gamma; ip.alpha_C = p->alpha_C;
+    ip.k_B = p->k_B; ip.time_unit = p->time_unit;
+    ip.max_de_iter = p->max_de_iter; ip.max_de_therm_iter = p->max_de_therm_iter; ip.max_dx_iter = p->max_dx_iter;
+    ip.max_de_step = p->max_de_step; ip.max_de_therm_step = p->max_de_therm_step; ip.max_dx_step = p->max_dx_step;
+    ip.tfloor = p->tfloor; ip.tceil = p->tceil; ip.cour_no = p->cour_no;
+    // ionrad.c:112-131: smallest face area and the "low" neutral density, from the ROOT dx
+    // (the reference's fallback at :129 is dx[1], reproduced as is)
+    Real a1 = d.dx[0]*d.dx[1], a2 = d.dx[0]*d.dx[2], a3 = d.dx[1]*d.dx[2];
+    if (a1 < a2) ip.min_area = (a1 < a3) ? a1 : a3; else ip.min_area = (a2 < a3) ? a2 : a3;
+    Real maxdx = d.dx[0] > d.dx[1] ? d.dx[0] : d.dx[1];
+    maxdx = maxdx > d.dx[2] ? maxdx : d.dx[1];
+    ip.d_nlo = 1.0e-4 * p->m_H / (p->sigma_ph * maxdx);      // MINOPTDEPTH, ionrad.h:29
+  }
+  if (hipMalloc(&g->sc, sizeof(DevScalars)) != hipSuccess || hipHostMalloc(&g->sc_host, sizeof(DevScalars)) != hipSuccess) {
+    hipFree(g->pool); delete g; return fail(-2, "[aa_create]: scalar buffers");
+  }
+  hipStreamCreate(&g->st); g->own_stream = true;
+  *out = g;
+  return 0;
+}
+
+void aa_destroy(aa_grid *g)
+{
+  if (!g) return;
+  hipStreamSynchronize(g->st);
+  prof_drain(g);
+  hipFree(g->pool); hipFree(g->sc); hipHostFree(g->sc_host);
+  if (g->pin_idx) hipFree(g->pin_idx);
+  if (g->pin_val) hipFree(g->pin_val);
+  if (g->own_stream) hipStreamDestroy(g->st);
+  delete g;
+}
+
+int aa_set_stream(aa_grid *g, void *s)
+{
+  hipStreamSynchronize(g->st);
+  if (g->own_stream) { hipStreamDestroy(g->st); g->own_stream = false; }
+  g->st = (hipStream_t)s;
+  return 0;
+}
+int aa_sync(aa_grid *g) { HIPCHK(hipStreamSynchronize(g->st)); return 0; }
+long long aa_device_bytes(const aa_grid *g) { return g->bytes; }
+
+// ---- state transfer: staging through the (idle) face-state area ---------------------------
+int aa_upload_cons(aa_grid *g, const double *U)
+{
+  const int nvar = 5 + g->p.nscal; const size_t n = (size_t)g->d.N1*g->d.N2*g->d.N3*nvar;
+  HIPCHK(hipMemcpyAsync(g->d.LR, U, n*sizeof(Real), hipMemcpyHostToDevice, g->st));
+  launch_aos_to_soa(g->d, nvar, g->d.LR, g->st);
+  HIPCHK(hipStreamSynchronize(g->st));
+  return 0;
+}
+int aa_download_cons(aa_grid *g, double *U)
+{
+  const int nvar = 5 + g->p.nscal; const size_t n = (size_t)g->d.N1*g->d.N2*g->d.N3*nvar;
+  launch_soa_to_aos(g->d, nvar, g->d.LR, g->st);
+  HIPCHK(hipMemcpyAsync(U, g->d.LR, n*sizeof(Real), hipMemcpyDeviceToHost, g->st));
+  HIPCHK(hipStreamSynchronize(g->st));
+  return 0;
+}
+int aa_upload_edgeflux(aa_grid *g, const double *ef)
+{
+  if (!g->p.ion) return fail(-1, "[aa_upload_edgeflux]: ion radiation is off");
+  const size_t n = (size_t)(g->d.Nx1 + 1)*(g->d.Nx2 + 1)*(g->d.Nx3 + 1);
+  HIPCHK(hipMemcpyAsync(g->d.edgeflux, ef, n*sizeof(Real), hipMemcpyHostToDevice, g->st));
+  HIPCHK(hipStreamSynchronize(g->st));
+  return 0;
+}
+int aa_download_edgeflux(aa_grid *g, double *ef)
+{
+  if (!g->p.ion) return fail(-1, "[aa_download_edgeflux]: ion radiation is off");
+  const size_t n = (size_t)(g->d.Nx1 + 1)*(g->d.Nx2 + 1)*(g->d.Nx3 + 1);
+  HIPCHK(hipMemcpyAsync(ef, g->d.edgeflux, n*sizeof(Real), hipMemcpyDeviceToHost, g->st));
+  HIPCHK(hipStreamSynchronize(g->st));
+  return 0;
+}
+int aa_get_mesh_state(const aa_grid *g, double *time, double *dt, int *nstep)
+{ if (time) *time = g->time; if (dt) *dt = g->dt; if (nstep) *nstep = g->nstep; return 0; }
+int aa_set_mesh_state(aa_grid *g, double time, double dt, int nstep)
+{ g->time = time; g->dt = dt; g->nstep = nstep; return 0; }
+
+// ---- hooks --------------------------------------------------------------------------------
+int aa_set_static_grav_tables(aa_grid *g, const double *pc, const double *p1, const double *p2, const double *p3)
+{
+  if (!pc) { g->grav = false; return 0; }
+  const size_t nb = (size_t)g->d.nc*sizeof(Real);
+  const double *src[4] = {pc, p1, p2, p3};
+  for (int w = 0; w < 4; w++) HIPCHK(hipMemcpyAsync(g->d.phi + (size_t)w*g->d.nc, src[w], nb, hipMemcpyHostToDevice, g->st));
+  HIPCHK(hipStreamSynchronize(g->st));
+  g->grav = true;
+  return 0;
+}
+
+int aa_set_static_grav_pot(aa_grid *g, aa_gravpot_fn fn)
+{
+  if (!fn) { g->grav = false; return 0; }
+  const DevGrid &d = g->d;
+  std::vector<double> t[4];
+  for (int w = 0; w < 4; w++) t[w].resize((size_t)d.nc);
+  for (int k = 0; k < d.N3; k++) for (int j = 0; j < d.N2; j++) for (int i = 0; i < d.N1; i++) {
+    // cc_pos.c:36-43
+    const double x1 = g->p.MinX[0] + ((double)(i - d.is) + 0.5)*d.dx[0];
+    const double x2 = g->p.MinX[1] + ((double)(j - d.js) + 0.5)*d.dx[1];
+    const double x3 = g->p.MinX[2] + ((double)(k - d.ks) + 0.5)*d.dx[2];
+    const size_t m = (size_t)k*d.sK + (size_t)j*d.sJ + i;
+    t[0][m] = fn(x1, x2, x3);
+    t[1][m] = fn(x1 - 0.5*d.dx[0], x2, x3);
+    t[2][m] = fn(x1, x2 - 0.5*d.dx[1], x3);
+    t[3][m] = fn(x1, x2, x3 - 0.5*d.dx[2]);
+  }
+  return aa_set_static_grav_tables(g, t[0].data(), t[1].data(), t[2].data(), t[3].data());
+}
+
+int aa_set_pinned_cells(aa_grid *g, long long n, const long long *index, const double *values)
+{
+  if (g->pin_idx) { hipFree(g->pin_idx); g->pin_idx = nullptr; }
+  if (g->pin_val) { hipFree(g->pin_val); g->pin_val = nullptr; }
+  g->npin = 0;
+  if (n <= 0) return 0;
+  const int nvar = 5 + g->p.nscal;
+  HIPCHK(hipMalloc(&g->pin_idx, (size_t)n*sizeof(long long)));
+  HIPCHK(hipMalloc(&g->pin_val, (size_t)n*nvar*sizeof(Real)));
+  HIPCHK(hipMemcpy(g->pin_idx, index, (size_t)n*sizeof(long long), hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(g->pin_val, values, (size_t)n*nvar*sizeof(Real), hipMemcpyHostToDevice));
+  g->npin = n;
+  return 0;
+}
+int aa_apply_pinned_cells(aa_grid *g)
+{
+  Scope s(g, "pinned_cells");
+  launch_pinned(g->d, 5 + g->p.nscal, g->npin, g->pin_idx, g->pin_val, g->st);
+  return 0;
+}
+
+int aa_add_radplane_3d(aa_grid *g, int dir, double flux)
+{
+  if (!g->p.ion) return fail(-1, "[add_radplane_3d]: ion radiation is off");
+  if (dir != -1) return fail(-1, "[add_radplane_3d]: only dir=-1 (rays along +x1) is supported, got %d", dir);
+  g->rad_dir = dir; g->flux_i = flux; g->nradplane = 1;
+  return 0;
+}
+
+// ---- per-step call sites ------------------------------------------------------------------
+int aa_bvals_mhd(aa_grid *g)
+{
+  Scope s(g, "bvals_mhd");
+  for (int d = 0; d < 3; d++) {          // x1, x2, x3 so the corners fill (bvals_mhd.c:170)
+    if (g->p.bc[2*d])     launch_bc(g->d, g->p.nscal, d, 0, g->p.bc[2*d], g->st);
+    if (g->p.bc[2*d + 1]) launch_bc(g->d, g->p.nscal, d, 1, g->p.bc[2*d + 1], g->st);
+  }
+  return 0;
+}
+
+int aa_bvals_ionrad(aa_grid *g)
+{
+  if (!g->p.ion || g->rad_dir != -1) return 0;
+  launch_edgeflux_bc(g->d, g->flux_i, g->st);
+  return 0;
+}
+
+static int fetch_scalars(aa_grid *g)
+{
+  HIPCHK(hipMemcpyAsync(g->sc_host, g->sc, sizeof(DevScalars), hipMemcpyDeviceToHost, g->st));
+  HIPCHK(hipStreamSynchronize(g->st));
+  return 0;
+}
+static inline double bits_to_double(unsigned long long b) { double x; memcpy(&x, &b, 8); return x; }
+static inline unsigned long long double_to_bits(double x) { unsigned long long b; memcpy(&b, &x, 8); return b; }
+
+int aa_new_dt_local(aa_grid *g, double *dt_cfl)
+{
+  { Scope s(g, "new_dt");
+    HIPCHK(hipMemsetAsync(g->sc->max_v, 0, 3*sizeof(unsigned long long), g->st));
+    launch_cfl(g->d, g->sc, g->st); }
+  int rc = fetch_scalars(g); if (rc) return rc;
+  double max_dti = 0.0;                   // new_dt.c:159-166
+  for (int d = 0; d < 3; d++) { double v = bits_to_double(g->sc_host->max_v[d])/g->d.dx[d]; max_dti = (max_dti > v) ? max_dti : v; }
+  *dt_cfl = g->p.cour_no/max_dti;
+  return 0;
+}
+
+int aa_new_dt(aa_grid *g)
+{
+  double dtc; int rc = aa_new_dt_local(g, &dtc); if (rc) return rc;
+  if (g->nstep == 0) g->dt = dtc; else g->dt = (2.0*g->dt < dtc) ? 2.0*g->dt : dtc;       // new_dt.c:169-173
+  if ((g->time < g->p.tlim) && ((g->p.tlim - g->time) < g->dt)) g->dt = g->p.tlim - g->time;   // :183-185
+  return 0;
+}
+
+int aa_integrate_3d_ctu(aa_grid *g)
+{
+  const DevGrid &d = g->d; const int ns = g->p.nscal; const Real dt = g->dt;
+  { Scope s(g, "sweep_x1"); launch_sweep(d, ns, 0, dt, g->grav, g->st); }
+  { Scope s(g, "sweep_x2"); launch_sweep(d, ns, 1, dt, g->grav, g->st); }
+  { Scope s(g, "sweep_x3"); launch_sweep(d, ns, 2, dt, g->grav, g->st); }
+  { Scope s(g, "correct");  launch_correct(d, ns, dt, g->grav, g->st); }
+  { Scope s(g, "flux2_x1"); launch_flux2(d, ns, 0, g->st); }
+  { Scope s(g, "flux2_x2"); launch_flux2(d, ns, 1, g->st); }
+  { Scope s(g, "flux2_x3"); launch_flux2(d, ns, 2, g->st); }
+  { Scope s(g, "update");   launch_update(d, ns, dt, g->grav, g->st); }
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+int aa_ion_begin(aa_grid *g)
+{
+  if (!g->p.ion) return fail(-1, "[ion_radtransfer]: ion radiation is off");
+  Scope s(g, "ion_begin");
+  launch_ion_begin(g->d, g->ion, g->st);
+  return 0;
+}
+
+int aa_ion_rates(aa_grid *g, double *dt_chem, double *dt_therm)
+{
+  {
+    DevScalars init; memset(&init, 0, sizeof init);
+    init.dt_chem = double_to_bits(DBL_MAX); init.dt_therm = double_to_bits(DBL_MAX);
+    *g->sc_host = init;
+    HIPCHK(hipMemcpyAsync(g->sc, g->sc_host, sizeof(DevScalars), hipMemcpyHostToDevice, g->st));
+  }
+  if (g->nradplane > 0) {
+    // ionradplane_3d.c:265: the hard-coded time ramp of the incident flux, evaluated once on the
+    // host (it is the same for every ray of the root level)
+    const Real flux0 = g->flux_i*(5.*(erf((g->time - 1.2e5)/8e4)+1)+0.1);
+    Scope s(g, "ray_sweep");
+    launch_ray_sweep(g->d, g->ion, flux0, g->st);
+  } else {
+    HIPCHK(hipMemsetAsync(g->d.ph_rate, 0, (size_t)g->d.nc*sizeof(Real), g->st));
+  }
+  { Scope s(g, "ion_rates"); launch_ion_rates(g->d, g->ion, g->sc, g->st); }
+  int rc = fetch_scalars(g); if (rc) return rc;
+  if (g->sc_host->neg_dt_chem) return fail(-4, "[compute_chem_rates]: negative dt_chem");   // ionrad_3d.c:389-391
+  *dt_chem = bits_to_double(g->sc_host->dt_chem);
+  *dt_therm = bits_to_double(g->sc_host->dt_therm);
+  return 0;
+}
+
+int aa_ion_update(aa_grid *g, double dt, long long *cellcount, double *dt_hydro)
+{
+  HIPCHK(hipMemsetAsync(&g->sc->max_dti, 0, 2*sizeof(unsigned long long), g->st));
+  { Scope s(g, "ion_update"); launch_ion_update(g->d, g->ion, dt, g->sc, g->st); }
+  int rc = fetch_scalars(g); if (rc) return rc;
+  if (cellcount) *cellcount = (long long)g->sc_host->cellcount;
+  if (dt_hydro) *dt_hydro = g->p.cour_no/bits_to_double(g->sc_host->max_dti);
+  return 0;
+}
+
+int aa_ion_radtransfer_3d(aa_grid *g, int *niter_out)
+{
+  // ionrad_3d.c:862-1047, root level
+  double dt_chem, dt_therm, dt_hydro = 0, dt, dt_done = 0.0;
+  long long cellcount;
+  int niter = 0, hydro_done = 0, rc;
+  if ((rc = aa_ion_begin(g))) return rc;
+  while (!hydro_done) {
+    if ((rc = aa_ion_rates(g, &dt_chem, &dt_therm))) return rc;
+    dt = (dt_therm < dt_chem) ? dt_therm : dt_chem;
+    if (dt_done + dt > g->dt) { dt = g->dt - dt_done; hydro_done = 1; }
+    if ((rc = aa_ion_update(g, dt, &cellcount, &dt_hydro))) return rc;
+    dt_done += dt;
+    niter++;
+    if (cellcount > MAXCELLCOUNT) { g->dt = dt_done; break; }
+    if (hydro_done) break;
+    if (dt_hydro < dt_done) { g->dt = dt_done; break; }
+  }
+  if (niter == g->p.maxiter) g->dt = dt_done;
+  if (g->dt < 0) return fail(-4, "[ion_radtransfer_3d]: dt = %e, dt_chem = %e, dt_therm = %e, dt_hydro = %e, dt_done = %e",
+                             g->dt, dt_chem, dt_therm, dt_hydro, dt_done);
+  if (niter_out) *niter_out = niter;
+  return 0;
+}
+
+int aa_start(aa_grid *g)
+{
+  int rc;
+  if ((rc = aa_bvals_mhd(g))) return rc;
+  if ((rc = aa_bvals_ionrad(g))) return rc;
+  return aa_new_dt(g);
+}
+
+int aa_step(aa_grid *g, int *niter_out)
+{
+  int rc, niter = 0;
+  if (g->p.ion && g->nradplane > 0) {                       // main.c:546-556
+    if ((rc = aa_ion_radtransfer_3d(g, &niter))) return rc;
+    if ((rc = aa_bvals_mhd(g))) return rc;
+  }
+  if ((rc = aa_integrate_3d_ctu(g))) return rc;              // :572-585
+  if (g->npin > 0 && (rc = aa_apply_pinned_cells(g))) return rc;   // Userwork_in_loop :597
+  g->nstep++; g->time += g->dt;                              // :618-626
+  if ((rc = aa_new_dt(g))) return rc;                        // :629
+  if ((rc = aa_bvals_mhd(g))) return rc;                     // :635-644
+  if (niter_out) *niter_out = niter;
+  return 0;
+}
+
+// ---- x3 halo ------------------------------------------------------------------------------
+long long aa_halo_doubles(const aa_grid *g) { return (long long)g->d.N1*g->d.N2*AA_NGHOST*(5 + g->p.nscal); }
+int aa_pack_x3(aa_grid *g, int side, double *buf)
+{
+  Scope s(g, "halo_pack");
+  const int k0 = side == 0 ? g->d.ks : g->d.ke - AA_NGHOST + 1;    // pack_ix3 / pack_ox3
+  launch_pack_x3(g->d, 5 + g->p.nscal, k0, buf, g->st);
+  return 0;
+}
+int aa_unpack_x3(aa_grid *g, int side, const double *buf)
+{
+  Scope s(g, "halo_unpack");
+  const int k0 = side == 0 ? g->d.ks - AA_NGHOST : g->d.ke + 1;    // unpack_ix3 / unpack_ox3
+  launch_unpack_x3(g->d, 5 + g->p.nscal, k0, buf, g->st);
+  return 0;
+}
+
+// ---- function-level tests -------------------------------------------------------------------
+int aa_test_fluxes(int nscal, double gamma, int n, const double *Ul, const double *Ur, const double *etah, double *F)
+{
+  const size_t nv = 5 + nscal, nb = (size_t)n*nv*sizeof(Real);
+  Real *d = nullptr;
+  HIPCHK(hipMalloc(&d, 3*nb + (size_t)n*sizeof(Real)));
+  Real *dUl = d, *dUr = d + (size_t)n*nv, *dF = d + 2*(size_t)n*nv, *de = d + 3*(size_t)n*nv;
+  HIPCHK(hipMemcpy(dUl, Ul, nb, hipMemcpyHostToDevice)); HIPCHK(hipMemcpy(dUr, Ur, nb, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(de, etah, (size_t)n*sizeof(Real), hipMemcpyHostToDevice));
+  launch_test_fluxes(nscal, gamma, n, dUl, dUr, de, dF, 0);
+  HIPCHK(hipDeviceSynchronize());
+  HIPCHK(hipMemcpy(F, dF, nb, hipMemcpyDeviceToHost));
+  hipFree(d);
+  return 0;
+}
+int aa_test_lr_states(int nscal, double gamma, int n, const double *W, double dt, double dx, int il, int iu, double *Wl, double *Wr)
+{
+  const size_t nv = 5 + nscal, nb = (size_t)n*nv*sizeof(Real);
+  if (il < 2 || iu > n - 3) return fail(-1, "[aa_test_lr_states]: W must cover [il-2, iu+2]");
+  Real *d = nullptr;
+  HIPCHK(hipMalloc(&d, 3*nb));
+  Real *dW = d, *dWl = d + (size_t)n*nv, *dWr = d + 2*(size_t)n*nv;
+  HIPCHK(hipMemcpy(dW, W, nb, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(dWl, Wl, nb, hipMemcpyHostToDevice)); HIPCHK(hipMemcpy(dWr, Wr, nb, hipMemcpyHostToDevice));
+  launch_test_lr(nscal, gamma, n, dW, dt, dx, il, iu, dWl, dWr, 0);
+  HIPCHK(hipDeviceSynchronize());
+  HIPCHK(hipMemcpy(Wl, dWl, nb, hipMemcpyDeviceToHost)); HIPCHK(hipMemcpy(Wr, dWr, nb, hipMemcpyDeviceToHost));
+  hipFree(d);
+  return 0;
+}
+
+// ---- measurement -----------------------------------------------------------------------------
+int aa_profile_enable(aa_grid *g, int on) { prof_drain(g); g->prof = on != 0; return 0; }
+int aa_profile_reset(aa_grid *g) { prof_drain(g); for (auto &e : g->pe) { e.total_ms = 0; e.launches = 0; } return 0; }
+int aa_profile_count(const aa_grid *g) { return (int)g->pe.size(); }
+const char *aa_profile_name(const aa_grid *g, int i) { return (i >= 0 && i < (int)g->pe.size()) ? g->pe[i].name.c_str() : ""; }
+int aa_profile_get(aa_grid *g, int i, double *total_ms, long long *launches)
+{
+  if (i < 0 || i >= (int)g->pe.size()) return fail(-1, "[aa_profile_get]: bad index");
+  prof_drain(g);
+  if (total_ms) *total_ms = g->pe[i].total_ms;
+  if (launches) *launches = g->pe[i].launches;
+  return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,86 @@
+// grid.h -- device-resident Grid descriptor and the launch interface between the C-ABI
+// layer (api.hip) and the kernel translation units (hydro_kernels.hip, ion_kernels.hip).
+//
+// HBM layout (one Grid = one GPU):
+//   every field is its own [N3][N2][N1] array of doubles (struct-of-arrays, i fastest, ghost
+//   zones included) so that a wavefront's 64 lanes on 64 consecutive i issue one 512-byte
+//   coalesced request per field.  Arrays of one family are spaced `nc` doubles apart:
+//     U    : 6*nc   d, M1, M2, M3, E, s0                      (GridS.U, athena.h:290)
+//     LR   : 36*nc  [dir][L|R][var] face states, GLOBAL momentum frame
+//                                                            (Ul/Ur_x?Face, integrate_3d_ctu.c:61-63)
+//     F    : 18*nc  [dir][var] fluxes, global frame           (x?Flux, :64)
+//     eta  : 3*nc   H-correction wave-speed spread per face   (eta1..3, :74)
+//     dhalf: nc                                               (:71)
+//     phi  : 4*nc   static potential at cell centres and at the lower x1/x2/x3 faces
+//   ion module (ionrad_3d.c:33-50): ph_rate, edot, nHdot, e_init, e_th_init, x_init (nc each),
+//   last_sign/sign_count packed in one int2 array; EdgeFlux [Nx3+1][Nx2+1][Nx1+1].
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace aa {
+
+typedef double Real;
+#define AA_NGHOST_ 4
+
+struct DevGrid {
+  int N1, N2, N3;                 // zones incl. ghosts
+  int is, ie, js, je, ks, ke;     // active range (nghost = 4)
+  long sJ, sK, nc;                // strides of j and k (i stride is 1); doubles per field
+  Real dx[3];
+  Real Gamma, Gamma_1;
+  Real *U, *LR, *F, *eta, *dhalf;
+  Real *phi;                      // null when StaticGravPot == NULL; [0]=centre, [1+d]=lower face d
+  // ion
+  Real *ph_rate, *edot, *nHdot, *e_init, *e_th_init, *x_init;
+  int2 *sign;                     // .x = last_sign, .y = sign_count
+  Real *edgeflux;
+  int Nx1, Nx2, Nx3;
+};
+
+struct IonPar {                   // ionrad.h:54-91 globals
+  Real sigma_ph, m_H, mu, e_gamma, alpha_C, k_B, time_unit;
+  Real max_de_iter, max_de_therm_iter, max_dx_iter;
+  Real max_de_step, max_de_therm_step, max_dx_step;
+  Real tfloor, tceil;
+  Real min_area, d_nlo;
+  Real cour_no;
+};
+
+// device scalars written by reduction kernels (all reductions are MIN/MAX of non-negative
+// doubles via their bit patterns, or integer sums: decomposition- and order-independent)
+struct DevScalars {
+  unsigned long long max_v[3];       // new_dt: max(|v_d| + a) per direction
+  unsigned long long dt_chem, dt_therm;   // min over cells
+  unsigned long long max_dti;        // compute_dt_hydro
+  unsigned long long cellcount;      // check_range
+  int neg_dt_chem;                   // error flag (ionrad_3d.c:389-391)
+  int pad;
+};
+
+// ---- launch wrappers (hydro_kernels.hip) ------------------------------------------
+void launch_sweep(const DevGrid &g, int nscal, int dir, Real dt, bool grav, hipStream_t st);
+void launch_correct(const DevGrid &g, int nscal, Real dt, bool grav, hipStream_t st);
+void launch_flux2(const DevGrid &g, int nscal, int dir, hipStream_t st);
+void launch_update(const DevGrid &g, int nscal, Real dt, bool grav, hipStream_t st);
+void launch_bc(const DevGrid &g, int nscal, int dir, int side, int flag, hipStream_t st);
+void launch_cfl(const DevGrid &g, DevScalars *sc, hipStream_t st);
+void launch_aos_to_soa(const DevGrid &g, int nvar, const Real *aos, hipStream_t st);
+void launch_soa_to_aos(const DevGrid &g, int nvar, Real *aos, hipStream_t st);
+void launch_pinned(const DevGrid &g, int nvar, long long n, const long long *idx, const Real *vals,
+                   hipStream_t st);
+void launch_pack_x3(const DevGrid &g, int nvar, int k0, Real *buf, hipStream_t st);
+void launch_unpack_x3(const DevGrid &g, int nvar, int k0, const Real *buf, hipStream_t st);
+void launch_test_fluxes(int nscal, Real gamma, int n, const Real *Ul, const Real *Ur, const Real *eta,
+                        Real *F, hipStream_t st);
+void launch_test_lr(int nscal, Real gamma, int n, const Real *W, Real dt, Real dx, int il, int iu,
+                    Real *Wl, Real *Wr, hipStream_t st);
+
+// ---- launch wrappers (ion_kernels.hip) ---------------------------------------------
+void launch_ion_begin(const DevGrid &g, const IonPar &p, hipStream_t st);
+void launch_ray_sweep(const DevGrid &g, const IonPar &p, Real flux0, hipStream_t st);
+void launch_ion_rates(const DevGrid &g, const IonPar &p, DevScalars *sc, hipStream_t st);
+void launch_ion_update(const DevGrid &g, const IonPar &p, Real dt, DevScalars *sc, hipStream_t st);
+void launch_edgeflux_bc(const DevGrid &g, Real flux_i, hipStream_t st);
+
+}  // namespace aa

@@ -1,0 +1,290 @@
+// hydro_dev.h -- per-cell / per-interface device arithmetic of the hydro hot path (gfx950).
+//
+// States are 6 doubles in the SWEEP frame: conserved (d,Mx,My,Mz,E,s0), primitive
+// (d,Vx,Vy,Vz,P,r0) -- the reference's Cons1DS/Prim1DS field order (athena.h:148-188).
+// Operation order follows the reference so that a build with -ffp-contract=off reproduces
+// the CPU results bit for bit; the default build lets the compiler fuse multiply-adds.
+// The dense 5x5 eigen-matrix products of the reference are written in their sparse form
+// (esystem_prim.c:138-198, esystem_roe.c:151-214): every partial sum is unchanged.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace aa {
+
+typedef double Real;
+#define AA_TINY 1.0e-20
+#define AA_DEV __device__ __forceinline__
+
+// The reference's MAX/MIN macros (defs.h.in:146-151).  NOT fmax/fmin: with a NaN operand the
+// ternary form is order-sensitive and the H-correction chain depends on that behaviour.
+AA_DEV Real rmax(Real a, Real b) { return (a > b) ? a : b; }
+AA_DEV Real rmin(Real a, Real b) { return (a < b) ? a : b; }
+AA_DEV Real sqr(Real x) { return x*x; }
+
+// convert_var.c:389 Cons1D_to_Prim1D
+template <int NS>
+AA_DEV void cons_to_prim(const Real u[6], Real w[6], Real Gamma_1)
+{
+  Real di = 1.0/u[0];
+  w[0] = u[0]; w[1] = u[1]*di; w[2] = u[2]*di; w[3] = u[3]*di;
+  Real p = u[4] - 0.5*(sqr(u[1]) + sqr(u[2]) + sqr(u[3]))*di;
+  p *= Gamma_1;
+  w[4] = rmax(p, AA_TINY);
+  w[5] = NS ? u[5]*di : 0.0;
+}
+
+// convert_var.c:432 Prim1D_to_Cons1D
+template <int NS>
+AA_DEV void prim_to_cons(const Real w[6], Real u[6], Real Gamma_1)
+{
+  u[0] = w[0]; u[1] = w[0]*w[1]; u[2] = w[0]*w[2]; u[3] = w[0]*w[3];
+  u[4] = w[4]/Gamma_1 + 0.5*w[0]*(sqr(w[1]) + sqr(w[2]) + sqr(w[3]));
+  u[5] = NS ? w[5]*w[0] : 0.0;
+}
+
+// convert_var.c:470 cfast (hydro)
+AA_DEV Real cfast(const Real u[6], Real Gamma, Real Gamma_1)
+{
+  Real p = Gamma_1*(u[4] - 0.0 - 0.5*(sqr(u[1]) + sqr(u[2]) + sqr(u[3]))/u[0]);
+  Real asq = Gamma*p/u[0];
+  return sqrt(asq);
+}
+
+// rsolvers/hlle.c:62 (compiled into roe.c as flux_hlle, roe.c:339-341)
+template <int NS>
+AA_DEV void flux_hlle(const Real ul[6], const Real ur[6], const Real wl[6], const Real wr[6],
+                      Real Gamma, Real Gamma_1, Real f[6])
+{
+  Real sqrtdl = sqrt(wl[0]), sqrtdr = sqrt(wr[0]);
+  Real isdlpdr = 1.0/(sqrtdl + sqrtdr);
+  Real v1 = (sqrtdl*wl[1] + sqrtdr*wr[1])*isdlpdr;
+  Real v2 = (sqrtdl*wl[2] + sqrtdr*wr[2])*isdlpdr;
+  Real v3 = (sqrtdl*wl[3] + sqrtdr*wr[3])*isdlpdr;
+  Real h  = ((ul[4] + wl[4] + 0.0)/sqrtdl + (ur[4] + wr[4] + 0.0)/sqrtdr)*isdlpdr;
+  Real vsq = v1*v1 + v2*v2 + v3*v3;
+  Real a = sqrt(Gamma_1*rmax((h - 0.5*vsq), AA_TINY));
+  Real ev0 = v1 - a, ev4 = v1 + a;
+
+  Real asq = Gamma*wl[4]/wl[0];
+  Real qsq = 0.0 + 0.0 + asq, tmp = 0.0 + 0.0 - asq;
+  Real cfl = sqrt(0.5*(qsq + sqrt(tmp*tmp + 4.0*asq*0.0)));
+  asq = Gamma*wr[4]/wr[0];
+  qsq = 0.0 + 0.0 + asq; tmp = 0.0 + 0.0 - asq;
+  Real cfr = sqrt(0.5*(qsq + sqrt(tmp*tmp + 4.0*asq*0.0)));
+
+  Real ar = rmax(ev4, (wr[1] + cfr));
+  Real al = rmin(ev0, (wl[1] - cfl));
+  Real bp = rmax(ar, 0.0), bm = rmin(al, 0.0);
+
+  Real Fl[6], Fr[6];
+  Fl[0] = ul[1] - bm*ul[0];          Fr[0] = ur[1] - bp*ur[0];
+  Fl[1] = ul[1]*(wl[1] - bm);        Fr[1] = ur[1]*(wr[1] - bp);
+  Fl[2] = ul[2]*(wl[1] - bm);        Fr[2] = ur[2]*(wr[1] - bp);
+  Fl[3] = ul[3]*(wl[1] - bm);        Fr[3] = ur[3]*(wr[1] - bp);
+  Fl[1] += wl[4];                    Fr[1] += wr[4];
+  Fl[4] = ul[4]*(wl[1] - bm) + wl[4]*wl[1];
+  Fr[4] = ur[4]*(wr[1] - bp) + wr[4]*wr[1];
+  Fl[5] = Fl[0]*wl[5];               Fr[5] = Fr[0]*wr[5];
+  tmp = 0.5*(bp + bm)/(bp - bm);
+#pragma unroll
+  for (int n = 0; n < 5 + NS; n++) f[n] = 0.5*(Fl[n] + Fr[n]) + (Fl[n] - Fr[n])*tmp;
+  if (!NS) f[5] = 0.0;
+}
+
+// rsolvers/roe.c:59 fluxes() with the H-correction etah and the HLLE fallback;
+// eigensystem rsolvers/esystem_roe.c:132
+template <int NS>
+AA_DEV void flux_roe(const Real ul[6], const Real ur[6], const Real wl[6], const Real wr[6],
+                     Real etah, Real Gamma, Real Gamma_1, Real f[6])
+{
+  Real sqrtdl = sqrt(wl[0]), sqrtdr = sqrt(wr[0]);
+  Real isdlpdr = 1.0/(sqrtdl + sqrtdr);
+  Real v1 = (sqrtdl*wl[1] + sqrtdr*wr[1])*isdlpdr;
+  Real v2 = (sqrtdl*wl[2] + sqrtdr*wr[2])*isdlpdr;
+  Real v3 = (sqrtdl*wl[3] + sqrtdr*wr[3])*isdlpdr;
+  Real h  = ((ul[4] + wl[4] + 0.0)/sqrtdl + (ur[4] + wr[4] + 0.0)/sqrtdr)*isdlpdr;
+  Real vsq = v1*v1 + v2*v2 + v3*v3;
+  Real asq = Gamma_1*rmax((h - 0.5*vsq), AA_TINY);
+  Real a = sqrt(asq);
+  Real ev0 = v1 - a, ev4 = v1 + a;
+
+  Real Fl[6], Fr[6];
+  Fl[0] = ul[1];            Fr[0] = ur[1];
+  Fl[1] = ul[1]*wl[1];      Fr[1] = ur[1]*wr[1];
+  Fl[2] = ul[1]*wl[2];      Fr[2] = ur[1]*wr[2];
+  Fl[3] = ul[1]*wl[3];      Fr[3] = ur[1]*wr[3];
+  Fl[1] += wl[4];           Fr[1] += wr[4];
+  Fl[4] = (ul[4] + wl[4])*wl[1];
+  Fr[4] = (ur[4] + wr[4])*wr[1];
+  Fl[5] = NS ? Fl[0]*wl[5] : 0.0;
+  Fr[5] = NS ? Fr[0]*wr[5] : 0.0;
+
+  if (ev0 >= 0.0) {                       // roe.c:215-235 supersonic: upwind flux
+#pragma unroll
+    for (int n = 0; n < 6; n++) f[n] = Fl[n];
+    return;
+  }
+  if (ev4 <= 0.0) {
+#pragma unroll
+    for (int n = 0; n < 6; n++) f[n] = Fr[n];
+    return;
+  }
+
+  Real na = 0.5/asq;
+  Real l00 = na*(0.5*Gamma_1*vsq + v1*a);
+  Real l01 = -na*(Gamma_1*v1 + a);
+  Real l02 = -na*Gamma_1*v2;
+  Real l03 = -na*Gamma_1*v3;
+  Real l04 = na*Gamma_1;
+  Real qa = Gamma_1/asq;
+  Real l30 = 1.0 - na*Gamma_1*vsq;
+  Real l31 = qa*v1, l32 = qa*v2, l33 = qa*v3, l34 = -qa;
+  Real l40 = na*(0.5*Gamma_1*vsq - v1*a);
+  Real l41 = -na*(Gamma_1*v1 - a);
+
+  Real dU[5], aa_[5];
+#pragma unroll
+  for (int n = 0; n < 5; n++) dU[n] = ur[n] - ul[n];
+  aa_[0] = l00*dU[0]; aa_[0] += l01*dU[1]; aa_[0] += l02*dU[2]; aa_[0] += l03*dU[3]; aa_[0] += l04*dU[4];
+  aa_[1] = (-v2)*dU[0]; aa_[1] += dU[2];
+  aa_[2] = (-v3)*dU[0]; aa_[2] += dU[3];
+  aa_[3] = l30*dU[0]; aa_[3] += l31*dU[1]; aa_[3] += l32*dU[2]; aa_[3] += l33*dU[3]; aa_[3] += l34*dU[4];
+  aa_[4] = l40*dU[0]; aa_[4] += l41*dU[1]; aa_[4] += l02*dU[2]; aa_[4] += l03*dU[3]; aa_[4] += l04*dU[4];
+
+  // roe.c:256-286: positivity of the intermediate states (tests only where ev[n+1] > ev[n])
+  Real u0 = ul[0], u1 = ul[1], u2 = ul[2], u3 = ul[3], u4 = ul[4];
+  bool hlle = false;
+  u0 += aa_[0]; u1 += aa_[0]*(v1 - a); u2 += aa_[0]*v2; u3 += aa_[0]*v3; u4 += aa_[0]*(h - v1*a);
+  if (v1 > ev0) {
+    if (u0 <= 0.0) hlle = true;
+    else { Real p_inter = u4 - 0.5*(sqr(u1) + sqr(u2) + sqr(u3))/u0; if (p_inter < 0.0) hlle = true; }
+  }
+  if (!hlle) {
+    u2 += aa_[1]; u4 += aa_[1]*v2;
+    u3 += aa_[2]; u4 += aa_[2]*v3;
+    u0 += aa_[3]; u1 += aa_[3]*v1; u2 += aa_[3]*v2; u3 += aa_[3]*v3; u4 += aa_[3]*(0.5*vsq);
+    if (ev4 > v1) {
+      if (u0 <= 0.0) hlle = true;
+      else { Real p_inter = u4 - 0.5*(sqr(u1) + sqr(u2) + sqr(u3))/u0; if (p_inter < 0.0) hlle = true; }
+    }
+  }
+  if (hlle) { flux_hlle<NS>(ul, ur, wl, wr, Gamma, Gamma_1, f); return; }
+
+  Real c0 = 0.5*rmax(fabs(ev0), etah)*aa_[0];
+  Real c1 = 0.5*rmax(fabs(v1), etah)*aa_[1];
+  Real c2 = 0.5*rmax(fabs(v1), etah)*aa_[2];
+  Real c3 = 0.5*rmax(fabs(v1), etah)*aa_[3];
+  Real c4 = 0.5*rmax(fabs(ev4), etah)*aa_[4];
+  f[0] = 0.5*(Fl[0] + Fr[0]); f[0] -= c0; f[0] -= c3; f[0] -= c4;
+  f[1] = 0.5*(Fl[1] + Fr[1]); f[1] -= c0*(v1 - a); f[1] -= c3*v1; f[1] -= c4*(v1 + a);
+  f[2] = 0.5*(Fl[2] + Fr[2]); f[2] -= c0*v2; f[2] -= c1; f[2] -= c3*v2; f[2] -= c4*v2;
+  f[3] = 0.5*(Fl[3] + Fr[3]); f[3] -= c0*v3; f[3] -= c2; f[3] -= c3*v3; f[3] -= c4*v3;
+  f[4] = 0.5*(Fl[4] + Fr[4]); f[4] -= c0*(h - v1*a); f[4] -= c1*v2; f[4] -= c2*v3;
+  f[4] -= c3*(0.5*vsq); f[4] -= c4*(h + v1*a);
+  f[5] = 0.0;
+  if (NS) f[5] = (f[0] >= 0.0) ? f[0]*wl[5] : f[0]*wr[5];
+}
+
+// reconstruction/lr_states_plm.c:62, one cell: from W[i-1], W[i], W[i+1] produce
+// wl_next = Wl[i+1] (left state of the upper interface) and wr_here = Wr[i] (right state of
+// the lower interface), PLM in characteristic variables + CTU characteristic tracing.
+// TRACE=false is the VL_INTEGRATOR branch (lr_states_plm.c:250-255).
+template <int NS, bool TRACE>
+AA_DEV void plm_cell(const Real wm[6], const Real w[6], const Real wp[6], Real dtodx, Real Gamma,
+                     Real wl_next[6], Real wr_here[6])
+{
+  constexpr int NV = 5 + NS;
+  Real d = w[0], vx = w[1];
+  Real asq = (Gamma*w[4])/d, a = sqrt(asq);
+  Real ev0 = vx - a, ev4 = vx + a;
+  Real r10 = -a/d, r14 = -r10;
+  Real l01 = -0.5*d/a, l04 = 0.5/asq, l14 = -1.0/asq, l41 = -l01;
+
+  Real dWc[6], dWl[6], dWr[6], dWg[6];
+#pragma unroll
+  for (int n = 0; n < NV; n++) {
+    dWc[n] = wp[n] - wm[n]; dWl[n] = w[n] - wm[n]; dWr[n] = wp[n] - w[n];
+    dWg[n] = (dWl[n]*dWr[n] > 0.0) ? 2.0*dWl[n]*dWr[n]/(dWl[n] + dWr[n]) : 0.0;
+  }
+  Real dac[6], dal[6], dar[6], dag[6];
+#define AA_PROJ(o, x) { o[0] = l01*x[1]; o[0] += l04*x[4]; o[1] = x[0]; o[1] += l14*x[4]; \
+                        o[2] = x[2]; o[3] = x[3]; o[4] = l41*x[1]; o[4] += l04*x[4]; \
+                        if (NS) o[5] = x[5]; }
+  AA_PROJ(dac, dWc) AA_PROJ(dal, dWl) AA_PROJ(dar, dWr) AA_PROJ(dag, dWg)
+#undef AA_PROJ
+  Real da[6];
+#pragma unroll
+  for (int n = 0; n < NV; n++) {
+    da[n] = 0.0;
+    if (dal[n]*dar[n] > 0.0) {
+      Real lim1 = rmin(fabs(dal[n]), fabs(dar[n]));
+      Real lim2 = rmin(0.5*fabs(dac[n]), fabs(dag[n]));
+      da[n] = ((dac[n] < 0.) ? -1. : 1.)*rmin(2.0*lim1, lim2);
+    }
+  }
+  Real dWm[6];
+  dWm[0] = da[0]; dWm[0] += da[1]; dWm[0] += da[4];
+  dWm[1] = da[0]*r10; dWm[1] += da[4]*r14;
+  dWm[2] = da[2]; dWm[3] = da[3];
+  dWm[4] = da[0]*asq; dWm[4] += da[4]*asq;
+  if (NS) dWm[5] = da[5];
+
+  Real Wlv[6], Wrv[6], dW[6];
+#pragma unroll
+  for (int n = 0; n < NV; n++) {
+    Wlv[n] = w[n] - 0.5*dWm[n];
+    Wrv[n] = w[n] + 0.5*dWm[n];
+    Real C = Wrv[n] + Wlv[n];
+    Wlv[n] = rmax(rmin(w[n], wm[n]), Wlv[n]);
+    Wlv[n] = rmin(rmax(w[n], wm[n]), Wlv[n]);
+    Wrv[n] = C - Wlv[n];
+    Wrv[n] = rmax(rmin(w[n], wp[n]), Wrv[n]);
+    Wrv[n] = rmin(rmax(w[n], wp[n]), Wrv[n]);
+    Wlv[n] = (C - Wrv[n]);
+    dW[n] = Wrv[n] - Wlv[n];
+  }
+  if (!NS) { wl_next[5] = 0.0; wr_here[5] = 0.0; }
+  if (!TRACE) {
+#pragma unroll
+    for (int n = 0; n < NV; n++) { wl_next[n] = Wrv[n]; wr_here[n] = Wlv[n]; }
+    return;
+  }
+  Real qx = 0.5*rmax(ev4, 0.0)*dtodx;
+#pragma unroll
+  for (int n = 0; n < NV; n++) wl_next[n] = Wrv[n] - qx*dW[n];
+  qx = -0.5*rmin(ev0, 0.0)*dtodx;
+#pragma unroll
+  for (int n = 0; n < NV; n++) wr_here[n] = Wlv[n] + qx*dW[n];
+
+  Real qa, qx1, qx2;
+  qx1 = 0.5*dtodx*ev4;
+  if (ev0 >= 0.0) {
+    qx2 = 0.5*dtodx*ev0; qx = qx1 - qx2;
+    qa = 0.0; qa += l01*qx*dW[1]; qa += l04*qx*dW[4];
+    wl_next[0] += qa; wl_next[1] += qa*r10; wl_next[4] += qa*asq;
+  }
+  if (vx >= 0.0) {
+    qx2 = 0.5*dtodx*vx; qx = qx1 - qx2;
+    qa = 0.0; qa += qx*dW[0]; qa += l14*qx*dW[4];  wl_next[0] += qa;
+    qa = 0.0; qa += qx*dW[2];                      wl_next[2] += qa;
+    qa = 0.0; qa += qx*dW[3];                      wl_next[3] += qa;
+  }
+  qx1 = -0.5*dtodx*ev0;
+  if (vx <= 0.0) {
+    qx2 = -0.5*dtodx*vx; qx = -qx1 + qx2;
+    qa = 0.0; qa += qx*dW[0]; qa += l14*qx*dW[4];  wr_here[0] += qa;
+    qa = 0.0; qa += qx*dW[2];                      wr_here[2] += qa;
+    qa = 0.0; qa += qx*dW[3];                      wr_here[3] += qa;
+  }
+  if (ev4 <= 0.0) {
+    qx2 = -0.5*dtodx*ev4; qx = -qx1 + qx2;
+    qa = 0.0; qa += l41*qx*dW[1]; qa += l04*qx*dW[4];
+    wr_here[0] += qa; wr_here[1] += qa*r14; wr_here[4] += qa*asq;
+  }
+  if (NS) {
+    if (vx > 0.)      wl_next[5] += 0.5*dtodx*(ev4 - vx)*dW[5];
+    else if (vx < 0.) wr_here[5] += 0.5*dtodx*(ev0 - vx)*dW[5];
+  }
+}
+
+}  // namespace aa

@@ -1,0 +1,572 @@
+// hydro_kernels.hip -- the 3-D CTU integrator of integrators/integrate_3d_ctu.c as HIP kernels
+// for gfx950 (HYDRO / ADIABATIC / CARTESIAN / PLM-characteristic / Roe + H-correction).
+//
+// Kernel chain of one integrate_3d_ctu() call (reference steps in brackets):
+//   sweep<x1>, sweep<x2>, sweep<x3>   [1-3]  prim conversion + PLM/tracing + gravity kick +
+//                                            first-pass Roe flux; writes Ul,Ur,F of that direction
+//   correct                           [5-8a,9a] transverse flux-gradient corrections of all six
+//                                            face states in place, d^{n+1/2}, eta of every face
+//   flux2<x1>, flux2<x2>, flux2<x3>   [9b-d] etah = max of 9 etas, second-pass Roe flux
+//   update                            [11a,12] gravity source + conservative update of U
+// All arrays are struct-of-arrays with i fastest (grid.h); every global access of a wavefront
+// is to consecutive i.  The x1 sweep exchanges neighbour cells through LDS; the x2/x3 sweeps
+// march a register sliding window along the sweep direction so no cell is converted or
+// reconstructed twice.  FP64 vector arithmetic throughout: there is no dense contraction, so
+// MFMA is not used.
+#include "grid.h"
+#include "hydro_dev.h"
+
+namespace aa {
+
+// ---- field accessors ------------------------------------------------------------------
+AA_DEV Real *Uf(const DevGrid &g, int v) { return g.U + (long)v*g.nc; }
+AA_DEV Real *LRf(const DevGrid &g, int d, int side, int v) { return g.LR + (long)((d*2 + side)*6 + v)*g.nc; }
+AA_DEV Real *Ff(const DevGrid &g, int d, int v) { return g.F + (long)(d*6 + v)*g.nc; }
+AA_DEV Real *Ef(const DevGrid &g, int d) { return g.eta + (long)d*g.nc; }
+AA_DEV Real *Pf(const DevGrid &g, int which) { return g.phi + (long)which*g.nc; }   // 0 centre, 1+d face
+
+// sweep-frame component n of direction D lives in global field gv<D>(n):
+// (Mx,My,Mz) = (M[D], M[D+1], M[D+2])   integrate_3d_ctu.c:206-208, :544-546, :727-729
+template <int D> AA_DEV constexpr int gv(int n) { return (n >= 1 && n <= 3) ? 1 + ((D + n - 1) % 3) : n; }
+template <int D> AA_DEV long stride(const DevGrid &g) { return D == 0 ? 1L : (D == 1 ? g.sJ : g.sK); }
+AA_DEV long stride_rt(const DevGrid &g, int d) { return d == 0 ? 1L : (d == 1 ? g.sJ : g.sK); }
+
+template <int D, int NS>
+AA_DEV void load_sweep(const Real *fam, long nc, long m, Real out[6])
+{
+#pragma unroll
+  for (int n = 0; n < 5 + NS; n++) out[n] = fam[(long)gv<D>(n)*nc + m];
+  if (!NS) out[5] = 0.0;
+}
+template <int D, int NS>
+AA_DEV void store_sweep(Real *fam, long nc, long m, const Real in[6])
+{
+#pragma unroll
+  for (int n = 0; n < 5 + NS; n++) fam[(long)gv<D>(n)*nc + m] = in[n];
+}
+
+// Face work shared by both sweep kernels (steps 1c-1d): gravity kick on the L/R primitive
+// states, conversion to conserved, first-pass flux (etah = 0), store.
+template <int NS, int D, bool GRAV>
+AA_DEV void face_first_pass(const DevGrid &g, long m, Real dtodx, Real wl[6], Real wr[6])
+{
+  if (GRAV) {   // integrate_3d_ctu.c:318-342 (x1), :611-628 (x2), :795-812 (x3)
+    const long s = stride<D>(g);
+    Real phicr = Pf(g, 0)[m], phicl = Pf(g, 0)[m - s], phifc = Pf(g, 1 + D)[m];
+    wl[1] -= dtodx*(phifc - phicl);
+    wr[1] -= dtodx*(phicr - phifc);
+  }
+  Real ul[6], ur[6], f[6];
+  prim_to_cons<NS>(wl, ul, g.Gamma_1);
+  prim_to_cons<NS>(wr, ur, g.Gamma_1);
+  flux_roe<NS>(ul, ur, wl, wr, 0.0, g.Gamma, g.Gamma_1, f);
+  store_sweep<D, NS>(LRf(g, D, 0, 0), g.nc, m, ul);
+  store_sweep<D, NS>(LRf(g, D, 1, 0), g.nc, m, ur);
+  store_sweep<D, NS>(Ff(g, D, 0), g.nc, m, f);
+}
+
+// ---- steps 2,3: x2 / x3 sweeps, register sliding window along the sweep direction ---------
+// One thread owns one (i, transverse) column and a chunk of `chunk` interfaces; lanes are
+// consecutive in i.  Cells reconstructed: l..u = s-2..e+2; interfaces l+1..u (:179-184).
+template <int NS, int D, bool GRAV>
+__global__ void __launch_bounds__(256)
+k_sweep_march(DevGrid g, Real dt, int chunk)
+{
+  static_assert(D == 1 || D == 2, "march kernel is for the strided directions");
+  const int ni = g.ie - g.is + 5;                              // i in [is-2, ie+2]
+  const int tlo = (D == 1 ? g.ks : g.js) - 2;
+  const int nt  = (D == 1 ? g.ke - g.ks : g.je - g.js) + 5;
+  const long lin = (long)blockIdx.x*blockDim.x + threadIdx.x;
+  if (lin >= (long)ni*nt) return;
+  const int i = g.is - 2 + (int)(lin % ni);
+  const int t = tlo + (int)(lin / ni);
+  const int lo = (D == 1 ? g.js : g.ks), hi = (D == 1 ? g.je : g.ke);
+  const int f0 = lo - 1 + blockIdx.y*chunk;                    // first interface of this chunk
+  int f1 = f0 + chunk - 1; if (f1 > hi + 2) f1 = hi + 2;
+  if (f0 > f1) return;
+  const long s = stride<D>(g);
+  const long base = (D == 1) ? ((long)t*g.sK + i) : ((long)t*g.sJ + i);
+  const Real dtodx = dt/g.dx[D];
+
+  Real wm[6], w[6], wp[6], wl_cur[6], wl_next[6], wr[6], u[6];
+  load_sweep<D, NS>(g.U, g.nc, base + (long)(f0 - 2)*s, u); cons_to_prim<NS>(u, wm, g.Gamma_1);
+  load_sweep<D, NS>(g.U, g.nc, base + (long)(f0 - 1)*s, u); cons_to_prim<NS>(u, w,  g.Gamma_1);
+  load_sweep<D, NS>(g.U, g.nc, base + (long)(f0    )*s, u); cons_to_prim<NS>(u, wp, g.Gamma_1);
+  plm_cell<NS, true>(wm, w, wp, dtodx, g.Gamma, wl_cur, wr);   // cell f0-1 -> Wl[f0]
+  for (int f = f0; f <= f1; f++) {
+#pragma unroll
+    for (int n = 0; n < 6; n++) { wm[n] = w[n]; w[n] = wp[n]; }
+    load_sweep<D, NS>(g.U, g.nc, base + (long)(f + 1)*s, u); cons_to_prim<NS>(u, wp, g.Gamma_1);
+    plm_cell<NS, true>(wm, w, wp, dtodx, g.Gamma, wl_next, wr); // cell f -> Wl[f+1], Wr[f]
+    face_first_pass<NS, D, GRAV>(g, base + (long)f*s, dtodx, wl_cur, wr);
+#pragma unroll
+    for (int n = 0; n < 6; n++) wl_cur[n] = wl_next[n];
+  }
+}
+
+// ---- step 1: x1 sweep, neighbours through LDS ------------------------------------------
+// A block of B threads reconstructs B consecutive cells of one (j,k) row and solves the B-1
+// interfaces between them; blocks overlap by one cell.
+template <int NS, bool GRAV>
+__global__ void __launch_bounds__(256)
+k_sweep_x1(DevGrid g, Real dt)
+{
+  extern __shared__ Real sm[];
+  const int B = blockDim.x, t = threadIdx.x;
+  const int j = g.js - 2 + blockIdx.y, k = g.ks - 2 + blockIdx.z;
+  const int c0 = g.is - 2 + blockIdx.x*(B - 1);
+  const int c = c0 + t;
+  const long row = (long)k*g.sK + (long)j*g.sJ;
+  const Real dtodx = dt/g.dx[0];
+  const int P = B + 2;                                 // LDS pitch per component
+  Real u[6], w[6];
+  const bool have = (c <= g.ie + 3);                   // cells up to ie+3 feed the stencil
+  if (have) { load_sweep<0, NS>(g.U, g.nc, row + c, u); cons_to_prim<NS>(u, w, g.Gamma_1); }
+  else {
+#pragma unroll
+    for (int n = 0; n < 6; n++) w[n] = 1.0;
+  }
+#pragma unroll
+  for (int n = 0; n < 5 + NS; n++) sm[n*P + t + 1] = w[n];
+  if (t == 0) {                                        // lower halo cell c0-1 (>= is-3)
+    Real uh[6], wh[6];
+    load_sweep<0, NS>(g.U, g.nc, row + c0 - 1, uh); cons_to_prim<NS>(uh, wh, g.Gamma_1);
+#pragma unroll
+    for (int n = 0; n < 5 + NS; n++) sm[n*P] = wh[n];
+  }
+  if (t == B - 1) {                                    // upper halo cell c0+B
+    Real uh[6], wh[6];
+    if (c + 1 <= g.ie + 3) { load_sweep<0, NS>(g.U, g.nc, row + c + 1, uh); cons_to_prim<NS>(uh, wh, g.Gamma_1); }
+    else {
+#pragma unroll
+      for (int n = 0; n < 6; n++) wh[n] = 1.0;
+    }
+#pragma unroll
+    for (int n = 0; n < 5 + NS; n++) sm[n*P + B + 1] = wh[n];
+  }
+  __syncthreads();
+  Real wm[6], wp[6], wl_next[6], wr[6];
+#pragma unroll
+  for (int n = 0; n < 5 + NS; n++) { wm[n] = sm[n*P + t]; wp[n] = sm[n*P + t + 2]; }
+  if (!NS) { wm[5] = 0.0; wp[5] = 0.0; }
+  const bool recon = (c <= g.ie + 2);                  // cells l..u
+  if (recon) plm_cell<NS, true>(wm, w, wp, dtodx, g.Gamma, wl_next, wr);
+  else {
+#pragma unroll
+    for (int n = 0; n < 6; n++) { wl_next[n] = 1.0; wr[n] = 1.0; }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int n = 0; n < 5 + NS; n++) sm[n*P + t] = wl_next[n];
+  __syncthreads();
+  if (t >= 1 && recon) {                               // interface c, between cells c-1 and c
+    Real wl[6];
+#pragma unroll
+    for (int n = 0; n < 5 + NS; n++) wl[n] = sm[n*P + t - 1];
+    if (!NS) wl[5] = 0.0;
+    face_first_pass<NS, 0, GRAV>(g, row + c, dtodx, wl, wr);
+  }
+}
+
+// ---- steps 5-7, 8a, 9a: transverse corrections, d^{n+1/2}, eta -----------------------------
+// One thread per cell (i,j,k) in [s-1, e+2]^3 handles the cell's three LOWER faces.
+template <int NS, int D, bool GRAV>
+AA_DEV void correct_face(const DevGrid &g, long m, int i, int j, int k, const Real q[3])
+{
+  // ranges (integrate_3d_ctu.c:978, :1282, :1691): along D [s-1, e+2], transverse [s-1, e+1]
+  const bool in = (D == 0 || i <= g.ie + 1) && (D == 1 || j <= g.je + 1) && (D == 2 || k <= g.ke + 1);
+  if (!in) return;
+  constexpr int NV = 5 + NS;
+  const long sD = stride<D>(g), ml = m - sD;
+  Real ul[6], ur[6];
+#pragma unroll
+  for (int v = 0; v < NV; v++) { ul[v] = LRf(g, D, 0, v)[m]; ur[v] = LRf(g, D, 1, v)[m]; }
+#pragma unroll
+  for (int e = 0; e < 3; e++) {
+    if (e == D) continue;
+    const long se = stride_rt(g, e);
+#pragma unroll
+    for (int v = 0; v < NV; v++) {
+      const Real *fe = Ff(g, e, v);
+      ul[v] -= q[e]*(fe[ml + se] - fe[ml]);
+      ur[v] -= q[e]*(fe[m + se] - fe[m]);
+    }
+  }
+  if (GRAV) {   // :1167-1219, :1463-1526, :1873-1937
+    const Real *pc = Pf(g, 0);
+    const Real dR = Uf(g, 0)[m], dL = Uf(g, 0)[ml];
+    Real phic = pc[m];
+#pragma unroll
+    for (int e = 0; e < 3; e++) {
+      if (e == D) continue;
+      const long se = stride_rt(g, e);
+      const Real *pfe = Pf(g, 1 + e), *fd = Ff(g, e, 0);
+      Real phir = pfe[m + se], phil = pfe[m];
+      ur[1 + e] -= q[e]*(phir - phil)*dR;
+      ur[4] -= q[e]*(fd[m]*(phic - phil) + fd[m + se]*(phir - phic));
+    }
+    phic = pc[ml];
+#pragma unroll
+    for (int e = 0; e < 3; e++) {
+      if (e == D) continue;
+      const long se = stride_rt(g, e);
+      const Real *pfe = Pf(g, 1 + e), *fd = Ff(g, e, 0);
+      Real phir = pfe[ml + se], phil = pfe[ml];
+      ul[1 + e] -= q[e]*(phir - phil)*dL;
+      ul[4] -= q[e]*(fd[ml]*(phic - phil) + fd[ml + se]*(phir - phic));
+    }
+  }
+#pragma unroll
+  for (int v = 0; v < NV; v++) { LRf(g, D, 0, v)[m] = ul[v]; LRf(g, D, 1, v)[m] = ur[v]; }
+  // eta (integrate_3d_ctu.c:2300-2343), in the sweep frame of D
+  Real sl[6], sr[6];
+#pragma unroll
+  for (int n = 0; n < 6; n++) { sl[n] = ul[gv<D>(n)]; sr[n] = ur[gv<D>(n)]; }
+  Real cfr = cfast(sr, g.Gamma, g.Gamma_1), cfl = cfast(sl, g.Gamma, g.Gamma_1);
+  Real lambdar = sr[1]/sr[0] + cfr, lambdal = sl[1]/sl[0] - cfl;
+  Ef(g, D)[m] = 0.5*fabs(lambdar - lambdal);
+}
+
+template <int NS, bool GRAV>
+__global__ void __launch_bounds__(256)
+k_correct(DevGrid g, Real dt)
+{
+  const int ni = g.ie - g.is + 4, nj = g.je - g.js + 4, nk = g.ke - g.ks + 4;   // [s-1, e+2]
+  const long lin = (long)blockIdx.x*blockDim.x + threadIdx.x;
+  if (lin >= (long)ni*nj*nk) return;
+  const int i = g.is - 1 + (int)(lin % ni);
+  const int j = g.js - 1 + (int)((lin / ni) % nj);
+  const int k = g.ks - 1 + (int)(lin / ((long)ni*nj));
+  const long m = (long)k*g.sK + (long)j*g.sJ + i;
+  Real q[3];
+#pragma unroll
+  for (int d = 0; d < 3; d++) q[d] = 0.5*(dt/g.dx[d]);
+  if (GRAV && i <= g.ie + 1 && j <= g.je + 1 && k <= g.ke + 1) {       // :2104-2125
+    g.dhalf[m] = Uf(g, 0)[m]
+      - q[0]*(Ff(g, 0, 0)[m + 1]    - Ff(g, 0, 0)[m])
+      - q[1]*(Ff(g, 1, 0)[m + g.sJ] - Ff(g, 1, 0)[m])
+      - q[2]*(Ff(g, 2, 0)[m + g.sK] - Ff(g, 2, 0)[m]);
+  }
+  correct_face<NS, 0, GRAV>(g, m, i, j, k, q);
+  correct_face<NS, 1, GRAV>(g, m, i, j, k, q);
+  correct_face<NS, 2, GRAV>(g, m, i, j, k, q);
+}
+
+// ---- steps 9b-d: second-pass fluxes with the H-correction -----------------------------------
+template <int NS, int D>
+__global__ void __launch_bounds__(256)
+k_flux2(DevGrid g)
+{
+  // faces needed by the update: along D [s, e+1], transverse [s, e]
+  const int ni = g.ie - g.is + 1 + (D == 0), nj = g.je - g.js + 1 + (D == 1), nk = g.ke - g.ks + 1 + (D == 2);
+  const long lin = (long)blockIdx.x*blockDim.x + threadIdx.x;
+  if (lin >= (long)ni*nj*nk) return;
+  const int i = g.is + (int)(lin % ni);
+  const int j = g.js + (int)((lin / ni) % nj);
+  const int k = g.ks + (int)(lin / ((long)ni*nj));
+  const long m = (long)k*g.sK + (long)j*g.sJ + i;
+  const long sD = stride<D>(g), ml = m - sD;
+  // the reference's MAX chain (a > b ? a : b) visits the two transverse directions in
+  // ASCENDING order, then the face's own eta (:2354-2363, :2383-2392, :2412-2421); the order
+  // matters when an eta is NaN (negative face pressure)
+  constexpr int E1 = (D == 0) ? 1 : 0, E2 = (D == 2) ? 1 : 2;
+  const long s1 = stride<E1>(g), s2 = stride<E2>(g);
+  const Real *e1 = Ef(g, E1), *e2 = Ef(g, E2);
+  Real etah = rmax(e1[ml], e1[m]);
+  etah = rmax(etah, e1[ml + s1]);
+  etah = rmax(etah, e1[m + s1]);
+  etah = rmax(etah, e2[ml]);
+  etah = rmax(etah, e2[m]);
+  etah = rmax(etah, e2[ml + s2]);
+  etah = rmax(etah, e2[m + s2]);
+  etah = rmax(etah, Ef(g, D)[m]);
+  Real ul[6], ur[6], wl[6], wr[6], f[6];
+  load_sweep<D, NS>(LRf(g, D, 0, 0), g.nc, m, ul);
+  load_sweep<D, NS>(LRf(g, D, 1, 0), g.nc, m, ur);
+  cons_to_prim<NS>(ul, wl, g.Gamma_1);
+  cons_to_prim<NS>(ur, wr, g.Gamma_1);
+  flux_roe<NS>(ul, ur, wl, wr, etah, g.Gamma, g.Gamma_1, f);
+  store_sweep<D, NS>(Ff(g, D, 0), g.nc, m, f);
+}
+
+// ---- steps 11a, 12: gravity source and conservative update ---------------------------------
+template <int NS, bool GRAV>
+__global__ void __launch_bounds__(256)
+k_update(DevGrid g, Real dt)
+{
+  const int ni = g.ie - g.is + 1, nj = g.je - g.js + 1, nk = g.ke - g.ks + 1;
+  const long lin = (long)blockIdx.x*blockDim.x + threadIdx.x;
+  if (lin >= (long)ni*nj*nk) return;
+  const int i = g.is + (int)(lin % ni);
+  const int j = g.js + (int)((lin / ni) % nj);
+  const int k = g.ks + (int)(lin / ((long)ni*nj));
+  const long m = (long)k*g.sK + (long)j*g.sJ + i;
+  constexpr int NV = 5 + NS;
+  Real u[6];
+#pragma unroll
+  for (int v = 0; v < NV; v++) u[v] = Uf(g, v)[m];
+  Real dtodx[3];
+#pragma unroll
+  for (int d = 0; d < 3; d++) dtodx[d] = dt/g.dx[d];
+  if (GRAV) {   // :2741-2782
+    const Real phic = Pf(g, 0)[m], dh = g.dhalf[m];
+#pragma unroll
+    for (int e = 0; e < 3; e++) {
+      const long se = stride_rt(g, e);
+      const Real phir = Pf(g, 1 + e)[m + se], phil = Pf(g, 1 + e)[m];
+      const Real *fd = Ff(g, e, 0);
+      u[1 + e] -= dtodx[e]*(phir - phil)*dh;
+      u[4] -= dtodx[e]*(fd[m]*(phic - phil) + fd[m + se]*(phir - phic));
+    }
+  }
+#pragma unroll
+  for (int d = 0; d < 3; d++) {   // :2981-3050, x1 then x2 then x3
+    const long sd = stride_rt(g, d);
+#pragma unroll
+    for (int v = 0; v < NV; v++) { const Real *f = Ff(g, d, v); u[v] -= dtodx[d]*(f[m + sd] - f[m]); }
+  }
+#pragma unroll
+  for (int v = 0; v < NV; v++) Uf(g, v)[m] = u[v];
+}
+
+// ---- physical boundary conditions: bvals_mhd.c reflect :959, outflow :1319, periodic :1637 ---
+// dir d, side 0/1; transverse extents: x1 -> active j,k; x2 -> all i, active k; x3 -> all i,j.
+__global__ void k_bc(DevGrid g, int nvar, int d, int side, int flag)
+{
+  const int lo3[3] = {g.is, g.js, g.ks}, hi3[3] = {g.ie, g.je, g.ke}, N[3] = {g.N1, g.N2, g.N3};
+  int r0[3], n[3];
+  for (int a = 0; a < 3; a++) {
+    if (a == d) { r0[a] = 0; n[a] = AA_NGHOST_; continue; }
+    if (a < d) { r0[a] = 0; n[a] = N[a]; } else { r0[a] = lo3[a]; n[a] = hi3[a] - lo3[a] + 1; }
+  }
+  const long lin = (long)blockIdx.x*blockDim.x + threadIdx.x;
+  if (lin >= (long)n[0]*n[1]*n[2]) return;
+  int idx[3];
+  idx[0] = r0[0] + (int)(lin % n[0]);
+  idx[1] = r0[1] + (int)((lin / n[0]) % n[1]);
+  idx[2] = r0[2] + (int)(lin / ((long)n[0]*n[1]));
+  const int gl = idx[d] + 1;                                    // ghost layer 1..4
+  int dst, src;
+  if (side == 0) { dst = lo3[d] - gl; src = (flag == 1) ? lo3[d] + (gl - 1) : (flag == 2) ? lo3[d] : hi3[d] - (gl - 1); }
+  else           { dst = hi3[d] + gl; src = (flag == 1) ? hi3[d] - (gl - 1) : (flag == 2) ? hi3[d] : lo3[d] + (gl - 1); }
+  idx[d] = 0;
+  const long base = (long)idx[2]*g.sK + (long)idx[1]*g.sJ + idx[0];
+  const long sd = stride_rt(g, d);
+  for (int v = 0; v < nvar; v++) {
+    Real x = Uf(g, v)[base + src*sd];
+    if (flag == 1 && v == 1 + d) x = -x;
+    Uf(g, v)[base + dst*sd] = x;
+  }
+}
+
+// ---- CFL reduction: new_dt.c:72-170 -----------------------------------------------------
+AA_DEV void atomic_max_pos(unsigned long long *addr, Real v)
+{ if (v == v) atomicMax(addr, (unsigned long long)__double_as_longlong(v)); }   // v >= 0; NaN skipped
+
+__global__ void __launch_bounds__(256)
+k_cfl(DevGrid g, DevScalars *sc)
+{
+  const int ni = g.ie - g.is + 1, nj = g.je - g.js + 1, nk = g.ke - g.ks + 1;
+  const long ntot = (long)ni*nj*nk;
+  Real mx[3] = {0.0, 0.0, 0.0};
+  for (long lin = (long)blockIdx.x*blockDim.x + threadIdx.x; lin < ntot; lin += (long)gridDim.x*blockDim.x) {
+    const int i = g.is + (int)(lin % ni);
+    const int j = g.js + (int)((lin / ni) % nj);
+    const int k = g.ks + (int)(lin / ((long)ni*nj));
+    const long m = (long)k*g.sK + (long)j*g.sJ + i;
+    Real d = Uf(g, 0)[m], di = 1.0/d;
+    Real v1 = Uf(g, 1)[m]*di, v2 = Uf(g, 2)[m]*di, v3 = Uf(g, 3)[m]*di;
+    Real qsq = v1*v1 + v2*v2 + v3*v3;
+    Real p = rmax(g.Gamma_1*(Uf(g, 4)[m] - 0.5*d*qsq), AA_TINY);
+    Real a = sqrt(g.Gamma*p*di);
+    mx[0] = rmax(mx[0], fabs(v1) + a); mx[1] = rmax(mx[1], fabs(v2) + a); mx[2] = rmax(mx[2], fabs(v3) + a);
+  }
+  __shared__ Real red[3][256];
+  for (int d = 0; d < 3; d++) red[d][threadIdx.x] = mx[d];
+  __syncthreads();
+  for (int s = blockDim.x/2; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) for (int d = 0; d < 3; d++) red[d][threadIdx.x] = rmax(red[d][threadIdx.x], red[d][threadIdx.x + s]);
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) for (int d = 0; d < 3; d++) atomic_max_pos(&sc->max_v[d], red[d][0]);
+}
+
+// ---- layout conversion, pinned cells, x3 halo pack/unpack ----------------------------------
+__global__ void k_aos_to_soa(DevGrid g, int nvar, const Real *aos)
+{
+  const long lin = (long)blockIdx.x*blockDim.x + threadIdx.x;
+  const long ntot = (long)g.N1*g.N2*g.N3;
+  if (lin >= ntot) return;
+  const int i = (int)(lin % g.N1), j = (int)((lin / g.N1) % g.N2), k = (int)(lin / ((long)g.N1*g.N2));
+  const long m = (long)k*g.sK + (long)j*g.sJ + i;
+  for (int v = 0; v < nvar; v++) Uf(g, v)[m] = aos[lin*nvar + v];
+}
+__global__ void k_soa_to_aos(DevGrid g, int nvar, Real *aos)
+{
+  const long lin = (long)blockIdx.x*blockDim.x + threadIdx.x;
+  const long ntot = (long)g.N1*g.N2*g.N3;
+  if (lin >= ntot) return;
+  const int i = (int)(lin % g.N1), j = (int)((lin / g.N1) % g.N2), k = (int)(lin / ((long)g.N1*g.N2));
+  const long m = (long)k*g.sK + (long)j*g.sJ + i;
+  for (int v = 0; v < nvar; v++) aos[lin*nvar + v] = Uf(g, v)[m];
+}
+__global__ void k_pinned(DevGrid g, int nvar, long long n, const long long *idx, const Real *vals)
+{
+  const long lin = (long)blockIdx.x*blockDim.x + threadIdx.x;
+  if (lin >= n) return;
+  const long long c = idx[lin];                       // linear [k][j][i] index of the host block
+  const int i = (int)(c % g.N1), j = (int)((c / g.N1) % g.N2), k = (int)(c / ((long)g.N1*g.N2));
+  const long m = (long)k*g.sK + (long)j*g.sJ + i;
+  for (int v = 0; v < nvar; v++) Uf(g, v)[m] = vals[lin*nvar + v];
+}
+// 4 k-planes starting at k0, all i and j (x3 is exchanged last, so corners travel: bvals_mhd.c:170)
+// buffer layout [v][kk][j][i]
+__global__ void k_pack_x3(DevGrid g, int nvar, int k0, Real *buf)
+{
+  const long plane = (long)g.N1*g.N2, ntot = plane*AA_NGHOST_;
+  const long lin = (long)blockIdx.x*blockDim.x + threadIdx.x;
+  if (lin >= ntot) return;
+  const int i = (int)(lin % g.N1), j = (int)((lin / g.N1) % g.N2), kk = (int)(lin / plane);
+  const long m = (long)(k0 + kk)*g.sK + (long)j*g.sJ + i;
+  for (int v = 0; v < nvar; v++) buf[(long)v*ntot + lin] = Uf(g, v)[m];
+}
+__global__ void k_unpack_x3(DevGrid g, int nvar, int k0, const Real *buf)
+{
+  const long plane = (long)g.N1*g.N2, ntot = plane*AA_NGHOST_;
+  const long lin = (long)blockIdx.x*blockDim.x + threadIdx.x;
+  if (lin >= ntot) return;
+  const int i = (int)(lin % g.N1), j = (int)((lin / g.N1) % g.N2), kk = (int)(lin / plane);
+  const long m = (long)(k0 + kk)*g.sK + (long)j*g.sJ + i;
+  for (int v = 0; v < nvar; v++) Uf(g, v)[m] = buf[(long)v*ntot + lin];
+}
+
+// ---- function-level test kernels ------------------------------------------------------------
+template <int NS>
+__global__ void k_test_fluxes(Real Gamma, int n, const Real *Ul, const Real *Ur, const Real *eta, Real *F)
+{
+  const int t = blockIdx.x*blockDim.x + threadIdx.x;
+  if (t >= n) return;
+  constexpr int NV = 5 + NS;
+  Real ul[6] = {0, 0, 0, 0, 0, 0}, ur[6] = {0, 0, 0, 0, 0, 0}, wl[6], wr[6], f[6];
+  for (int v = 0; v < NV; v++) { ul[v] = Ul[(long)t*NV + v]; ur[v] = Ur[(long)t*NV + v]; }
+  cons_to_prim<NS>(ul, wl, Gamma - 1.0); cons_to_prim<NS>(ur, wr, Gamma - 1.0);
+  flux_roe<NS>(ul, ur, wl, wr, eta[t], Gamma, Gamma - 1.0, f);
+  for (int v = 0; v < NV; v++) F[(long)t*NV + v] = f[v];
+}
+template <int NS>
+__global__ void k_test_lr(Real Gamma, int n, const Real *W, Real dt, Real dx, int il, int iu, Real *Wl, Real *Wr)
+{
+  const int c = il - 1 + blockIdx.x*blockDim.x + threadIdx.x;     // cells il-1 .. iu+1
+  if (c > iu + 1) return;
+  constexpr int NV = 5 + NS;
+  Real wm[6] = {0, 0, 0, 0, 0, 0}, w[6] = {0, 0, 0, 0, 0, 0}, wp[6] = {0, 0, 0, 0, 0, 0}, a[6], b[6];
+  for (int v = 0; v < NV; v++) { wm[v] = W[(long)(c - 1)*NV + v]; w[v] = W[(long)c*NV + v]; wp[v] = W[(long)(c + 1)*NV + v]; }
+  plm_cell<NS, true>(wm, w, wp, dt/dx, Gamma, a, b);
+  for (int v = 0; v < NV; v++) { Wl[(long)(c + 1)*NV + v] = a[v]; Wr[(long)c*NV + v] = b[v]; }
+}
+
+// =============================================================================================
+// host-side launchers
+// =============================================================================================
+static inline unsigned nblk(long n, int b) { return (unsigned)((n + b - 1)/b); }
+
+template <int NS, bool GRAV>
+static void sweep_impl(const DevGrid &g, int dir, Real dt, hipStream_t st)
+{
+  if (dir == 0) {
+    const int nfaces = (g.ie - g.is + 1) + 3;          // interfaces l+1..u
+    int nb = (nfaces + 254)/255;
+    int B = (nfaces + nb - 1)/nb + 1;                  // B-1 interfaces per block
+    B = ((B + 63)/64)*64; if (B > 256) B = 256;
+    nb = (nfaces + (B - 1) - 1)/(B - 1);
+    dim3 grid(nb, g.je - g.js + 5, g.ke - g.ks + 5);
+    size_t lds = (size_t)(5 + NS)*(B + 2)*sizeof(Real);
+    hipLaunchKernelGGL((k_sweep_x1<NS, GRAV>), grid, dim3(B), lds, st, g, dt);
+  } else {
+    const int chunk = 32;
+    const long ni = g.ie - g.is + 5;
+    const long nt = (dir == 1 ? g.ke - g.ks : g.je - g.js) + 5;
+    const int nfaces = (dir == 1 ? g.je - g.js : g.ke - g.ks) + 1 + 3;
+    dim3 grid(nblk(ni*nt, 64), (nfaces + chunk - 1)/chunk);
+    if (dir == 1) hipLaunchKernelGGL((k_sweep_march<NS, 1, GRAV>), grid, dim3(64), 0, st, g, dt, chunk);
+    else          hipLaunchKernelGGL((k_sweep_march<NS, 2, GRAV>), grid, dim3(64), 0, st, g, dt, chunk);
+  }
+}
+void launch_sweep(const DevGrid &g, int nscal, int dir, Real dt, bool grav, hipStream_t st)
+{
+  if (nscal) { if (grav) sweep_impl<1, true>(g, dir, dt, st); else sweep_impl<1, false>(g, dir, dt, st); }
+  else       { if (grav) sweep_impl<0, true>(g, dir, dt, st); else sweep_impl<0, false>(g, dir, dt, st); }
+}
+
+void launch_correct(const DevGrid &g, int nscal, Real dt, bool grav, hipStream_t st)
+{
+  const long n = (long)(g.ie - g.is + 4)*(g.je - g.js + 4)*(g.ke - g.ks + 4);
+  dim3 grid(nblk(n, 256)), blk(256);
+  if (nscal) { if (grav) hipLaunchKernelGGL((k_correct<1, true>), grid, blk, 0, st, g, dt);
+               else      hipLaunchKernelGGL((k_correct<1, false>), grid, blk, 0, st, g, dt); }
+  else       { if (grav) hipLaunchKernelGGL((k_correct<0, true>), grid, blk, 0, st, g, dt);
+               else      hipLaunchKernelGGL((k_correct<0, false>), grid, blk, 0, st, g, dt); }
+}
+
+template <int NS>
+static void flux2_impl(const DevGrid &g, int dir, hipStream_t st)
+{
+  const long n = (long)(g.ie - g.is + 1 + (dir == 0))*(g.je - g.js + 1 + (dir == 1))*(g.ke - g.ks + 1 + (dir == 2));
+  dim3 grid(nblk(n, 256)), blk(256);
+  if (dir == 0) hipLaunchKernelGGL((k_flux2<NS, 0>), grid, blk, 0, st, g);
+  else if (dir == 1) hipLaunchKernelGGL((k_flux2<NS, 1>), grid, blk, 0, st, g);
+  else hipLaunchKernelGGL((k_flux2<NS, 2>), grid, blk, 0, st, g);
+}
+void launch_flux2(const DevGrid &g, int nscal, int dir, hipStream_t st)
+{ if (nscal) flux2_impl<1>(g, dir, st); else flux2_impl<0>(g, dir, st); }
+
+void launch_update(const DevGrid &g, int nscal, Real dt, bool grav, hipStream_t st)
+{
+  const long n = (long)(g.ie - g.is + 1)*(g.je - g.js + 1)*(g.ke - g.ks + 1);
+  dim3 grid(nblk(n, 256)), blk(256);
+  if (nscal) { if (grav) hipLaunchKernelGGL((k_update<1, true>), grid, blk, 0, st, g, dt);
+               else      hipLaunchKernelGGL((k_update<1, false>), grid, blk, 0, st, g, dt); }
+  else       { if (grav) hipLaunchKernelGGL((k_update<0, true>), grid, blk, 0, st, g, dt);
+               else      hipLaunchKernelGGL((k_update<0, false>), grid, blk, 0, st, g, dt); }
+}
+
+void launch_bc(const DevGrid &g, int nscal, int dir, int side, int flag, hipStream_t st)
+{
+  const int lo3[3] = {g.is, g.js, g.ks}, hi3[3] = {g.ie, g.je, g.ke}, N[3] = {g.N1, g.N2, g.N3};
+  long n = 1;
+  for (int a = 0; a < 3; a++) n *= (a == dir) ? 4 : (a < dir ? N[a] : hi3[a] - lo3[a] + 1);
+  hipLaunchKernelGGL(k_bc, dim3(nblk(n, 256)), dim3(256), 0, st, g, 5 + nscal, dir, side, flag);
+}
+
+void launch_cfl(const DevGrid &g, DevScalars *sc, hipStream_t st)
+{
+  const long n = (long)(g.ie - g.is + 1)*(g.je - g.js + 1)*(g.ke - g.ks + 1);
+  unsigned nb = nblk(n, 256); if (nb > 4096) nb = 4096;
+  hipLaunchKernelGGL(k_cfl, dim3(nb), dim3(256), 0, st, g, sc);
+}
+
+void launch_aos_to_soa(const DevGrid &g, int nvar, const Real *aos, hipStream_t st)
+{ const long n = (long)g.N1*g.N2*g.N3; hipLaunchKernelGGL(k_aos_to_soa, dim3(nblk(n, 256)), dim3(256), 0, st, g, nvar, aos); }
+void launch_soa_to_aos(const DevGrid &g, int nvar, Real *aos, hipStream_t st)
+{ const long n = (long)g.N1*g.N2*g.N3; hipLaunchKernelGGL(k_soa_to_aos, dim3(nblk(n, 256)), dim3(256), 0, st, g, nvar, aos); }
+void launch_pinned(const DevGrid &g, int nvar, long long n, const long long *idx, const Real *vals, hipStream_t st)
+{ if (n > 0) hipLaunchKernelGGL(k_pinned, dim3(nblk(n, 256)), dim3(256), 0, st, g, nvar, n, idx, vals); }
+void launch_pack_x3(const DevGrid &g, int nvar, int k0, Real *buf, hipStream_t st)
+{ const long n = (long)g.N1*g.N2*4; hipLaunchKernelGGL(k_pack_x3, dim3(nblk(n, 256)), dim3(256), 0, st, g, nvar, k0, buf); }
+void launch_unpack_x3(const DevGrid &g, int nvar, int k0, const Real *buf, hipStream_t st)
+{ const long n = (long)g.N1*g.N2*4; hipLaunchKernelGGL(k_unpack_x3, dim3(nblk(n, 256)), dim3(256), 0, st, g, nvar, k0, buf); }
+
+void launch_test_fluxes(int nscal, Real gamma, int n, const Real *Ul, const Real *Ur, const Real *eta, Real *F, hipStream_t st)
+{
+  if (nscal) hipLaunchKernelGGL((k_test_fluxes<1>), dim3(nblk(n, 128)), dim3(128), 0, st, gamma, n, Ul, Ur, eta, F);
+  else       hipLaunchKernelGGL((k_test_fluxes<0>), dim3(nblk(n, 128)), dim3(128), 0, st, gamma, n, Ul, Ur, eta, F);
+}
+void launch_test_lr(int nscal, Real gamma, int n, const Real *W, Real dt, Real dx, int il, int iu, Real *Wl, Real *Wr, hipStream_t st)
+{
+  (void)n;
+  const int nc = iu - il + 3;
+  if (nscal) hipLaunchKernelGGL((k_test_lr<1>), dim3(nblk(nc, 128)), dim3(128), 0, st, gamma, n, W, dt, dx, il, iu, Wl, Wr);
+  else       hipLaunchKernelGGL((k_test_lr<0>), dim3(nblk(nc, 128)), dim3(128), 0, st, gamma, n, W, dt, dx, il, iu, Wl, Wr);
+}
+
+}  // namespace aa

@@ -1,0 +1,340 @@
+// ion_kernels.hip -- plane-parallel ionizing-radiation step (ionradiation/ionrad_3d.c,
+// ionradplane_3d.c, ionrad_chemistry.c) as HIP kernels for gfx950.
+//
+// One radiation sub-cycle = three kernels:
+//   ray_sweep   get_ph_rate_plane (ionradplane_3d.c:88): every (j,k) ray is an exclusive prefix
+//               product of exp(-tau) along x1 with a data-dependent cut-off.  A block stages a
+//               64-ray x 64-cell tile: all 256 threads evaluate exp(-tau) (the expensive part)
+//               with coalesced loads, then one wavefront -- one lane per ray -- carries the
+//               product serially through LDS in exactly the reference's multiplication order,
+//               then all threads turn the staged incoming fluxes into ph_rate / EdgeFlux with
+//               coalesced stores.  The flux is carried across tiles in LDS; a block whose rays
+//               are all extinguished only streams zeros.
+//   ion_rates   compute_chem_rates + compute_therm_rates (:288, :414) fused, block MIN -> atomics
+//   ion_update  ionization_update + apply_temp_floor + apply_neutral_floor + check_range +
+//               compute_dt_hydro (:565, :70, :140, :206, :593) fused: one read-modify-write pass
+// HBM-bound integer-free FP64 streaming; no MFMA.
+#include <float.h>
+#include "grid.h"
+#include "hydro_dev.h"
+
+namespace aa {
+
+#define MINFLUXFRAC 1.0e-3    /* ionrad.h:26 */
+#define IONFRACFLOOR 1.0e-4   /* :31 */
+#define CION 8.0e5            /* :36 */
+#define MAXSIGNCOUNT 4        /* ionrad_3d.c:286 */
+#define DAMPFACTOR 0.5        /* :287 */
+#define KB_CHEM 1.38e-16      /* ionrad_chemistry.c:43 */
+
+AA_DEV Real *Uq(const DevGrid &g, int v) { return g.U + (long)v*g.nc; }
+
+struct CellState { Real d, M1, M2, M3, E, s; };
+struct IonQ { Real n_H, n_Hplus, n_e, x, ke, e_th, T; };
+
+AA_DEV CellState load_cell(const DevGrid &g, long m)
+{ CellState c; c.d = Uq(g,0)[m]; c.M1 = Uq(g,1)[m]; c.M2 = Uq(g,2)[m]; c.M3 = Uq(g,3)[m]; c.E = Uq(g,4)[m]; c.s = Uq(g,5)[m]; return c; }
+
+// ionrad_3d.c:82-101 (same expressions are repeated at :313-331 and :438-456)
+AA_DEV IonQ ion_q(const CellState &c, const IonPar &p, Real Gamma_1)
+{
+  IonQ q;
+  q.n_H = c.s / p.m_H;
+  q.n_Hplus = (c.d - c.s) / p.m_H;
+  q.n_e = q.n_Hplus + c.d * p.alpha_C / (14.0 * p.m_H);
+  q.x = q.n_e / (q.n_H + q.n_Hplus);
+  q.ke = 0.5 * (c.M1*c.M1 + c.M2*c.M2 + c.M3*c.M3) / c.d;
+  q.e_th = c.E - q.ke;
+  Real e_sp = q.e_th / c.d;
+  q.T = Gamma_1 * e_sp * (q.x*0.5*p.m_H+(1.0-q.x)*p.mu)/ p.k_B;
+  return q;
+}
+
+AA_DEV Real neutral_lim(Real d, const IonPar &p)   // ionrad_3d.c:147-148
+{ Real d_nlim = d*IONFRACFLOOR; return d_nlim < p.d_nlo ? d_nlim : p.d_nlo; }
+
+// apply_temp_floor (:70-131) then apply_neutral_floor (:140-156) on one cell
+AA_DEV void floors(CellState &c, const IonPar &p, Real Gamma_1)
+{
+  IonQ q = ion_q(c, p, Gamma_1);
+  if (q.T < p.tfloor) {
+    Real e_sp = p.tfloor * p.k_B / ((q.x*0.5*p.m_H+(1.0-q.x)*p.mu) * Gamma_1);
+    c.E = 0.5 * (c.M1*c.M1 + c.M2*c.M2 + c.M3*c.M3) / c.d + e_sp * c.d;
+  }
+  if ((q.T > p.tceil) && (p.tceil > 0)) {
+    Real e_sp = p.tceil * p.k_B / ((q.x*0.5*p.m_H+(1.0-q.x)*p.mu) * Gamma_1);
+    c.E = 0.5 * (c.M1*c.M1 + c.M2*c.M2 + c.M3*c.M3) / c.d + e_sp * c.d;
+  }
+  Real d_nlim = neutral_lim(c.d, p);
+  if (c.s < d_nlim) c.s = d_nlim; else if (c.s > c.d) c.s = c.d;
+}
+
+AA_DEV bool active_cell(const DevGrid &g, long lin, long &m)
+{
+  const int ni = g.Nx1, nj = g.Nx2;
+  if (lin >= (long)ni*nj*g.Nx3) return false;
+  const int i = g.is + (int)(lin % ni), j = g.js + (int)((lin / ni) % nj), k = g.ks + (int)(lin / ((long)ni*nj));
+  m = (long)k*g.sK + (long)j*g.sJ + i;
+  return true;
+}
+
+// ---- entry of ion_radtransfer_3d: floors + save_energy_and_x (:896-905, :162-196) -------------
+__global__ void __launch_bounds__(256)
+k_ion_begin(DevGrid g, IonPar p)
+{
+  long m;
+  if (!active_cell(g, (long)blockIdx.x*blockDim.x + threadIdx.x, m)) return;
+  CellState c = load_cell(g, m);
+  const Real E0 = c.E, s0 = c.s;
+  floors(c, p, g.Gamma_1);
+  if (c.E != E0) Uq(g,4)[m] = c.E;
+  if (c.s != s0) Uq(g,5)[m] = c.s;
+  IonQ q = ion_q(c, p, g.Gamma_1);
+  g.e_init[m] = c.E;
+  g.e_th_init[m] = c.E - 0.5 * (c.M1*c.M1 + c.M2*c.M2 + c.M3*c.M3) / c.d;
+  g.x_init[m] = q.n_e / (q.n_H + q.n_Hplus);
+  g.sign[m] = make_int2(0, 0);
+}
+
+// ---- ray sweep --------------------------------------------------------------------------------
+#define RS_RAYS 64
+#define RS_CH 64
+__global__ void __launch_bounds__(256)
+k_ray_sweep(DevGrid g, IonPar p, Real flux0)
+{
+  __shared__ Real s_etau[RS_RAYS][RS_CH + 1];
+  __shared__ Real s_fin[RS_RAYS][RS_CH + 1];
+  __shared__ Real s_flux[RS_RAYS];
+  __shared__ int  s_dead[RS_RAYS];
+  __shared__ int  s_nalive;
+  const int tid = threadIdx.x;
+  const int j0 = g.js + blockIdx.x*RS_RAYS;                 // rays: 64 consecutive j at one k
+  const int k = g.ks + blockIdx.y;
+  const int nrays = min(RS_RAYS, g.je - j0 + 1);
+  const int col = tid & 63, rsub = tid >> 6;                 // 4 ray-rows per pass, 16 passes
+  const long efp = (long)(g.Nx1 + 1), efrow = (long)(g.Nx2 + 1)*efp;
+  if (tid < RS_RAYS) { s_flux[tid] = flux0; s_dead[tid] = (tid < nrays) ? 0 : 1; }
+  if (tid == 0) s_nalive = nrays;
+  __syncthreads();
+  for (int c0 = g.is; c0 <= g.ie; c0 += RS_CH) {
+    const int i = c0 + col;
+    const bool incol = (i <= g.ie);
+    const int ncol = min(RS_CH, g.ie - c0 + 1);
+    const bool alive = (s_nalive > 0);                        // block-uniform
+    Real nH[RS_RAYS/4];
+    if (alive) {
+#pragma unroll
+      for (int q = 0; q < RS_RAYS/4; q++) {
+        const int r = rsub + 4*q;
+        nH[q] = 1.0;
+        if (incol && r < nrays) {
+          const long m = (long)k*g.sK + (long)(j0 + r)*g.sJ + i;
+          const Real n_H = Uq(g,5)[m] / p.m_H;                // ionradplane_3d.c:281
+          const Real tau = p.sigma_ph * n_H * g.dx[0];        // :294
+          nH[q] = n_H;
+          s_etau[r][col] = exp(-tau);
+        }
+      }
+    }
+    __syncthreads();
+    if (alive && tid < nrays) {                               // one lane per ray: serial product
+      const int r = tid;
+      Real flux = s_flux[r]; int dead = s_dead[r];
+      for (int cc = 0; cc < ncol; cc++) {
+        if (dead) { s_fin[r][cc] = 0.0; continue; }
+        s_fin[r][cc] = flux;                                  // EdgeFlux[..][i-s] = flux  (:279)
+        flux *= s_etau[r][cc];                                // :298
+        const Real flux_frac = flux / (flux0 + 1e-12);        // :299
+        if (flux_frac < MINFLUXFRAC) { dead = 1; flux = 0.0; atomicSub(&s_nalive, 1); }   // :300-306
+      }
+      s_flux[r] = flux; s_dead[r] = dead;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < RS_RAYS/4; q++) {
+      const int r = rsub + 4*q;
+      if (incol && r < nrays) {
+        const long m = (long)k*g.sK + (long)(j0 + r)*g.sJ + i;
+        Real kph = 0.0, fin = 0.0;
+        if (alive) {
+          fin = s_fin[r][col];
+          kph = fin * (1.0 - s_etau[r][col]) / (nH[q]*g.dx[0]);   // :296
+        }
+        g.ph_rate[m] = kph;                                   // ph_rate_init + "+=" (:55, :297)
+        g.edgeflux[(long)(k - g.ks)*efrow + (long)(j0 + r - g.js)*efp + (i - g.is)] = fin;
+      }
+    }
+    __syncthreads();
+  }
+  if (tid < nrays)                                            // :308
+    g.edgeflux[(long)(k - g.ks)*efrow + (long)(j0 + tid - g.js)*efp + g.Nx1] = s_dead[tid] ? 0.0 : s_flux[tid];
+}
+
+// bvals_ionrad.c:63 / outflow_flux_ix1 :308: EdgeFlux[k][j][0] = flux_i for k<=Nx3, j<=Nx2
+__global__ void k_edgeflux_bc(DevGrid g, Real flux_i)
+{
+  const long lin = (long)blockIdx.x*blockDim.x + threadIdx.x;
+  const long n = (long)(g.Nx2 + 1)*(g.Nx3 + 1);
+  if (lin >= n) return;
+  g.edgeflux[lin*(long)(g.Nx1 + 1)] = flux_i;
+}
+
+// ---- rates ------------------------------------------------------------------------------------
+AA_DEV void block_min_to(unsigned long long *addr, Real v, Real *red)
+{
+  red[threadIdx.x] = v;
+  __syncthreads();
+  for (int s = blockDim.x/2; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) red[threadIdx.x] = rmin(red[threadIdx.x], red[threadIdx.x + s]);
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) atomicMin(addr, (unsigned long long)__double_as_longlong(red[0]));
+  __syncthreads();
+}
+
+__global__ void __launch_bounds__(256)
+k_ion_rates(DevGrid g, IonPar p, DevScalars *sc)
+{
+  __shared__ Real red[256];
+  long m;
+  Real dt_chem = DBL_MAX, dt_therm = DBL_MAX;
+  if (active_cell(g, (long)blockIdx.x*blockDim.x + threadIdx.x, m)) {
+    const CellState c = load_cell(g, m);
+    const IonQ q = ion_q(c, p, g.Gamma_1);
+    const Real ph = g.ph_rate[m];
+    // compute_chem_rates, ionrad_3d.c:334-394
+    Real T = q.T; if (T < p.tfloor) T = p.tfloor;
+    Real nHdot = 2.59e-13*pow(T/1.0e4, -0.7) * p.time_unit * q.n_e * q.n_Hplus - ph * q.n_H;   // chemistry :111
+    int2 sg = g.sign[m];
+    if (nHdot < 0.0) {
+      if (sg.x == 1) sg.y++; else if (sg.y > 0) sg.y--;
+      sg.x = -1;
+    } else if (nHdot > 0.0) {
+      if (sg.x == -1) sg.y++; else if (sg.y > 0) sg.y--;
+      sg.x = 1;
+    } else { sg.x = 0; sg.y = 0; }
+    g.sign[m] = sg;
+    for (int n = MAXSIGNCOUNT; n < sg.y; n++) nHdot *= DAMPFACTOR;
+    g.nHdot[m] = nHdot;
+    const Real d_nlim = neutral_lim(c.d, p);
+    Real dt1, dt2;
+    if (nHdot == 0.0) { dt1 = dt2 = DBL_MAX; }
+    else if (nHdot > 0.0) {
+      dt1 = p.max_dx_iter / (1+p.max_dx_iter) * q.n_e / nHdot;
+      dt2 = p.max_dx_iter * q.n_H / nHdot;
+    } else if (c.s > 1.0001*d_nlim) {
+      dt1 = -p.max_dx_iter * q.n_e / nHdot;
+      dt2 = -p.max_dx_iter / (1+p.max_dx_iter) * q.n_H / nHdot;
+    } else { dt1 = dt2 = DBL_MAX; }
+    dt_chem = (dt1 < dt2) ? dt1 : dt2;
+    if (dt_chem < 0) { atomicExch(&sc->neg_dt_chem, 1); dt_chem = DBL_MAX; }
+    // compute_therm_rates, :460-557 (uses the un-floored T)
+    Real edot = 0.0;
+    bool skip = (q.T < p.tfloor) || ((nHdot < 0) && (c.s < 1.0001*d_nlim));
+    if (!skip) {
+      const Real Tt = q.T;
+      const Real rcool = (Tt < 100.0) ? 0.0 : 6.11e-10*pow(Tt,-0.89)*KB_CHEM*Tt;          // chemistry :137
+      const Real lya = -7.5e-19*q.n_e*q.n_H*exp(-118348/Tt);                               // :350, call at ionrad_3d.c:484
+      edot = ph * p.e_gamma * q.n_H - rcool * p.time_unit * q.n_Hplus * q.n_e + lya * p.time_unit;
+      Real t1, t2; bool have = true;
+      if (edot == 0.0) { t1 = t2 = DBL_MAX; }
+      else if (edot > 0.0) {
+        t1 = p.max_de_iter * c.E / edot;
+        t2 = p.max_de_therm_iter * q.e_th / edot;
+      } else {
+        const Real e_sp_min = p.tfloor * p.k_B / ((q.x*0.5*p.m_H+(1.0-q.x)*p.mu) * g.Gamma_1);
+        const Real e_th_min = e_sp_min * c.d;
+        const Real e_min = 0.5 * (c.M1*c.M1 + c.M2*c.M2 + c.M3*c.M3) / c.d + e_th_min;
+        if ((q.e_th/(1.0+p.max_de_therm_iter) < e_th_min) && (c.E/(1.0+p.max_de_iter) < e_min)) have = false;
+        t1 = -p.max_de_iter / (1+p.max_de_iter) * c.E / edot;
+        t2 = -p.max_de_therm_iter / (1+p.max_de_therm_iter) * q.e_th / edot;
+      }
+      if (have) dt_therm = (t1 < t2) ? t1 : t2;
+    }
+    g.edot[m] = edot;
+  }
+  // dt values are > 0 (or +DBL_MAX): their bit patterns order like the values
+  if (!(dt_therm == dt_therm) || dt_therm < 0) dt_therm = DBL_MAX;
+  block_min_to(&sc->dt_chem, dt_chem, red);
+  block_min_to(&sc->dt_therm, dt_therm, red);
+}
+
+// ---- update + floors + range check + hydro CFL --------------------------------------------------
+__global__ void __launch_bounds__(256)
+k_ion_update(DevGrid g, IonPar p, Real dt, DevScalars *sc)
+{
+  __shared__ Real red[256];
+  __shared__ unsigned int cnt;
+  if (threadIdx.x == 0) cnt = 0;
+  __syncthreads();
+  long m;
+  Real dti = 0.0;
+  if (active_cell(g, (long)blockIdx.x*blockDim.x + threadIdx.x, m)) {
+    CellState c = load_cell(g, m);
+    const Real E0 = c.E, s0 = c.s;
+    const Real nHdot = g.nHdot[m];
+    const Real d_nlim = neutral_lim(c.d, p);
+    if ((nHdot > 0) || (c.s > 1.0001*d_nlim)) {          // ionization_update :577-585
+      c.E += g.edot[m] * dt;
+      c.s += nHdot * dt * p.m_H;
+    }
+    floors(c, p, g.Gamma_1);
+    if (c.E != E0) Uq(g,4)[m] = c.E;
+    if (c.s != s0) Uq(g,5)[m] = c.s;
+    // check_range :223-264
+    {
+      const Real n_H = c.s / p.m_H;
+      bool counted = false;
+      if (!(g.ph_rate[m] / (p.min_area * n_H) > 2.0*CION)) {
+        const Real e_thermal = c.E - 0.5 * (c.M1*c.M1 + c.M2*c.M2 + c.M3*c.M3) / c.d;
+        const Real eth0 = g.e_th_init[m], e0 = g.e_init[m];
+        if ((e_thermal / eth0 >= 1 + p.max_de_therm_step) || (eth0 / e_thermal >= 1 + p.max_de_therm_step)) counted = true;
+        else if ((p.max_de_step > 0) && ((c.E / e0 >= 1 + p.max_de_step) || (e0 / c.E >= 1 + p.max_de_step))) counted = true;
+        else if (p.max_dx_step > 0) {
+          const Real n_Hplus = (c.d - c.s) / p.m_H;
+          const Real n_e = n_Hplus + c.d * p.alpha_C / (14.0 * p.m_H);
+          const Real x = n_e / (n_H + n_Hplus), x0 = g.x_init[m];
+          if ((x / x0 >= 1 + p.max_dx_step) || (x0 / x >= 1 + p.max_dx_step)) counted = true;
+        }
+      }
+      if (counted) atomicAdd(&cnt, 1u);
+    }
+    // compute_dt_hydro :609-660
+    {
+      const Real di = 1.0/c.d, v1 = c.M1*di, v2 = c.M2*di, v3 = c.M3*di;
+      const Real qsq = v1*v1 + v2*v2 + v3*v3;
+      const Real pp = rmax(g.Gamma_1*(c.E - 0.5*c.d*qsq), AA_TINY);
+      const Real a = sqrt(g.Gamma*pp*di);
+      dti = rmax(dti, (fabs(v1) + a)/g.dx[0]);
+      dti = rmax(dti, (fabs(v2) + a)/g.dx[1]);
+      dti = rmax(dti, (fabs(v3) + a)/g.dx[2]);
+    }
+  }
+  if (!(dti == dti)) dti = 0.0;
+  red[threadIdx.x] = dti;
+  __syncthreads();
+  for (int s = blockDim.x/2; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) red[threadIdx.x] = rmax(red[threadIdx.x], red[threadIdx.x + s]);
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    atomicMax(&sc->max_dti, (unsigned long long)__double_as_longlong(red[0]));
+    if (cnt) atomicAdd(&sc->cellcount, (unsigned long long)cnt);
+  }
+}
+
+// =============================================================================================
+static inline unsigned nblk(long n, int b) { return (unsigned)((n + b - 1)/b); }
+
+void launch_ion_begin(const DevGrid &g, const IonPar &p, hipStream_t st)
+{ const long n = (long)g.Nx1*g.Nx2*g.Nx3; hipLaunchKernelGGL(k_ion_begin, dim3(nblk(n, 256)), dim3(256), 0, st, g, p); }
+void launch_ray_sweep(const DevGrid &g, const IonPar &p, Real flux0, hipStream_t st)
+{ hipLaunchKernelGGL(k_ray_sweep, dim3((g.Nx2 + RS_RAYS - 1)/RS_RAYS, g.Nx3), dim3(256), 0, st, g, p, flux0); }
+void launch_ion_rates(const DevGrid &g, const IonPar &p, DevScalars *sc, hipStream_t st)
+{ const long n = (long)g.Nx1*g.Nx2*g.Nx3; hipLaunchKernelGGL(k_ion_rates, dim3(nblk(n, 256)), dim3(256), 0, st, g, p, sc); }
+void launch_ion_update(const DevGrid &g, const IonPar &p, Real dt, DevScalars *sc, hipStream_t st)
+{ const long n = (long)g.Nx1*g.Nx2*g.Nx3; hipLaunchKernelGGL(k_ion_update, dim3(nblk(n, 256)), dim3(256), 0, st, g, p, dt, sc); }
+void launch_edgeflux_bc(const DevGrid &g, Real flux_i, hipStream_t st)
+{ const long n = (long)(g.Nx2 + 1)*(g.Nx3 + 1); hipLaunchKernelGGL(k_edgeflux_bc, dim3(nblk(n, 256)), dim3(256), 0, st, g, flux_i); }
+
+}  // namespace aa

@@ -1,0 +1,116 @@
+/* include/athena_amd.h -- C-ABI of the MI355X-native hot path of Atmospheric Athena.
+ *
+ * Plain C, plain pointers and sizes; no torch / HIP types in any signature (a HIP stream is
+ * passed as `void*`).  One `aa_grid` = one Grid of the reference (one slab of the root
+ * Domain, resident on one GPU).  Every entry point names the reference interface it
+ * replaces (paths under /root/reference/src).  All functions return 0 on success and a
+ * negative code on error; `aa_last_error()` returns the message the reference would have
+ * passed to ath_error() (utils.c:118).  Nothing here falls back to a CPU path: if the GPU
+ * or the library is missing, creation fails.
+ *
+ * Host-side state is exchanged in the reference's own layout: `GridS.U` is one contiguous
+ * block of ConsS {d,M1,M2,M3,E[,s0]} indexed [k][j][i] over Nx+2*nghost zones per direction
+ * (athena.h:81-100,:290; ath_array.c:78-120) and `GridS.EdgeFlux` is [Nx3+1][Nx2+1][Nx1+1]
+ * (init_grid.c:242-250).  On the device the state is struct-of-arrays.
+ */
+#ifndef ATHENA_AMD_H
+#define ATHENA_AMD_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum { AA_NGHOST = 4 };                     /* defs.h.in:129-140 */
+enum { AA_BC_NONE = 0, AA_BC_REFLECT = 1, AA_BC_OUTFLOW = 2, AA_BC_PERIODIC = 4 }; /* bvals_mhd.c:560-586 */
+
+typedef struct aa_params {
+  int    Nx[3];            /* active zones of this Grid (all > 1: 3-D only)                     */
+  int    rootNx[3];        /* active zones of the root Domain                                   */
+  double xmin[3], xmax[3]; /* root Domain extent; dx = (xmax-xmin)/rootNx (init_mesh.c:225)     */
+  double MinX[3];          /* lower edge of this Grid (init_grid.c:104-111)                     */
+  int    bc[6];            /* ix1,ox1,ix2,ox2,ix3,ox3; AA_BC_NONE = neighbour Grid fills it     */
+  int    nscal;            /* NSCALARS (0 or 1; 1 whenever ion != 0)                            */
+  int    ion;              /* ION_RADIATION + ION_RADPLANE                                      */
+  double gamma, cour_no, tlim;   /* <problem>gamma, <time>cour_no, <time>tlim (main.c:368-378)  */
+  /* <ionradiation> block, ionrad_3d.c:742-757 */
+  double sigma_ph, m_H, mu, e_gamma, alpha_C, k_B, time_unit;
+  double max_de_iter, max_de_therm_iter, max_dx_iter;
+  double max_de_step, max_de_therm_step, max_dx_step;
+  double tfloor, tceil;
+  int    maxiter;
+  int    device;           /* HIP device ordinal                                                */
+} aa_params;
+
+typedef struct aa_grid aa_grid;
+
+/* ---- lifecycle: init_grid.c (U, EdgeFlux), integrate_init_3d (integrate_3d_ctu.c:3374),
+ *      ion_radtransfer_init_3d (ionrad_3d.c:739), ion_radtransfer_init (ionrad.c:64)      */
+int         aa_create(const aa_params *p, aa_grid **out);
+void        aa_destroy(aa_grid *g);   /* integrate_destruct_3d :3498 */
+const char *aa_last_error(void);
+int         aa_set_stream(aa_grid *g, void *hip_stream);   /* run on a caller-owned stream */
+int         aa_sync(aa_grid *g);
+long long   aa_device_bytes(const aa_grid *g);
+
+/* ---- state transfer (host view coherence points: problem(), Userwork_*, outputs) */
+int aa_upload_cons(aa_grid *g, const double *U_aos);      /* host ConsS block -> device SoA */
+int aa_download_cons(aa_grid *g, double *U_aos);
+int aa_upload_edgeflux(aa_grid *g, const double *ef);
+int aa_download_edgeflux(aa_grid *g, double *ef);
+int aa_get_mesh_state(const aa_grid *g, double *time, double *dt, int *nstep);  /* MeshS.time/dt/nstep */
+int aa_set_mesh_state(aa_grid *g, double time, double dt, int nstep);
+
+/* ---- hooks the problem file installs */
+/* globals.h:24 StaticGravPot: the callback is evaluated ONCE on the host at cell centres and
+ * face centres (cc_pos.c:36-43) and kept as device tables; pass NULL to remove it.           */
+typedef double (*aa_gravpot_fn)(double x1, double x2, double x3);
+int aa_set_static_grav_pot(aa_grid *g, aa_gravpot_fn fn);
+int aa_set_static_grav_tables(aa_grid *g, const double *phi_cc, const double *phi_f1,
+                              const double *phi_f2, const double *phi_f3); /* [N3][N2][N1] each */
+/* Userwork_in_loop of prob/ioniz_sphere.c:255-306 re-imposes fixed values on a fixed set of
+ * cells every step; the device-side equivalent is a list of pinned cells (linear index into
+ * the [k][j][i] block incl. ghosts, nvar values each) applied after the integrator.          */
+int aa_set_pinned_cells(aa_grid *g, long long n, const long long *index, const double *values);
+int aa_apply_pinned_cells(aa_grid *g);
+/* ionradplane_3d.c:56 add_radplane_3d (called by problem()); dir must be -1 (+x1 rays) */
+int aa_add_radplane_3d(aa_grid *g, int dir, double flux);
+
+/* ---- the reference's per-step call sites */
+int aa_bvals_mhd(aa_grid *g);                       /* bvals_mhd.c:174 (physical BCs only)        */
+int aa_bvals_ionrad(aa_grid *g);                    /* bvals_ionrad.c:63                          */
+int aa_new_dt(aa_grid *g);                          /* new_dt.c:32                                */
+int aa_integrate_3d_ctu(aa_grid *g);                /* integrate_3d_ctu.c:110, dt = Grid dt       */
+int aa_ion_radtransfer_3d(aa_grid *g, int *niter);  /* ionrad_3d.c:862; may shrink the Grid dt    */
+int aa_start(aa_grid *g);                           /* main.c:412-451: bvals, bvals_ionrad, new_dt */
+int aa_step(aa_grid *g, int *niter);                /* one pass of main.c:519-669                 */
+
+/* ---- phases, for drivers that interleave neighbour exchange / global reductions
+ *      (the places where the reference calls MPI)                          */
+int aa_new_dt_local(aa_grid *g, double *dt_cfl);                /* new_dt.c:72-170 before Allreduce */
+int aa_ion_begin(aa_grid *g);                                   /* ionrad_3d.c:896-905            */
+int aa_ion_rates(aa_grid *g, double *dt_chem, double *dt_therm);/* :922-938 before Allreduce      */
+int aa_ion_update(aa_grid *g, double dt, long long *cellcount, double *dt_hydro); /* :965-1002    */
+/* x3 halo: pack_ix3/pack_ox3/unpack_* (bvals_mhd.c:2608-3175).  side 0 = inner (ks..ks+3),
+ * side 1 = outer; buffers are DEVICE pointers of aa_halo_doubles() doubles.                */
+long long aa_halo_doubles(const aa_grid *g);
+int aa_pack_x3(aa_grid *g, int side, double *dev_buf);
+int aa_unpack_x3(aa_grid *g, int side, const double *dev_buf);
+
+/* ---- function-level kernels on device arrays' host mirrors (parity tests): n states of
+ *      nvar = 5+nscal doubles each, same conventions as fluxes()/lr_states()              */
+int aa_test_fluxes(int nscal, double gamma, int n, const double *Ul, const double *Ur,
+                   const double *etah, double *F);                      /* roe.c:59        */
+int aa_test_lr_states(int nscal, double gamma, int n, const double *W, double dt, double dx,
+                      int il, int iu, double *Wl, double *Wr);          /* lr_states_plm.c:62 */
+
+/* ---- measurement: per-kernel accumulated device time (hipEvent pairs on the stream) */
+int         aa_profile_enable(aa_grid *g, int on);
+int         aa_profile_reset(aa_grid *g);
+int         aa_profile_count(const aa_grid *g);
+const char *aa_profile_name(const aa_grid *g, int i);
+int         aa_profile_get(aa_grid *g, int i, double *total_ms, long long *launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
