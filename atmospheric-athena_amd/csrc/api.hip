@@ -10,6 +10,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <string>
+#include <thread>
 #include <vector>
 #include "../../include/athena_amd.h"
 #include "grid.h"
@@ -218,17 +219,25 @@ int aa_set_static_grav_pot(aa_grid *g, aa_gravpot_fn fn)
   const DevGrid &d = g->d;
   std::vector<double> t[4];
   for (int w = 0; w < 4; w++) t[w].resize((size_t)d.nc);
-  for (int k = 0; k < d.N3; k++) for (int j = 0; j < d.N2; j++) for (int i = 0; i < d.N1; i++) {
-    // cc_pos.c:36-43
-    const double x1 = g->p.MinX[0] + ((double)(i - d.is) + 0.5)*d.dx[0];
-    const double x2 = g->p.MinX[1] + ((double)(j - d.js) + 0.5)*d.dx[1];
-    const double x3 = g->p.MinX[2] + ((double)(k - d.ks) + 0.5)*d.dx[2];
-    const size_t m = (size_t)k*d.sK + (size_t)j*d.sJ + i;
-    t[0][m] = fn(x1, x2, x3);
-    t[1][m] = fn(x1 - 0.5*d.dx[0], x2, x3);
-    t[2][m] = fn(x1, x2 - 0.5*d.dx[1], x3);
-    t[3][m] = fn(x1, x2, x3 - 0.5*d.dx[2]);
-  }
+  // the callback is a pure function of position (as in the reference, which calls it ~52 times
+  // per cell per step): evaluate k-planes on all host cores
+  unsigned nth = std::thread::hardware_concurrency(); if (nth < 1) nth = 1; if (nth > 64) nth = 64;
+  if ((int)nth > d.N3) nth = d.N3;
+  std::vector<std::thread> pool;
+  for (unsigned w = 0; w < nth; w++) pool.emplace_back([&, w]() {
+    for (int k = (int)w; k < d.N3; k += (int)nth) for (int j = 0; j < d.N2; j++) for (int i = 0; i < d.N1; i++) {
+      // cc_pos.c:36-43
+      const double x1 = g->p.MinX[0] + ((double)(i - d.is) + 0.5)*d.dx[0];
+      const double x2 = g->p.MinX[1] + ((double)(j - d.js) + 0.5)*d.dx[1];
+      const double x3 = g->p.MinX[2] + ((double)(k - d.ks) + 0.5)*d.dx[2];
+      const size_t m = (size_t)k*d.sK + (size_t)j*d.sJ + i;
+      t[0][m] = fn(x1, x2, x3);
+      t[1][m] = fn(x1 - 0.5*d.dx[0], x2, x3);
+      t[2][m] = fn(x1, x2 - 0.5*d.dx[1], x3);
+      t[3][m] = fn(x1, x2, x3 - 0.5*d.dx[2]);
+    }
+  });
+  for (auto &th : pool) th.join();
   return aa_set_static_grav_tables(g, t[0].data(), t[1].data(), t[2].data(), t[3].data());
 }
 

@@ -1,0 +1,228 @@
+"""Main loop of the reference (main.c:519-669) over a root Domain cut into x3 slabs, one slab
+per process / GPU, with the reference's MPI calls replaced by torch.distributed (backend
+"nccl" = RCCL over xGMI on MI355X; "gloo" in the CPU tests):
+
+  * bvals_mhd's x3 Isend/Irecv pair (bvals_mhd.c:423-493)  -> batched isend/irecv of the packed
+    4-plane halo (all i and j incl. ghosts so corners travel, bvals_mhd.c:170), both directions
+    at once; periodic wrap = neighbour rank +-1 mod N exactly as the reference rewires lx/rx ids
+  * MPI_Allreduce(MIN) of dt in new_dt (new_dt.c:177) and of dt_chem / dt_therm / dt_hydro, and
+    SUM of the out-of-range cell count (ionrad_3d.c:275,399,554,672) -> all_reduce on small
+    tensors; the four per-sub-cycle reductions collapse into two rounds
+  * the domain is never cut along x1 (the ray direction), so the reference's rank pipeline of
+    get_ph_rate_plane (ionradplane_3d.c:226-400) does not exist here.
+
+All reductions are MIN/MAX of doubles or integer sums, hence bitwise independent of the
+decomposition: an N-slab run reproduces the 1-slab run exactly for position-independent
+problems (the reference has the same property).
+
+The per-slab arithmetic is behind the small ``Engine`` interface; the product engine is
+``HipEngine`` (the C-ABI library).  With one rank and no engine override the whole loop runs
+inside the C library (aa_step) with no Python between kernels.
+"""
+from __future__ import annotations
+
+from typing import List, Optional
+
+import numpy as np
+
+from .config import GridConfig, RunConfig, slab
+
+MAXCELLCOUNT = 20   # ionrad.h:38
+
+
+class HipEngine:
+    """One slab on one MI355X, through include/athena_amd.h."""
+
+    def __init__(self, grid: GridConfig, device: int = 0, strict: Optional[bool] = None, use_torch_stream: bool = True):
+        import torch
+        from . import lib
+        self.torch = torch
+        self.cfg = grid
+        torch.cuda.set_device(device)
+        self.g = lib.setup_problem(grid, device, strict)
+        if use_torch_stream:
+            # run the kernels on torch's current stream so that torch.distributed collectives and
+            # torch.cuda.Event timing are ordered with them
+            self.g.set_stream(torch.cuda.current_stream().cuda_stream)
+        n = self.g.halo_doubles()
+        dev = torch.device("cuda", device)
+        self.send = [torch.empty(n, dtype=torch.float64, device=dev) for _ in range(2)]
+        self.recv = [torch.empty(n, dtype=torch.float64, device=dev) for _ in range(2)]
+        self.scalar_device = dev
+
+    # slab arithmetic
+    def bvals_local(self): self.g.bvals_mhd()
+    def bvals_ionrad(self): self.g.bvals_ionrad()
+    def new_dt_local(self) -> float: return self.g.new_dt_local()
+    def integrate(self): self.g.integrate_3d_ctu()
+    def userwork(self): self.g.apply_pinned_cells()
+    def ion_begin(self): self.g.ion_begin()
+    def ion_rates(self): return self.g.ion_rates()
+    def ion_update(self, dt): return self.g.ion_update(dt)
+    def set_mesh_state(self, time, dt, nstep): self.g.set_mesh_state(time, dt, nstep)
+    def has_radiation(self) -> bool: return bool(self.cfg.run.ion)
+    def step_local(self) -> int: return self.g.step()
+    def start_local(self): self.g.start()
+    def mesh_state(self): return self.g.mesh_state()
+
+    # halo
+    def pack_x3(self, side: int):
+        self.g.pack_x3(side, self.send[side].data_ptr()); return self.send[side]
+
+    def recv_buffer(self, side: int): return self.recv[side]
+    def unpack_x3(self, side: int): self.g.unpack_x3(side, self.recv[side].data_ptr())
+    def sync(self): self.g.sync()
+    def download(self) -> np.ndarray: return self.g.download()
+    def close(self): self.g.close()
+
+
+class Driver:
+    """main() of the reference for one process of an N-process run."""
+
+    def __init__(self, run: RunConfig, engine_factory=None, rank: int = 0, nranks: int = 1, device: int = 0,
+                 strict: Optional[bool] = None):
+        self.run = run
+        self.rank, self.nranks = rank, nranks
+        self.grid = slab(run, rank, nranks)
+        self.eng = engine_factory(self.grid) if engine_factory else HipEngine(self.grid, device, strict)
+        self.time, self.dt, self.nstep = 0.0, 0.0, 0
+        self.niter_trace: List[int] = []
+        if nranks > 1:
+            import torch
+            import torch.distributed as dist
+            self.torch, self.dist = torch, dist
+            assert dist.is_initialized() and dist.get_world_size() == nranks and dist.get_rank() == rank
+            self._sdev = getattr(self.eng, "scalar_device", torch.device("cpu"))
+
+    # ---- collectives ------------------------------------------------------------------
+    def _allreduce(self, vals, op):
+        if self.nranks == 1:
+            return list(vals)
+        t = self.torch.tensor(list(vals), dtype=self.torch.float64, device=self._sdev)
+        self.dist.all_reduce(t, op=op)
+        return t.tolist()
+
+    def _min(self, *vals): return self._allreduce(vals, self.dist.ReduceOp.MIN if self.nranks > 1 else None)
+
+    def exchange_x3(self):
+        """bvals_mhd.c:423-493 for the x3 direction."""
+        if self.nranks == 1:
+            return
+        g, dist = self.grid, self.dist
+        host_stage = (dist.get_backend() == "gloo")   # gloo moves host tensors only
+
+        def out(side):
+            t = self.eng.pack_x3(side)
+            return t.cpu() if (host_stage and t.is_cuda) else t
+
+        rbuf = {}
+
+        def inn(side):
+            t = self.eng.recv_buffer(side)
+            rbuf[side] = (self.torch.empty(t.shape, dtype=t.dtype) if (host_stage and t.is_cuda) else t)
+            return rbuf[side]
+
+        if g.lx3 == g.rx3 and g.lx3 >= 0:
+            # two slabs with periodic wrap: both messages go to the same peer; post them so that the
+            # peer's inner planes (its first send) land in my OUTER ghosts (my first receive)
+            ops = [dist.P2POp(dist.isend, out(0), g.lx3, tag=0),
+                   dist.P2POp(dist.isend, out(1), g.rx3, tag=1),
+                   dist.P2POp(dist.irecv, inn(1), g.rx3, tag=0),
+                   dist.P2POp(dist.irecv, inn(0), g.lx3, tag=1)]
+        else:
+            ops = []
+            # my inner planes fill the lower neighbour's outer ghosts, and vice versa
+            if g.lx3 >= 0:
+                ops.append(dist.P2POp(dist.isend, out(0), g.lx3, tag=0))
+                ops.append(dist.P2POp(dist.irecv, inn(0), g.lx3, tag=1))
+            if g.rx3 >= 0:
+                ops.append(dist.P2POp(dist.isend, out(1), g.rx3, tag=1))
+                ops.append(dist.P2POp(dist.irecv, inn(1), g.rx3, tag=0))
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()
+        for side in (0, 1):
+            if side in rbuf:
+                dst = self.eng.recv_buffer(side)
+                if rbuf[side] is not dst:
+                    dst.copy_(rbuf[side])
+                self.eng.unpack_x3(side)
+
+    # ---- the reference's call sites ---------------------------------------------------------
+    def bvals_mhd(self):
+        self.eng.bvals_local()      # x1, x2 and physical x3 faces
+        self.exchange_x3()
+
+    def new_dt(self):               # new_dt.c:169-185
+        dtc = self._min(self.eng.new_dt_local())[0] if self.nranks > 1 else self.eng.new_dt_local()
+        self.dt = dtc if self.nstep == 0 else min(2.0 * self.dt, dtc)
+        if self.time < self.run.tlim and (self.run.tlim - self.time) < self.dt:
+            self.dt = self.run.tlim - self.time
+        self.eng.set_mesh_state(self.time, self.dt, self.nstep)
+
+    def ion_radtransfer(self) -> int:   # ionrad_3d.c:862-1047, root level
+        e = self.eng
+        dt_done, niter, hydro_done = 0.0, 0, False
+        e.ion_begin()
+        while not hydro_done:
+            dt_chem, dt_therm = e.ion_rates()
+            if self.nranks > 1:
+                dt_chem, dt_therm = self._allreduce((dt_chem, dt_therm), self.dist.ReduceOp.MIN)
+            dt = min(dt_therm, dt_chem)
+            if dt_done + dt > self.dt:
+                dt = self.dt - dt_done
+                hydro_done = True
+            cellcount, dt_hydro = e.ion_update(dt)
+            if self.nranks > 1:
+                # one round: SUM of the count and MIN of dt_hydro (as MAX of its negative)
+                t = self.torch.tensor([float(cellcount), 0.0], dtype=self.torch.float64, device=self._sdev)
+                h = self.torch.tensor([dt_hydro], dtype=self.torch.float64, device=self._sdev)
+                w1 = self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, async_op=True)
+                w2 = self.dist.all_reduce(h, op=self.dist.ReduceOp.MIN, async_op=True)
+                w1.wait(); w2.wait()
+                cellcount, dt_hydro = int(t[0].item()), float(h[0].item())
+            dt_done += dt
+            niter += 1
+            if cellcount > MAXCELLCOUNT:
+                self.dt = dt_done
+                break
+            if hydro_done:
+                break
+            if dt_hydro < dt_done:
+                self.dt = dt_done
+                break
+        if niter == self.run.maxiter:
+            self.dt = dt_done
+        if self.dt < 0:
+            raise RuntimeError(f"[ion_radtransfer_3d]: dt = {self.dt}")
+        e.set_mesh_state(self.time, self.dt, self.nstep)
+        return niter
+
+    # ---- main.c ---------------------------------------------------------------------------------
+    def start(self):                # main.c:412-451
+        if self.nranks == 1 and hasattr(self.eng, "start_local"):
+            self.eng.start_local()
+            self.time, self.dt, self.nstep = self.eng.mesh_state()
+            return
+        self.eng.set_mesh_state(self.time, self.dt, self.nstep)
+        self.bvals_mhd()
+        self.eng.bvals_ionrad()
+        self.new_dt()
+
+    def step(self) -> int:          # main.c:519-669
+        if self.nranks == 1 and hasattr(self.eng, "step_local"):
+            niter = self.eng.step_local()
+            self.time, self.dt, self.nstep = self.eng.mesh_state()
+            self.niter_trace.append(niter)
+            return niter
+        niter = 0
+        if self.eng.has_radiation():
+            niter = self.ion_radtransfer()
+            self.bvals_mhd()
+        self.eng.integrate()
+        self.eng.userwork()
+        self.nstep += 1
+        self.time += self.dt
+        self.new_dt()
+        self.bvals_mhd()
+        self.niter_trace.append(niter)
+        return niter

@@ -72,6 +72,7 @@ int aa_problem_ioniz_sphere(const aa_params *p, double cs, double rp, double mp,
   int i, j, k;
   if (p->nscal != 1) return -1;
   sphere_setup(p, cs, rp, mp, np);
+#pragma omp parallel for private(i, j)
   for (k = NG; k <= NG + p->Nx[2]; k++) for (j = NG; j <= NG + p->Nx[1]; j++) for (i = NG; i <= NG + p->Nx[0]; i++) {
     double *u = cell(p, U, i, j, k), x[3], rad;
     centre(p, i, j, k, x);
@@ -134,6 +135,7 @@ int aa_problem_blast(const aa_params *p, double radius, double pamb, double damb
   const double Gamma_1 = p->gamma - 1.0;
   int i, j, k;
   if (p->nscal != 0) return -1;
+#pragma omp parallel for private(i, j)
   for (k = NG; k < NG + p->Nx[2]; k++) for (j = NG; j < NG + p->Nx[1]; j++) for (i = NG; i < NG + p->Nx[0]; i++) {
     double *u = cell(p, U, i, j, k), x[3], rad, P, d;
     centre(p, i, j, k, x);

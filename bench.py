@@ -1,0 +1,183 @@
+#!/usr/bin/env python3
+"""bench.py -- whole-job throughput of the hot path on N MI355X of one node.
+
+One "step" = one pass of the reference's main loop (main.c:519-669) on synthetic input already
+resident in HBM: ion-radiation step with its sub-cycles (ionrad_3d.c:862) + ghost zones +
+3-D CTU hydro step (integrate_3d_ctu.c:110) + per-step core reset + new_dt + ghost zones.
+Workload at N=1: BASELINE.json configs[3] on one GPU, tst/massloss/athinput.ioniz_sphere_hires
+keys at 512^3 single level (hydro + static gravity + ion radiation).  With N>1 the box is cut
+into x3 slabs of 512x512x512 each (weak scaling: 512 x 512 x 512*N zones, same dx), halo
+exchange and scalar reductions over RCCL.
+
+Prints ONE JSON line (rank 0).  `value` = active zones advanced per second by the whole job.
+"""
+import argparse
+import importlib
+import json
+import os
+import re
+import shutil
+import subprocess
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+PKG = "atmospheric-athena_amd"
+
+HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/s measured copy)
+
+# Compulsory bytes per cell of each kernel = distinct doubles it must read + write per zone
+# (NVAR=6): the figures are derived in DESIGN.md section 4.
+KERNEL_BYTES = {
+    "sweep_x1": 8 * (6 + 18), "sweep_x2": 8 * (6 + 18), "sweep_x3": 8 * (6 + 18),
+    "correct": 8 * (36 + 18 + 36 + 3), "flux2_x1": 8 * (12 + 3 + 6), "flux2_x2": 8 * (12 + 3 + 6),
+    "flux2_x3": 8 * (12 + 3 + 6), "update": 8 * (6 + 18 + 6),
+    "ray_sweep": 8 * (1 + 2), "ion_rates": 8 * (6 + 1 + 2 + 2), "ion_update": 8 * (6 + 6 + 2),
+    "ion_begin": 8 * (6 + 4), "bvals_mhd": 0, "new_dt": 8 * 5, "pinned_cells": 0,
+}
+
+
+def cpu_baseline(nx=64, nlim=8):
+    """The REAL reference (oracle/_ref, built from /root/reference by oracle/Makefile.ref) timed
+    on one host core on a bounded sample of the same deck; falls back to the CPU restatement."""
+    exe = os.path.join(ROOT, "oracle", "_ref", "athena_ioniz_sphere")
+    deck = os.path.join(ROOT, PKG, "decks", "athinput.ioniz_sphere")
+    if os.path.exists(exe):
+        tmp = tempfile.mkdtemp(prefix="cpu_baseline_")
+        try:
+            t0 = time.time()
+            pr = subprocess.run([exe, "-i", deck, "-d", os.path.join(tmp, "run"),
+                                 f"domain1/Nx1={nx}", f"domain1/Nx2={nx}", f"domain1/Nx3={nx}", f"time/nlim={nlim}"],
+                                stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, cwd=tmp, timeout=600)
+            wall = time.time() - t0
+            m = re.search(r"zone-cycles/wall-second = ([0-9.eE+-]+)", pr.stdout)
+            its = [int(x) for x in re.findall(r"Radiation done in (\d+) iterations", pr.stderr)]
+            if pr.returncode == 0 and m:
+                return {"value": float(m.group(1)), "unit": "cell-updates/s", "cores": 1, "kind": "reference",
+                        "sample": f"ioniz_sphere {nx}^3, {nlim} steps, sub-cycles/step {its}, {wall:.1f} s wall"}
+        except Exception:
+            pass
+        finally:
+            shutil.rmtree(tmp, ignore_errors=True)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import orc
+    s = orc.make_sim("ioniz_sphere", [f"domain1/Nx{d}={nx}" for d in (1, 2, 3)]).start()
+    t0 = time.time(); its = [s.step() for _ in range(nlim)]; wall = time.time() - t0
+    return {"value": nx ** 3 * nlim / wall, "unit": "cell-updates/s", "cores": 1, "kind": "port",
+            "sample": f"ioniz_sphere {nx}^3, {nlim} steps, sub-cycles/step {its}, {wall:.1f} s wall"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--nx", type=int, default=512, help="zones per direction per GPU (default: the 512^3 workload)")
+    ap.add_argument("--problem", default="ioniz_sphere", choices=["ioniz_sphere", "ifront", "blast"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-times", action="store_true")
+    a = ap.parse_args()
+
+    import torch
+    aa = importlib.import_module(PKG)
+    driver = importlib.import_module(PKG + ".driver")
+    rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        if world == 1 and a.gpus > 1:
+            sys.exit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N bench.py --gpus N")
+        a.gpus = world
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs an MI355X: the hot path has no CPU fallback")
+    torch.cuda.set_device(local)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+
+    # weak scaling: every GPU holds nx^3 zones; the box grows along x3 with the same dx
+    nx = a.nx
+    deck = os.path.join(ROOT, PKG, "decks", "athinput." + a.problem)
+    par = aa.athinput.ParTable.from_file(deck)
+    x3min, x3max = par.getd("domain1", "x3min"), par.getd("domain1", "x3max")
+    par.cmdline([f"domain1/Nx1={nx}", f"domain1/Nx2={nx}", f"domain1/Nx3={nx * world}",
+                 f"domain1/x3max={x3min + (x3max - x3min) * world!r}"])
+    run = aa.config.from_par(par, a.problem)
+    t_setup = time.time()
+    drv = driver.Driver(run, None, rank, world, local)
+    drv.start()
+    eng = drv.eng
+    torch.cuda.synchronize()
+    t_setup = time.time() - t_setup
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        drv.step()
+    eng.g.profile_reset()
+    if not a.no_kernel_times:
+        eng.g.profile_enable(True)
+    drv.niter_trace.clear()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        drv.step()
+    barrier()
+    t1 = time.perf_counter()
+    prof = eng.g.profile() if not a.no_kernel_times else {}
+    eng.g.profile_enable(False)
+    elapsed = t1 - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        zones = nx * nx * nx * world
+        nsub = sum(drv.niter_trace) / max(1, len(drv.niter_trace))
+        value = zones * a.steps / elapsed
+        out = {
+            "metric": "cell-updates/sec (hydro+ion-rad step)", "value": value, "unit": "cell-updates/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * elapsed / a.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+            "data": "synthetic (ioniz_sphere deck values on a uniform grid, generated in place)",
+            "config": {"workload": f"{a.problem} {nx}x{nx}x{nx * world} single level, CTU+PLM+Roe+H-correction"
+                                   + (" + static gravity + plane-parallel ion radiation" if a.problem == "ioniz_sphere"
+                                      else (" + plane-parallel ion radiation" if a.problem == "ifront" else "")),
+                       "zones_per_gpu": nx ** 3, "partition": f"x3 slabs x{world}", "nvar": 5 + run.nscal,
+                       "radiation_subcycles_per_step": nsub, "subcycle_trace": drv.niter_trace,
+                       "final_dt": drv.dt, "hbm_resident_GB": eng.g.device_bytes() / 1e9, "setup_s": t_setup},
+        }
+        # roofline of the dominant kernel: compulsory bytes of one launch / its mean duration
+        # (hipEvent pairs recorded on the launch stream inside the timed region)
+        if prof:
+            dom = max(prof, key=lambda k: prof[k][0])
+            ms, n = prof[dom]
+            ncell = nx ** 3
+            bpl = KERNEL_BYTES.get(dom, 0) * ncell
+            ach = bpl / (ms / n * 1e-3) / 1e9 if n else 0.0
+            out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                               "frac": ach / HBM_PEAK_GBS, "traffic": None, "bytes_per_launch": bpl,
+                               "avg_launch_ms": ms / n if n else None}
+            out["kernel_ms_per_step"] = {k: v[0] / a.steps for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])}
+            out["kernel_launches_per_step"] = {k: v[1] / a.steps for k, v in prof.items()}
+        # the survey's whole-step definition: (96 + 64*<N_sub>) B per cell-update
+        bstep = (2 * 8 * (5 + run.nscal)) + (64 * nsub if run.ion else 0)
+        out["step_roofline"] = {"bytes_per_cell_update": bstep, "achieved": value / world * bstep / 1e9,
+                                "peak": HBM_PEAK_GBS, "unit": "GB/s per GPU",
+                                "frac": value / world * bstep / 1e9 / HBM_PEAK_GBS}
+        if not a.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,96 @@
+"""CPU-side checks: the athinput reader, the C-ABI libraries export every symbol the header
+declares (loaded, never called: no GPU here), the host C problem files reproduce the oracle's
+initial conditions bit for bit."""
+import ctypes as C
+import importlib
+import os
+import re
+
+import numpy as np
+import pytest
+
+import orc
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKGDIR = os.path.join(ROOT, "atmospheric-athena_amd")
+
+
+def test_athinput_reader(aa):
+    P = aa.athinput.ParTable
+    t = P.from_text("<job>\nproblem_id = x # c\nmaxout=3\n<time>\ncour_no = 0.4\nnlim = 100000000000\n"
+                    "<ionradiation>\nmaxiter = 100000000.\n")
+    assert t.gets("job", "problem_id") == "x" and t.geti("job", "maxout") == 3
+    assert t.getd("time", "cour_no") == 0.4
+    assert t.geti("ionradiation", "maxiter") == 100000000          # atoi() semantics
+    t.cmdline(["time/cour_no=0.3"])
+    assert t.getd("time", "cour_no") == 0.3
+    with pytest.raises(aa.athinput.ParError):                       # par.c:194: only existing keys
+        t.cmdline(["time/newkey=1"])
+    with pytest.raises(aa.athinput.ParError):
+        t.cmdline(["nosuchblock/x=1"])
+    with pytest.raises(aa.athinput.ParError):
+        t.getd("time", "missing")
+    assert t.getd_def("time", "missing", 2.5) == 2.5 and t.exist("time", "missing")
+
+
+def test_config_rejects_what_the_reference_rejects(aa):
+    deck = os.path.join(PKGDIR, "decks", "athinput.blast")
+    with pytest.raises(aa.athinput.ParError):                       # integrate.c:66-68
+        aa.config.load(deck, ["time/cour_no=0.8"], "blast")
+    with pytest.raises(aa.athinput.ParError):                       # bvals_mhd.c:586
+        aa.config.load(deck, ["domain1/bc_ix1=7"], "blast")
+    with pytest.raises(aa.athinput.ParError):
+        aa.config.load(deck, ["domain1/Nx3=1"], "blast")
+
+
+@pytest.mark.parametrize("so", ["libathena_amd.so", "libathena_amd_strict.so"])
+def test_cabi_exports_every_declared_symbol(so):
+    hdr = open(os.path.join(ROOT, "include", "athena_amd.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    names = sorted(set(re.findall(r"\b(aa_[a-z0-9_]+)\s*\(", hdr)))
+    names = [n for n in names if n != "aa_gravpot_fn"]
+    assert len(names) >= 35
+    L = C.CDLL(os.path.join(PKGDIR, so))
+    missing = [n for n in names if not hasattr(L, n)]
+    assert not missing, missing
+
+
+def test_binding_signature_table_matches_header():
+    lib = importlib.import_module("atmospheric-athena_amd.lib")
+    hdr = open(os.path.join(ROOT, "include", "athena_amd.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    names = set(re.findall(r"\b(aa_[a-z0-9_]+)\s*\(", hdr)) - {"aa_gravpot_fn"}
+    L = lib.load(False)
+    assert set(L._sig) == names
+
+
+@pytest.mark.parametrize("problem,nx", [("ifront", (8, 6, 10)), ("ioniz_sphere", (20, 16, 12)), ("blast", (12, 8, 10))])
+def test_host_problem_files_match_oracle(aa, problem, nx):
+    lib = importlib.import_module("atmospheric-athena_amd.lib")
+    ov = [f"domain1/Nx{d + 1}={nx[d]}" for d in range(3)]
+    o = orc.make_sim(problem, ov)
+    run = aa.config.load(os.path.join(PKGDIR, "decks", "athinput." + problem), ov, problem)
+    p = lib.params_from_grid(aa.config.slab(run))
+    H = lib.host()
+    nv = 5 + run.nscal
+    U = np.zeros((nx[2] + 8, nx[1] + 8, nx[0] + 8, nv))
+    dp = U.ctypes.data_as(C.POINTER(C.c_double)); pr = run.prob
+    if problem == "ifront":
+        assert H.aa_problem_ifront(C.byref(p), pr["n_H"], pr["cs"], dp) == 0
+    elif problem == "ioniz_sphere":
+        assert H.aa_problem_ioniz_sphere(C.byref(p), pr["cs"], pr["rp"], pr["mp"], pr["np"], dp) == 0
+    else:
+        assert H.aa_problem_blast(C.byref(p), pr["radius"], pr["pamb"], 1.0, 1.0, pr["prat"], dp) == 0
+    assert np.array_equal(U[4:-4, 4:-4, 4:-4], o.active[..., :nv])
+    if problem == "ioniz_sphere":
+        # the pinned-cell list is Userwork_in_loop: applying it equals the oracle's userwork
+        n = H.aa_ioniz_sphere_pinned(C.byref(p), None, None)
+        idx = np.zeros(n, dtype=np.int64); val = np.zeros((n, 6))
+        H.aa_ioniz_sphere_pinned(C.byref(p), idx.ctypes.data_as(C.POINTER(C.c_longlong)), val.ctypes.data_as(C.POINTER(C.c_double)))
+        o.U[4:-4, 4:-4, 4:-4, :] *= 1.37                            # disturb, then reset
+        V = o.U.copy().reshape(-1, 6)
+        o.userwork()
+        V[idx] = val
+        assert n > 0 and np.array_equal(V.reshape(o.U.shape), o.U)
+        # potential: same function as the oracle's (first step with gravity is bitwise in the gpu tests)
+        assert np.isfinite(H.aa_planet_pot(1e9, 2e9, -3e9))
