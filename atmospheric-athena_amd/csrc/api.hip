@@ -132,6 +132,12 @@ int aa_create(const aa_params *p, aa_grid **out)
     Real maxdx = d.dx[0] > d.dx[1] ? d.dx[0] : d.dx[1];
     maxdx = maxdx > d.dx[2] ? maxdx : d.dx[1];
     ip.d_nlo = 1.0e-4 * p->m_H / (p->sigma_ph * maxdx);      // MINOPTDEPTH, ionrad.h:29
+    ip.inv_mH = 1.0/p->m_H; ip.inv_kB = 1.0/p->k_B; ip.aC14 = p->alpha_C/(14.0*p->m_H);
+    ip.rec_floor = 2.59e-13*pow(p->tfloor/1.0e4, -0.7);      // recomb_rate_coef(tfloor), ionrad_chemistry.c:111
+    ip.cx1 = p->max_dx_iter/(1 + p->max_dx_iter);
+    ip.ce1 = p->max_de_therm_iter/(1 + p->max_de_therm_iter); ip.ce2 = p->max_de_iter/(1 + p->max_de_iter);
+    ip.ie1 = 1.0/(1.0 + p->max_de_therm_iter); ip.ie2 = 1.0/(1.0 + p->max_de_iter);
+    for (int a = 0; a < 3; a++) ip.inv_dx[a] = 1.0/d.dx[a];
   }
   if (hipMalloc(&g->sc, sizeof(DevScalars)) != hipSuccess || hipHostMalloc(&g->sc_host, sizeof(DevScalars)) != hipSuccess) {
     hipFree(g->pool); delete g; return fail(-2, "[aa_create]: scalar buffers");

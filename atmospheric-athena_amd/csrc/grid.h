@@ -45,6 +45,8 @@ struct IonPar {                   // ionrad.h:54-91 globals
   Real tfloor, tceil;
   Real min_area, d_nlo;
   Real cour_no;
+  // host-computed reciprocals / constants (FP64 division is the expensive op in the ion kernels)
+  Real inv_mH, inv_kB, aC14, rec_floor, cx1, ce1, ce2, ie1, ie2, inv_dx[3];
 };
 
 // device scalars written by reduction kernels (all reductions are MIN/MAX of non-negative

@@ -65,6 +65,11 @@ AA_DEV void face_first_pass(const DevGrid &g, long m, Real dtodx, Real wl[6], Re
   store_sweep<D, NS>(Ff(g, D, 0), g.nc, m, f);
 }
 
+// Workgroups are dealt round-robin over the 8 XCDs (blockIdx b and b+8 share an XCD and its L2).
+// Stencil kernels want NEIGHBOURING rows in the same L2, so give each XCD one contiguous 1/8 of
+// the linear cell range: logical block = (b % 8)*per + b/8 with the grid rounded up to 8*per.
+AA_DEV long xcd_block(unsigned per) { return (long)(blockIdx.x & 7u)*per + (blockIdx.x >> 3); }
+
 // ---- steps 2,3: x2 / x3 sweeps, register sliding window along the sweep direction ---------
 // One thread owns one (i, transverse) column and a chunk of `chunk` interfaces; lanes are
 // consecutive in i.  Cells reconstructed: l..u = s-2..e+2; interfaces l+1..u (:179-184).
@@ -232,7 +237,7 @@ __global__ void __launch_bounds__(256)
 k_correct(DevGrid g, Real dt)
 {
   const int ni = g.ie - g.is + 4, nj = g.je - g.js + 4, nk = g.ke - g.ks + 4;   // [s-1, e+2]
-  const long lin = (long)blockIdx.x*blockDim.x + threadIdx.x;
+  const long lin = xcd_block(gridDim.x >> 3)*blockDim.x + threadIdx.x;
   if (lin >= (long)ni*nj*nk) return;
   const int i = g.is - 1 + (int)(lin % ni);
   const int j = g.js - 1 + (int)((lin / ni) % nj);
@@ -259,7 +264,7 @@ k_flux2(DevGrid g)
 {
   // faces needed by the update: along D [s, e+1], transverse [s, e]
   const int ni = g.ie - g.is + 1 + (D == 0), nj = g.je - g.js + 1 + (D == 1), nk = g.ke - g.ks + 1 + (D == 2);
-  const long lin = (long)blockIdx.x*blockDim.x + threadIdx.x;
+  const long lin = xcd_block(gridDim.x >> 3)*blockDim.x + threadIdx.x;
   if (lin >= (long)ni*nj*nk) return;
   const int i = g.is + (int)(lin % ni);
   const int j = g.js + (int)((lin / ni) % nj);
@@ -295,7 +300,7 @@ __global__ void __launch_bounds__(256)
 k_update(DevGrid g, Real dt)
 {
   const int ni = g.ie - g.is + 1, nj = g.je - g.js + 1, nk = g.ke - g.ks + 1;
-  const long lin = (long)blockIdx.x*blockDim.x + threadIdx.x;
+  const long lin = xcd_block(gridDim.x >> 3)*blockDim.x + threadIdx.x;
   if (lin >= (long)ni*nj*nk) return;
   const int i = g.is + (int)(lin % ni);
   const int j = g.js + (int)((lin / ni) % nj);
@@ -469,6 +474,7 @@ __global__ void k_test_lr(Real Gamma, int n, const Real *W, Real dt, Real dx, in
 // host-side launchers
 // =============================================================================================
 static inline unsigned nblk(long n, int b) { return (unsigned)((n + b - 1)/b); }
+static inline unsigned nblk8(long n, int b) { unsigned x = nblk(n, b); return ((x + 7u)/8u)*8u; }   // for xcd_block()
 
 template <int NS, bool GRAV>
 static void sweep_impl(const DevGrid &g, int dir, Real dt, hipStream_t st)
@@ -501,7 +507,7 @@ void launch_sweep(const DevGrid &g, int nscal, int dir, Real dt, bool grav, hipS
 void launch_correct(const DevGrid &g, int nscal, Real dt, bool grav, hipStream_t st)
 {
   const long n = (long)(g.ie - g.is + 4)*(g.je - g.js + 4)*(g.ke - g.ks + 4);
-  dim3 grid(nblk(n, 256)), blk(256);
+  dim3 grid(nblk8(n, 256)), blk(256);
   if (nscal) { if (grav) hipLaunchKernelGGL((k_correct<1, true>), grid, blk, 0, st, g, dt);
                else      hipLaunchKernelGGL((k_correct<1, false>), grid, blk, 0, st, g, dt); }
   else       { if (grav) hipLaunchKernelGGL((k_correct<0, true>), grid, blk, 0, st, g, dt);
@@ -512,7 +518,7 @@ template <int NS>
 static void flux2_impl(const DevGrid &g, int dir, hipStream_t st)
 {
   const long n = (long)(g.ie - g.is + 1 + (dir == 0))*(g.je - g.js + 1 + (dir == 1))*(g.ke - g.ks + 1 + (dir == 2));
-  dim3 grid(nblk(n, 256)), blk(256);
+  dim3 grid(nblk8(n, 256)), blk(256);
   if (dir == 0) hipLaunchKernelGGL((k_flux2<NS, 0>), grid, blk, 0, st, g);
   else if (dir == 1) hipLaunchKernelGGL((k_flux2<NS, 1>), grid, blk, 0, st, g);
   else hipLaunchKernelGGL((k_flux2<NS, 2>), grid, blk, 0, st, g);
@@ -523,7 +529,7 @@ void launch_flux2(const DevGrid &g, int nscal, int dir, hipStream_t st)
 void launch_update(const DevGrid &g, int nscal, Real dt, bool grav, hipStream_t st)
 {
   const long n = (long)(g.ie - g.is + 1)*(g.je - g.js + 1)*(g.ke - g.ks + 1);
-  dim3 grid(nblk(n, 256)), blk(256);
+  dim3 grid(nblk8(n, 256)), blk(256);
   if (nscal) { if (grav) hipLaunchKernelGGL((k_update<1, true>), grid, blk, 0, st, g, dt);
                else      hipLaunchKernelGGL((k_update<1, false>), grid, blk, 0, st, g, dt); }
   else       { if (grav) hipLaunchKernelGGL((k_update<0, true>), grid, blk, 0, st, g, dt);

@@ -30,23 +30,27 @@ namespace aa {
 AA_DEV Real *Uq(const DevGrid &g, int v) { return g.U + (long)v*g.nc; }
 
 struct CellState { Real d, M1, M2, M3, E, s; };
-struct IonQ { Real n_H, n_Hplus, n_e, x, ke, e_th, T; };
+struct IonQ { Real n_H, n_Hplus, n_e, x, ke, e_th, T, di, muq; };
 
 AA_DEV CellState load_cell(const DevGrid &g, long m)
 { CellState c; c.d = Uq(g,0)[m]; c.M1 = Uq(g,1)[m]; c.M2 = Uq(g,2)[m]; c.M3 = Uq(g,3)[m]; c.E = Uq(g,4)[m]; c.s = Uq(g,5)[m]; return c; }
 
-// ionrad_3d.c:82-101 (same expressions are repeated at :313-331 and :438-456)
+// ionrad_3d.c:82-101 (same expressions are repeated at :313-331 and :438-456).  The ion step is
+// not bit-reproducible against the CPU anyway (device exp/log vs glibc), so the seven divisions
+// of the reference are folded into two plus multiplications by host-computed reciprocals:
+// FP64 division is ~10x the cost of a multiply on CDNA4 and these kernels are ALU-bound otherwise.
 AA_DEV IonQ ion_q(const CellState &c, const IonPar &p, Real Gamma_1)
 {
   IonQ q;
-  q.n_H = c.s / p.m_H;
-  q.n_Hplus = (c.d - c.s) / p.m_H;
-  q.n_e = q.n_Hplus + c.d * p.alpha_C / (14.0 * p.m_H);
+  q.n_H = c.s * p.inv_mH;
+  q.n_Hplus = (c.d - c.s) * p.inv_mH;
+  q.n_e = q.n_Hplus + c.d * p.aC14;
   q.x = q.n_e / (q.n_H + q.n_Hplus);
-  q.ke = 0.5 * (c.M1*c.M1 + c.M2*c.M2 + c.M3*c.M3) / c.d;
+  q.di = 1.0 / c.d;
+  q.ke = 0.5 * (c.M1*c.M1 + c.M2*c.M2 + c.M3*c.M3) * q.di;
   q.e_th = c.E - q.ke;
-  Real e_sp = q.e_th / c.d;
-  q.T = Gamma_1 * e_sp * (q.x*0.5*p.m_H+(1.0-q.x)*p.mu)/ p.k_B;
+  q.muq = q.x*0.5*p.m_H+(1.0-q.x)*p.mu;
+  q.T = Gamma_1 * (q.e_th * q.di) * q.muq * p.inv_kB;
   return q;
 }
 
@@ -58,16 +62,19 @@ AA_DEV void floors(CellState &c, const IonPar &p, Real Gamma_1)
 {
   IonQ q = ion_q(c, p, Gamma_1);
   if (q.T < p.tfloor) {
-    Real e_sp = p.tfloor * p.k_B / ((q.x*0.5*p.m_H+(1.0-q.x)*p.mu) * Gamma_1);
-    c.E = 0.5 * (c.M1*c.M1 + c.M2*c.M2 + c.M3*c.M3) / c.d + e_sp * c.d;
+    Real e_sp = p.tfloor * p.k_B / (q.muq * Gamma_1);
+    c.E = q.ke + e_sp * c.d;
   }
   if ((q.T > p.tceil) && (p.tceil > 0)) {
-    Real e_sp = p.tceil * p.k_B / ((q.x*0.5*p.m_H+(1.0-q.x)*p.mu) * Gamma_1);
-    c.E = 0.5 * (c.M1*c.M1 + c.M2*c.M2 + c.M3*c.M3) / c.d + e_sp * c.d;
+    Real e_sp = p.tceil * p.k_B / (q.muq * Gamma_1);
+    c.E = q.ke + e_sp * c.d;
   }
   Real d_nlim = neutral_lim(c.d, p);
   if (c.s < d_nlim) c.s = d_nlim; else if (c.s > c.d) c.s = c.d;
 }
+
+AA_DEV bool ratio_ge(Real a, Real b, Real L)
+{ return (a > 0.0 && b > 0.0) ? (a >= L*b) : (a / b >= L); }
 
 AA_DEV bool active_cell(const DevGrid &g, long lin, long &m)
 {
@@ -91,8 +98,8 @@ k_ion_begin(DevGrid g, IonPar p)
   if (c.s != s0) Uq(g,5)[m] = c.s;
   IonQ q = ion_q(c, p, g.Gamma_1);
   g.e_init[m] = c.E;
-  g.e_th_init[m] = c.E - 0.5 * (c.M1*c.M1 + c.M2*c.M2 + c.M3*c.M3) / c.d;
-  g.x_init[m] = q.n_e / (q.n_H + q.n_Hplus);
+  g.e_th_init[m] = q.e_th;
+  g.x_init[m] = q.x;
   g.sign[m] = make_int2(0, 0);
 }
 
@@ -129,7 +136,7 @@ k_ray_sweep(DevGrid g, IonPar p, Real flux0)
         nH[q] = 1.0;
         if (incol && r < nrays) {
           const long m = (long)k*g.sK + (long)(j0 + r)*g.sJ + i;
-          const Real n_H = Uq(g,5)[m] / p.m_H;                // ionradplane_3d.c:281
+          const Real n_H = Uq(g,5)[m] * p.inv_mH;              // ionradplane_3d.c:281
           const Real tau = p.sigma_ph * n_H * g.dx[0];        // :294
           nH[q] = n_H;
           s_etau[r][col] = exp(-tau);
@@ -197,15 +204,26 @@ k_ion_rates(DevGrid g, IonPar p, DevScalars *sc)
 {
   __shared__ Real red[256];
   long m;
-  Real dt_chem = DBL_MAX, dt_therm = DBL_MAX;
-  if (active_cell(g, (long)blockIdx.x*blockDim.x + threadIdx.x, m)) {
+  Real dt_chem_min = DBL_MAX, dt_therm_min = DBL_MAX;
+  // grid-stride: a capped grid keeps the number of same-address atomics at 2 per block
+  // (one word sustains only ~90 atomics/us on MI355X; one block per 256 cells made the two
+  // atomicMin of this kernel cost 12 ms at 512^3)
+  for (long lin = (long)blockIdx.x*blockDim.x + threadIdx.x; active_cell(g, lin, m); lin += (long)gridDim.x*blockDim.x) {
+    Real dt_chem = DBL_MAX, dt_therm = DBL_MAX;
     const CellState c = load_cell(g, m);
     const IonQ q = ion_q(c, p, g.Gamma_1);
     const Real ph = g.ph_rate[m];
-    // compute_chem_rates, ionrad_3d.c:334-394
-    Real T = q.T; if (T < p.tfloor) T = p.tfloor;
-    Real nHdot = 2.59e-13*pow(T/1.0e4, -0.7) * p.time_unit * q.n_e * q.n_Hplus - ph * q.n_H;   // chemistry :111
+    // compute_chem_rates, ionrad_3d.c:334-394.  recomb_rate_coef = 2.59e-13 (T/1e4)^-0.7 and
+    // recomb_cool_rate_coef = 6.11e-10 T^-0.89 k_B T (ionrad_chemistry.c:111,:137) share ONE log:
+    // T^y = exp(y ln T) (rel. error ~ |y ln T| eps ~ 1e-15), and the floored temperature uses the
+    // host-computed coefficient.
+    const bool cold = (q.T < p.tfloor);
+    Real lnT = 0.0, rec;
+    if (cold) rec = p.rec_floor;
+    else { lnT = log(q.T); rec = 2.59e-13*exp(-0.7*(lnT - 9.210340371976184)); }   // ln(1e4)
+    Real nHdot = rec * p.time_unit * q.n_e * q.n_Hplus - ph * q.n_H;
     int2 sg = g.sign[m];
+    const int2 sg0 = sg;
     if (nHdot < 0.0) {
       if (sg.x == 1) sg.y++; else if (sg.y > 0) sg.y--;
       sg.x = -1;
@@ -213,50 +231,55 @@ k_ion_rates(DevGrid g, IonPar p, DevScalars *sc)
       if (sg.x == -1) sg.y++; else if (sg.y > 0) sg.y--;
       sg.x = 1;
     } else { sg.x = 0; sg.y = 0; }
-    g.sign[m] = sg;
+    if (sg.x != sg0.x || sg.y != sg0.y) g.sign[m] = sg;
     for (int n = MAXSIGNCOUNT; n < sg.y; n++) nHdot *= DAMPFACTOR;
     g.nHdot[m] = nHdot;
     const Real d_nlim = neutral_lim(c.d, p);
+    const Real inv_n = 1.0/nHdot;
     Real dt1, dt2;
     if (nHdot == 0.0) { dt1 = dt2 = DBL_MAX; }
     else if (nHdot > 0.0) {
-      dt1 = p.max_dx_iter / (1+p.max_dx_iter) * q.n_e / nHdot;
-      dt2 = p.max_dx_iter * q.n_H / nHdot;
+      dt1 = p.cx1 * q.n_e * inv_n;               // max_dx_iter/(1+max_dx_iter) * n_e / nHdot
+      dt2 = p.max_dx_iter * q.n_H * inv_n;
     } else if (c.s > 1.0001*d_nlim) {
-      dt1 = -p.max_dx_iter * q.n_e / nHdot;
-      dt2 = -p.max_dx_iter / (1+p.max_dx_iter) * q.n_H / nHdot;
+      dt1 = -p.max_dx_iter * q.n_e * inv_n;
+      dt2 = -p.cx1 * q.n_H * inv_n;
     } else { dt1 = dt2 = DBL_MAX; }
     dt_chem = (dt1 < dt2) ? dt1 : dt2;
     if (dt_chem < 0) { atomicExch(&sc->neg_dt_chem, 1); dt_chem = DBL_MAX; }
     // compute_therm_rates, :460-557 (uses the un-floored T)
     Real edot = 0.0;
-    bool skip = (q.T < p.tfloor) || ((nHdot < 0) && (c.s < 1.0001*d_nlim));
+    bool skip = cold || ((nHdot < 0) && (c.s < 1.0001*d_nlim));
     if (!skip) {
       const Real Tt = q.T;
-      const Real rcool = (Tt < 100.0) ? 0.0 : 6.11e-10*pow(Tt,-0.89)*KB_CHEM*Tt;          // chemistry :137
-      const Real lya = -7.5e-19*q.n_e*q.n_H*exp(-118348/Tt);                               // :350, call at ionrad_3d.c:484
+      const Real rcool = (Tt < 100.0) ? 0.0 : 6.11e-10*exp(-0.89*lnT)*KB_CHEM*Tt;          // chemistry :137
+      const Real arg = 118348/Tt;
+      const Real lya = (arg > 745.2) ? 0.0 : -7.5e-19*q.n_e*q.n_H*exp(-arg);              // :350, call at ionrad_3d.c:484
       edot = ph * p.e_gamma * q.n_H - rcool * p.time_unit * q.n_Hplus * q.n_e + lya * p.time_unit;
       Real t1, t2; bool have = true;
+      const Real inv_e = 1.0/edot;
       if (edot == 0.0) { t1 = t2 = DBL_MAX; }
       else if (edot > 0.0) {
-        t1 = p.max_de_iter * c.E / edot;
-        t2 = p.max_de_therm_iter * q.e_th / edot;
+        t1 = p.max_de_iter * c.E * inv_e;
+        t2 = p.max_de_therm_iter * q.e_th * inv_e;
       } else {
-        const Real e_sp_min = p.tfloor * p.k_B / ((q.x*0.5*p.m_H+(1.0-q.x)*p.mu) * g.Gamma_1);
+        const Real e_sp_min = p.tfloor * p.k_B / (q.muq * g.Gamma_1);
         const Real e_th_min = e_sp_min * c.d;
-        const Real e_min = 0.5 * (c.M1*c.M1 + c.M2*c.M2 + c.M3*c.M3) / c.d + e_th_min;
-        if ((q.e_th/(1.0+p.max_de_therm_iter) < e_th_min) && (c.E/(1.0+p.max_de_iter) < e_min)) have = false;
-        t1 = -p.max_de_iter / (1+p.max_de_iter) * c.E / edot;
-        t2 = -p.max_de_therm_iter / (1+p.max_de_therm_iter) * q.e_th / edot;
+        const Real e_min = q.ke + e_th_min;
+        if ((q.e_th*p.ie1 < e_th_min) && (c.E*p.ie2 < e_min)) have = false;   // e/(1+max_de*_iter)
+        t1 = -p.ce2 * c.E * inv_e;
+        t2 = -p.ce1 * q.e_th * inv_e;
       }
       if (have) dt_therm = (t1 < t2) ? t1 : t2;
     }
     g.edot[m] = edot;
+    if (!(dt_therm == dt_therm) || dt_therm < 0) dt_therm = DBL_MAX;
+    dt_chem_min = rmin(dt_chem_min, dt_chem);
+    dt_therm_min = rmin(dt_therm_min, dt_therm);
   }
   // dt values are > 0 (or +DBL_MAX): their bit patterns order like the values
-  if (!(dt_therm == dt_therm) || dt_therm < 0) dt_therm = DBL_MAX;
-  block_min_to(&sc->dt_chem, dt_chem, red);
-  block_min_to(&sc->dt_therm, dt_therm, red);
+  block_min_to(&sc->dt_chem, dt_chem_min, red);
+  block_min_to(&sc->dt_therm, dt_therm_min, red);
 }
 
 // ---- update + floors + range check + hydro CFL --------------------------------------------------
@@ -269,7 +292,8 @@ k_ion_update(DevGrid g, IonPar p, Real dt, DevScalars *sc)
   __syncthreads();
   long m;
   Real dti = 0.0;
-  if (active_cell(g, (long)blockIdx.x*blockDim.x + threadIdx.x, m)) {
+  unsigned int mycnt = 0;
+  for (long lin = (long)blockIdx.x*blockDim.x + threadIdx.x; active_cell(g, lin, m); lin += (long)gridDim.x*blockDim.x) {
     CellState c = load_cell(g, m);
     const Real E0 = c.E, s0 = c.s;
     const Real nHdot = g.nHdot[m];
@@ -281,35 +305,36 @@ k_ion_update(DevGrid g, IonPar p, Real dt, DevScalars *sc)
     floors(c, p, g.Gamma_1);
     if (c.E != E0) Uq(g,4)[m] = c.E;
     if (c.s != s0) Uq(g,5)[m] = c.s;
-    // check_range :223-264
+    const IonQ q = ion_q(c, p, g.Gamma_1);
+    // check_range :223-264.  a/b >= L is tested as a >= L*b when both are positive (the common
+    // case; ratios sit near 1, limits at 11), by division otherwise.
     {
-      const Real n_H = c.s / p.m_H;
       bool counted = false;
-      if (!(g.ph_rate[m] / (p.min_area * n_H) > 2.0*CION)) {
-        const Real e_thermal = c.E - 0.5 * (c.M1*c.M1 + c.M2*c.M2 + c.M3*c.M3) / c.d;
+      const Real ph = g.ph_rate[m];
+      const bool dtype = (q.n_H > 0.0) ? (ph > 2.0*CION*p.min_area*q.n_H) : (ph / (p.min_area * q.n_H) > 2.0*CION);
+      if (!dtype) {
         const Real eth0 = g.e_th_init[m], e0 = g.e_init[m];
-        if ((e_thermal / eth0 >= 1 + p.max_de_therm_step) || (eth0 / e_thermal >= 1 + p.max_de_therm_step)) counted = true;
-        else if ((p.max_de_step > 0) && ((c.E / e0 >= 1 + p.max_de_step) || (e0 / c.E >= 1 + p.max_de_step))) counted = true;
+        const Real L1 = 1 + p.max_de_therm_step, L2 = 1 + p.max_de_step, L3 = 1 + p.max_dx_step;
+        if (ratio_ge(q.e_th, eth0, L1) || ratio_ge(eth0, q.e_th, L1)) counted = true;
+        else if ((p.max_de_step > 0) && (ratio_ge(c.E, e0, L2) || ratio_ge(e0, c.E, L2))) counted = true;
         else if (p.max_dx_step > 0) {
-          const Real n_Hplus = (c.d - c.s) / p.m_H;
-          const Real n_e = n_Hplus + c.d * p.alpha_C / (14.0 * p.m_H);
-          const Real x = n_e / (n_H + n_Hplus), x0 = g.x_init[m];
-          if ((x / x0 >= 1 + p.max_dx_step) || (x0 / x >= 1 + p.max_dx_step)) counted = true;
+          const Real x0 = g.x_init[m];
+          if (ratio_ge(q.x, x0, L3) || ratio_ge(x0, q.x, L3)) counted = true;
         }
       }
-      if (counted) atomicAdd(&cnt, 1u);
+      if (counted) mycnt++;
     }
-    // compute_dt_hydro :609-660
+    // compute_dt_hydro :609-660 (only compared against dt_done, never used as a time step)
     {
-      const Real di = 1.0/c.d, v1 = c.M1*di, v2 = c.M2*di, v3 = c.M3*di;
+      const Real v1 = c.M1*q.di, v2 = c.M2*q.di, v3 = c.M3*q.di;
       const Real qsq = v1*v1 + v2*v2 + v3*v3;
       const Real pp = rmax(g.Gamma_1*(c.E - 0.5*c.d*qsq), AA_TINY);
-      const Real a = sqrt(g.Gamma*pp*di);
-      dti = rmax(dti, (fabs(v1) + a)/g.dx[0]);
-      dti = rmax(dti, (fabs(v2) + a)/g.dx[1]);
-      dti = rmax(dti, (fabs(v3) + a)/g.dx[2]);
+      const Real a = sqrt(g.Gamma*pp*q.di);
+      Real t3 = rmax(rmax((fabs(v1) + a)*p.inv_dx[0], (fabs(v2) + a)*p.inv_dx[1]), (fabs(v3) + a)*p.inv_dx[2]);
+      if (t3 == t3) dti = rmax(dti, t3);
     }
   }
+  if (mycnt) atomicAdd(&cnt, mycnt);
   if (!(dti == dti)) dti = 0.0;
   red[threadIdx.x] = dti;
   __syncthreads();
@@ -331,9 +356,11 @@ void launch_ion_begin(const DevGrid &g, const IonPar &p, hipStream_t st)
 void launch_ray_sweep(const DevGrid &g, const IonPar &p, Real flux0, hipStream_t st)
 { hipLaunchKernelGGL(k_ray_sweep, dim3((g.Nx2 + RS_RAYS - 1)/RS_RAYS, g.Nx3), dim3(256), 0, st, g, p, flux0); }
 void launch_ion_rates(const DevGrid &g, const IonPar &p, DevScalars *sc, hipStream_t st)
-{ const long n = (long)g.Nx1*g.Nx2*g.Nx3; hipLaunchKernelGGL(k_ion_rates, dim3(nblk(n, 256)), dim3(256), 0, st, g, p, sc); }
+{ const long n = (long)g.Nx1*g.Nx2*g.Nx3; unsigned nb = nblk(n, 256); if (nb > 4096) nb = 4096;
+  hipLaunchKernelGGL(k_ion_rates, dim3(nb), dim3(256), 0, st, g, p, sc); }
 void launch_ion_update(const DevGrid &g, const IonPar &p, Real dt, DevScalars *sc, hipStream_t st)
-{ const long n = (long)g.Nx1*g.Nx2*g.Nx3; hipLaunchKernelGGL(k_ion_update, dim3(nblk(n, 256)), dim3(256), 0, st, g, p, dt, sc); }
+{ const long n = (long)g.Nx1*g.Nx2*g.Nx3; unsigned nb = nblk(n, 256); if (nb > 4096) nb = 4096;
+  hipLaunchKernelGGL(k_ion_update, dim3(nb), dim3(256), 0, st, g, p, dt, sc); }
 void launch_edgeflux_bc(const DevGrid &g, Real flux_i, hipStream_t st)
 { const long n = (long)(g.Nx2 + 1)*(g.Nx3 + 1); hipLaunchKernelGGL(k_edgeflux_bc, dim3(nblk(n, 256)), dim3(256), 0, st, g, flux_i); }
 
