@@ -13,6 +13,7 @@
 // march a register sliding window along the sweep direction so no cell is converted or
 // reconstructed twice.  FP64 vector arithmetic throughout: there is no dense contraction, so
 // MFMA is not used.
+#include <stdlib.h>
 #include "grid.h"
 #include "hydro_dev.h"
 
@@ -69,6 +70,28 @@ AA_DEV void face_first_pass(const DevGrid &g, long m, Real dtodx, Real wl[6], Re
 // Stencil kernels want NEIGHBOURING rows in the same L2, so give each XCD one contiguous 1/8 of
 // the linear cell range: logical block = (b % 8)*per + b/8 with the grid rounded up to 8*per.
 AA_DEV long xcd_block(unsigned per) { return (long)(blockIdx.x & 7u)*per + (blockIdx.x >> 3); }
+
+// Zone ordering of the stencil kernels.  `strip` > 0 walks the (i,j,k) box strip-major: j is cut
+// into strips of `strip` rows and each strip is traversed k-plane by k-plane, so the distance
+// between a zone and its k+-1 neighbours is one strip-plane of all streamed fields (tens of MB:
+// resident in the 256 MB Infinity Cache) instead of a full plane (~216 MB at 512^3).
+struct Order { int strip; int xcd; };
+AA_DEV bool decode_zone(const Order o, int ni, int nj, int nk, int &i, int &j, int &k)
+{
+  const long lin = (o.xcd ? xcd_block(gridDim.x >> 3) : (long)blockIdx.x)*blockDim.x + threadIdx.x;
+  if (lin >= (long)ni*nj*nk) return false;
+  if (o.strip <= 0 || o.strip >= nj) {
+    i = (int)(lin % ni); j = (int)((lin / ni) % nj); k = (int)(lin / ((long)ni*nj));
+    return true;
+  }
+  const long per_full = (long)ni*o.strip*nk;          // zones in a full strip
+  const int s = (int)(lin / per_full);
+  const int j0 = s*o.strip;
+  const int sj = (j0 + o.strip <= nj) ? o.strip : nj - j0;   // last strip may be thinner
+  const long r = lin - (long)s*per_full;
+  i = (int)(r % ni); j = j0 + (int)((r / ni) % sj); k = (int)(r / ((long)ni*sj));
+  return true;
+}
 
 // ---- steps 2,3: x2 / x3 sweeps, register sliding window along the sweep direction ---------
 // One thread owns one (i, transverse) column and a chunk of `chunk` interfaces; lanes are
@@ -234,14 +257,12 @@ AA_DEV void correct_face(const DevGrid &g, long m, int i, int j, int k, const Re
 
 template <int NS, bool GRAV>
 __global__ void __launch_bounds__(256)
-k_correct(DevGrid g, Real dt)
+k_correct(DevGrid g, Real dt, Order ord)
 {
   const int ni = g.ie - g.is + 4, nj = g.je - g.js + 4, nk = g.ke - g.ks + 4;   // [s-1, e+2]
-  const long lin = xcd_block(gridDim.x >> 3)*blockDim.x + threadIdx.x;
-  if (lin >= (long)ni*nj*nk) return;
-  const int i = g.is - 1 + (int)(lin % ni);
-  const int j = g.js - 1 + (int)((lin / ni) % nj);
-  const int k = g.ks - 1 + (int)(lin / ((long)ni*nj));
+  int i, j, k;
+  if (!decode_zone(ord, ni, nj, nk, i, j, k)) return;
+  i += g.is - 1; j += g.js - 1; k += g.ks - 1;
   const long m = (long)k*g.sK + (long)j*g.sJ + i;
   Real q[3];
 #pragma unroll
@@ -260,15 +281,13 @@ k_correct(DevGrid g, Real dt)
 // ---- steps 9b-d: second-pass fluxes with the H-correction -----------------------------------
 template <int NS, int D>
 __global__ void __launch_bounds__(256)
-k_flux2(DevGrid g)
+k_flux2(DevGrid g, Order ord)
 {
   // faces needed by the update: along D [s, e+1], transverse [s, e]
   const int ni = g.ie - g.is + 1 + (D == 0), nj = g.je - g.js + 1 + (D == 1), nk = g.ke - g.ks + 1 + (D == 2);
-  const long lin = xcd_block(gridDim.x >> 3)*blockDim.x + threadIdx.x;
-  if (lin >= (long)ni*nj*nk) return;
-  const int i = g.is + (int)(lin % ni);
-  const int j = g.js + (int)((lin / ni) % nj);
-  const int k = g.ks + (int)(lin / ((long)ni*nj));
+  int i, j, k;
+  if (!decode_zone(ord, ni, nj, nk, i, j, k)) return;
+  i += g.is; j += g.js; k += g.ks;
   const long m = (long)k*g.sK + (long)j*g.sJ + i;
   const long sD = stride<D>(g), ml = m - sD;
   // the reference's MAX chain (a > b ? a : b) visits the two transverse directions in
@@ -297,14 +316,12 @@ k_flux2(DevGrid g)
 // ---- steps 11a, 12: gravity source and conservative update ---------------------------------
 template <int NS, bool GRAV>
 __global__ void __launch_bounds__(256)
-k_update(DevGrid g, Real dt)
+k_update(DevGrid g, Real dt, Order ord)
 {
   const int ni = g.ie - g.is + 1, nj = g.je - g.js + 1, nk = g.ke - g.ks + 1;
-  const long lin = xcd_block(gridDim.x >> 3)*blockDim.x + threadIdx.x;
-  if (lin >= (long)ni*nj*nk) return;
-  const int i = g.is + (int)(lin % ni);
-  const int j = g.js + (int)((lin / ni) % nj);
-  const int k = g.ks + (int)(lin / ((long)ni*nj));
+  int i, j, k;
+  if (!decode_zone(ord, ni, nj, nk, i, j, k)) return;
+  i += g.is; j += g.js; k += g.ks;
   const long m = (long)k*g.sK + (long)j*g.sJ + i;
   constexpr int NV = 5 + NS;
   Real u[6];
@@ -474,6 +491,15 @@ __global__ void k_test_lr(Real Gamma, int n, const Real *W, Real dt, Real dx, in
 // host-side launchers
 // =============================================================================================
 static inline unsigned nblk(long n, int b) { return (unsigned)((n + b - 1)/b); }
+static Order zone_order()
+{
+  static Order o = {-1, -1};
+  if (o.strip < 0) {
+    const char *e = getenv("AA_STRIP"); o.strip = e ? atoi(e) : 64;
+    e = getenv("AA_XCD"); o.xcd = e ? atoi(e) : 1;
+  }
+  return o;
+}
 static inline unsigned nblk8(long n, int b) { unsigned x = nblk(n, b); return ((x + 7u)/8u)*8u; }   // for xcd_block()
 
 template <int NS, bool GRAV>
@@ -508,10 +534,10 @@ void launch_correct(const DevGrid &g, int nscal, Real dt, bool grav, hipStream_t
 {
   const long n = (long)(g.ie - g.is + 4)*(g.je - g.js + 4)*(g.ke - g.ks + 4);
   dim3 grid(nblk8(n, 256)), blk(256);
-  if (nscal) { if (grav) hipLaunchKernelGGL((k_correct<1, true>), grid, blk, 0, st, g, dt);
-               else      hipLaunchKernelGGL((k_correct<1, false>), grid, blk, 0, st, g, dt); }
-  else       { if (grav) hipLaunchKernelGGL((k_correct<0, true>), grid, blk, 0, st, g, dt);
-               else      hipLaunchKernelGGL((k_correct<0, false>), grid, blk, 0, st, g, dt); }
+  if (nscal) { if (grav) hipLaunchKernelGGL((k_correct<1, true>), grid, blk, 0, st, g, dt, zone_order());
+               else      hipLaunchKernelGGL((k_correct<1, false>), grid, blk, 0, st, g, dt, zone_order()); }
+  else       { if (grav) hipLaunchKernelGGL((k_correct<0, true>), grid, blk, 0, st, g, dt, zone_order());
+               else      hipLaunchKernelGGL((k_correct<0, false>), grid, blk, 0, st, g, dt, zone_order()); }
 }
 
 template <int NS>
@@ -519,9 +545,9 @@ static void flux2_impl(const DevGrid &g, int dir, hipStream_t st)
 {
   const long n = (long)(g.ie - g.is + 1 + (dir == 0))*(g.je - g.js + 1 + (dir == 1))*(g.ke - g.ks + 1 + (dir == 2));
   dim3 grid(nblk8(n, 256)), blk(256);
-  if (dir == 0) hipLaunchKernelGGL((k_flux2<NS, 0>), grid, blk, 0, st, g);
-  else if (dir == 1) hipLaunchKernelGGL((k_flux2<NS, 1>), grid, blk, 0, st, g);
-  else hipLaunchKernelGGL((k_flux2<NS, 2>), grid, blk, 0, st, g);
+  if (dir == 0) hipLaunchKernelGGL((k_flux2<NS, 0>), grid, blk, 0, st, g, zone_order());
+  else if (dir == 1) hipLaunchKernelGGL((k_flux2<NS, 1>), grid, blk, 0, st, g, zone_order());
+  else hipLaunchKernelGGL((k_flux2<NS, 2>), grid, blk, 0, st, g, zone_order());
 }
 void launch_flux2(const DevGrid &g, int nscal, int dir, hipStream_t st)
 { if (nscal) flux2_impl<1>(g, dir, st); else flux2_impl<0>(g, dir, st); }
@@ -530,10 +556,10 @@ void launch_update(const DevGrid &g, int nscal, Real dt, bool grav, hipStream_t 
 {
   const long n = (long)(g.ie - g.is + 1)*(g.je - g.js + 1)*(g.ke - g.ks + 1);
   dim3 grid(nblk8(n, 256)), blk(256);
-  if (nscal) { if (grav) hipLaunchKernelGGL((k_update<1, true>), grid, blk, 0, st, g, dt);
-               else      hipLaunchKernelGGL((k_update<1, false>), grid, blk, 0, st, g, dt); }
-  else       { if (grav) hipLaunchKernelGGL((k_update<0, true>), grid, blk, 0, st, g, dt);
-               else      hipLaunchKernelGGL((k_update<0, false>), grid, blk, 0, st, g, dt); }
+  if (nscal) { if (grav) hipLaunchKernelGGL((k_update<1, true>), grid, blk, 0, st, g, dt, zone_order());
+               else      hipLaunchKernelGGL((k_update<1, false>), grid, blk, 0, st, g, dt, zone_order()); }
+  else       { if (grav) hipLaunchKernelGGL((k_update<0, true>), grid, blk, 0, st, g, dt, zone_order());
+               else      hipLaunchKernelGGL((k_update<0, false>), grid, blk, 0, st, g, dt, zone_order()); }
 }
 
 void launch_bc(const DevGrid &g, int nscal, int dir, int side, int flag, hipStream_t st)

@@ -21,6 +21,7 @@ inside the C library (aa_step) with no Python between kernels.
 """
 from __future__ import annotations
 
+import os
 from typing import List, Optional
 
 import numpy as np
@@ -87,7 +88,10 @@ class Driver:
         self.eng = engine_factory(self.grid) if engine_factory else HipEngine(self.grid, device, strict)
         self.time, self.dt, self.nstep = 0.0, 0.0, 0
         self.niter_trace: List[int] = []
-        if nranks > 1:
+        # AA_FORCE_DISTRIBUTED=1 runs the Python-orchestrated loop (with its collectives) even on one
+        # rank: used to rehearse the N>1 code path on a single GPU
+        self.distributed = nranks > 1 or bool(os.environ.get("AA_FORCE_DISTRIBUTED"))
+        if self.distributed:
             import torch
             import torch.distributed as dist
             self.torch, self.dist = torch, dist
@@ -96,17 +100,17 @@ class Driver:
 
     # ---- collectives ------------------------------------------------------------------
     def _allreduce(self, vals, op):
-        if self.nranks == 1:
+        if not self.distributed:
             return list(vals)
         t = self.torch.tensor(list(vals), dtype=self.torch.float64, device=self._sdev)
         self.dist.all_reduce(t, op=op)
         return t.tolist()
 
-    def _min(self, *vals): return self._allreduce(vals, self.dist.ReduceOp.MIN if self.nranks > 1 else None)
+    def _min(self, *vals): return self._allreduce(vals, self.dist.ReduceOp.MIN if self.distributed else None)
 
     def exchange_x3(self):
         """bvals_mhd.c:423-493 for the x3 direction."""
-        if self.nranks == 1:
+        if not self.distributed or (self.grid.lx3 < 0 and self.grid.rx3 < 0):
             return
         g, dist = self.grid, self.dist
         host_stage = (dist.get_backend() == "gloo")   # gloo moves host tensors only
@@ -153,7 +157,7 @@ class Driver:
         self.exchange_x3()
 
     def new_dt(self):               # new_dt.c:169-185
-        dtc = self._min(self.eng.new_dt_local())[0] if self.nranks > 1 else self.eng.new_dt_local()
+        dtc = self._min(self.eng.new_dt_local())[0] if self.distributed else self.eng.new_dt_local()
         self.dt = dtc if self.nstep == 0 else min(2.0 * self.dt, dtc)
         if self.time < self.run.tlim and (self.run.tlim - self.time) < self.dt:
             self.dt = self.run.tlim - self.time
@@ -165,14 +169,14 @@ class Driver:
         e.ion_begin()
         while not hydro_done:
             dt_chem, dt_therm = e.ion_rates()
-            if self.nranks > 1:
+            if self.distributed:
                 dt_chem, dt_therm = self._allreduce((dt_chem, dt_therm), self.dist.ReduceOp.MIN)
             dt = min(dt_therm, dt_chem)
             if dt_done + dt > self.dt:
                 dt = self.dt - dt_done
                 hydro_done = True
             cellcount, dt_hydro = e.ion_update(dt)
-            if self.nranks > 1:
+            if self.distributed:
                 # one round: SUM of the count and MIN of dt_hydro (as MAX of its negative)
                 t = self.torch.tensor([float(cellcount), 0.0], dtype=self.torch.float64, device=self._sdev)
                 h = self.torch.tensor([dt_hydro], dtype=self.torch.float64, device=self._sdev)
@@ -199,7 +203,7 @@ class Driver:
 
     # ---- main.c ---------------------------------------------------------------------------------
     def start(self):                # main.c:412-451
-        if self.nranks == 1 and hasattr(self.eng, "start_local"):
+        if not self.distributed and hasattr(self.eng, "start_local"):
             self.eng.start_local()
             self.time, self.dt, self.nstep = self.eng.mesh_state()
             return
@@ -209,7 +213,7 @@ class Driver:
         self.new_dt()
 
     def step(self) -> int:          # main.c:519-669
-        if self.nranks == 1 and hasattr(self.eng, "step_local"):
+        if not self.distributed and hasattr(self.eng, "step_local"):
             niter = self.eng.step_local()
             self.time, self.dt, self.nstep = self.eng.mesh_state()
             self.niter_trace.append(niter)

@@ -92,9 +92,10 @@ def main():
     if not torch.cuda.is_available():
         sys.exit("bench.py needs an MI355X: the hot path has no CPU fallback")
     torch.cuda.set_device(local)
-    if world > 1:
+    force = bool(os.environ.get("AA_FORCE_DISTRIBUTED"))
+    if world > 1 or force:
         import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
 
     # weak scaling: every GPU holds nx^3 zones; the box grows along x3 with the same dx
@@ -113,7 +114,7 @@ def main():
     t_setup = time.time() - t_setup
 
     def barrier():
-        if world > 1:
+        if world > 1 or force:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -132,7 +133,7 @@ def main():
     prof = eng.g.profile() if not a.no_kernel_times else {}
     eng.g.profile_enable(False)
     elapsed = t1 - t0
-    if world > 1:
+    if world > 1 or force:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -174,7 +175,7 @@ def main():
         if not a.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out))
-    if world > 1:
+    if world > 1 or force:
         dist.barrier()
         dist.destroy_process_group()
 
