@@ -116,7 +116,7 @@ int aa_create(const aa_params *p, aa_grid **out)
   d.U = q; q += 6*nc; d.LR = q; q += 36*nc; d.F = q; q += 18*nc; d.eta = q; q += 3*nc; d.dhalf = q; q += nc;
   d.phi = q; q += 4*nc;
   if (p->ion) {
-    d.ph_rate = q; q += nc; d.edot = q; q += nc; d.nHdot = q; q += nc;
+    d.ph_rate = q; q += nc; d.kin = q; q += nc; d.vmax = q; q += nc;
     d.e_init = q; q += nc; d.e_th_init = q; q += nc; d.x_init = q; q += nc;
     d.sign = (int2*)q; q += nc; d.edgeflux = q; q += nef;
     IonPar &ip = g->ion;
@@ -138,6 +138,7 @@ int aa_create(const aa_params *p, aa_grid **out)
     ip.ce1 = p->max_de_therm_iter/(1 + p->max_de_therm_iter); ip.ce2 = p->max_de_iter/(1 + p->max_de_iter);
     ip.ie1 = 1.0/(1.0 + p->max_de_therm_iter); ip.ie2 = 1.0/(1.0 + p->max_de_iter);
     for (int a = 0; a < 3; a++) ip.inv_dx[a] = 1.0/d.dx[a];
+    ip.iso = (d.dx[0] == d.dx[1] && d.dx[1] == d.dx[2]);
   }
   if (hipMalloc(&g->sc, sizeof(DevScalars)) != hipSuccess || hipHostMalloc(&g->sc_host, sizeof(DevScalars)) != hipSuccess) {
     hipFree(g->pool); delete g; return fail(-2, "[aa_create]: scalar buffers");

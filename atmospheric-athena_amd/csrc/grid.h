@@ -12,7 +12,8 @@
 //     eta  : 3*nc   H-correction wave-speed spread per face   (eta1..3, :74)
 //     dhalf: nc                                               (:71)
 //     phi  : 4*nc   static potential at cell centres and at the lower x1/x2/x3 faces
-//   ion module (ionrad_3d.c:33-50): ph_rate, edot, nHdot, e_init, e_th_init, x_init (nc each),
+//   ion module (ionrad_3d.c:33-50): ph_rate, e_init, e_th_init, x_init, plus ke and max|v|/dx frozen
+//   at the start of the ion step (the reference's edot/nHdot arrays are recomputed, not stored),
 //   last_sign/sign_count packed in one int2 array; EdgeFlux [Nx3+1][Nx2+1][Nx1+1].
 #pragma once
 #include <hip/hip_runtime.h>
@@ -32,7 +33,7 @@ struct DevGrid {
   Real *U, *LR, *F, *eta, *dhalf;
   Real *phi;                      // null when StaticGravPot == NULL; [0]=centre, [1+d]=lower face d
   // ion
-  Real *ph_rate, *edot, *nHdot, *e_init, *e_th_init, *x_init;
+  Real *ph_rate, *kin, *vmax, *e_init, *e_th_init, *x_init;   // kin (kinetic energy), vmax: frozen during the ion step
   int2 *sign;                     // .x = last_sign, .y = sign_count
   Real *edgeflux;
   int Nx1, Nx2, Nx3;
@@ -47,6 +48,7 @@ struct IonPar {                   // ionrad.h:54-91 globals
   Real cour_no;
   // host-computed reciprocals / constants (FP64 division is the expensive op in the ion kernels)
   Real inv_mH, inv_kB, aC14, rec_floor, cx1, ce1, ce2, ie1, ie2, inv_dx[3];
+  int iso;                          // dx1 == dx2 == dx3
 };
 
 // device scalars written by reduction kernels (all reductions are MIN/MAX of non-negative

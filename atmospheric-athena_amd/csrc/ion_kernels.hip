@@ -1,19 +1,28 @@
 // ion_kernels.hip -- plane-parallel ionizing-radiation step (ionradiation/ionrad_3d.c,
 // ionradplane_3d.c, ionrad_chemistry.c) as HIP kernels for gfx950.
 //
-// One radiation sub-cycle = three kernels:
-//   ray_sweep   get_ph_rate_plane (ionradplane_3d.c:88): every (j,k) ray is an exclusive prefix
+// During the ion step only E and s0 change; d and the momenta (hence the kinetic energy and the
+// speeds) are frozen.  ion_begin therefore stores ke and max_d|v_d| once, and one radiation
+// sub-cycle is three kernels that touch 1, 5 and 9 fields per zone (the reference's loops touch
+// 6 + scratch each):
+//
+//   ray_sweep   get_ph_rate_plane (ionradplane_3d.c:88).  Every (j,k) ray is an exclusive prefix
 //               product of exp(-tau) along x1 with a data-dependent cut-off.  A block stages a
-//               64-ray x 64-cell tile: all 256 threads evaluate exp(-tau) (the expensive part)
-//               with coalesced loads, then one wavefront -- one lane per ray -- carries the
-//               product serially through LDS in exactly the reference's multiplication order,
-//               then all threads turn the staged incoming fluxes into ph_rate / EdgeFlux with
-//               coalesced stores.  The flux is carried across tiles in LDS; a block whose rays
-//               are all extinguished only streams zeros.
-//   ion_rates   compute_chem_rates + compute_therm_rates (:288, :414) fused, block MIN -> atomics
+//               64-ray x RS_CH-cell tile: all 256 threads evaluate exp(-tau) (the expensive part)
+//               with coalesced loads; one wavefront -- one lane per ray -- carries the product
+//               serially through LDS in exactly the reference's multiplication order; then all
+//               threads turn the staged incoming fluxes into ph_rate / EdgeFlux with coalesced
+//               stores.  The flux is carried across tiles in LDS; a block whose rays are all
+//               extinguished only streams zeros.
+//   ion_rates   compute_chem_rates + compute_therm_rates (ionrad_3d.c:288, :414): the two
+//               time-step limits (block MIN -> 2 atomics per block).  The rates themselves are NOT
+//               stored.
 //   ion_update  ionization_update + apply_temp_floor + apply_neutral_floor + check_range +
-//               compute_dt_hydro (:565, :70, :140, :206, :593) fused: one read-modify-write pass
-// HBM-bound integer-free FP64 streaming; no MFMA.
+//               compute_dt_hydro (:565, :70, :140, :206, :593): re-evaluates the two rates from
+//               (state, ph_rate) -- a log and three exp per cell are cheaper than 32 B/zone of
+//               HBM round trip -- applies them with the globally reduced dt, and reduces the
+//               out-of-range count and the hydro CFL limit.
+// HBM-bound FP64 streaming; no MFMA.
 #include <float.h>
 #include "grid.h"
 #include "hydro_dev.h"
@@ -29,17 +38,14 @@ namespace aa {
 
 AA_DEV Real *Uq(const DevGrid &g, int v) { return g.U + (long)v*g.nc; }
 
-struct CellState { Real d, M1, M2, M3, E, s; };
-struct IonQ { Real n_H, n_Hplus, n_e, x, ke, e_th, T, di, muq; };
-
-AA_DEV CellState load_cell(const DevGrid &g, long m)
-{ CellState c; c.d = Uq(g,0)[m]; c.M1 = Uq(g,1)[m]; c.M2 = Uq(g,2)[m]; c.M3 = Uq(g,3)[m]; c.E = Uq(g,4)[m]; c.s = Uq(g,5)[m]; return c; }
+struct Cell { Real d, ke, E, s; };                       // what the ion step needs of a zone
+struct IonQ { Real n_H, n_Hplus, n_e, x, e_th, T, di, muq; };
 
 // ionrad_3d.c:82-101 (same expressions are repeated at :313-331 and :438-456).  The ion step is
 // not bit-reproducible against the CPU anyway (device exp/log vs glibc), so the seven divisions
 // of the reference are folded into two plus multiplications by host-computed reciprocals:
-// FP64 division is ~10x the cost of a multiply on CDNA4 and these kernels are ALU-bound otherwise.
-AA_DEV IonQ ion_q(const CellState &c, const IonPar &p, Real Gamma_1)
+// FP64 division is ~10x the cost of a multiply on CDNA4.
+AA_DEV IonQ ion_q(const Cell &c, const IonPar &p, Real Gamma_1)
 {
   IonQ q;
   q.n_H = c.s * p.inv_mH;
@@ -47,8 +53,7 @@ AA_DEV IonQ ion_q(const CellState &c, const IonPar &p, Real Gamma_1)
   q.n_e = q.n_Hplus + c.d * p.aC14;
   q.x = q.n_e / (q.n_H + q.n_Hplus);
   q.di = 1.0 / c.d;
-  q.ke = 0.5 * (c.M1*c.M1 + c.M2*c.M2 + c.M3*c.M3) * q.di;
-  q.e_th = c.E - q.ke;
+  q.e_th = c.E - c.ke;
   q.muq = q.x*0.5*p.m_H+(1.0-q.x)*p.mu;
   q.T = Gamma_1 * (q.e_th * q.di) * q.muq * p.inv_kB;
   return q;
@@ -58,20 +63,46 @@ AA_DEV Real neutral_lim(Real d, const IonPar &p)   // ionrad_3d.c:147-148
 { Real d_nlim = d*IONFRACFLOOR; return d_nlim < p.d_nlo ? d_nlim : p.d_nlo; }
 
 // apply_temp_floor (:70-131) then apply_neutral_floor (:140-156) on one cell
-AA_DEV void floors(CellState &c, const IonPar &p, Real Gamma_1)
+AA_DEV void floors(Cell &c, const IonPar &p, Real Gamma_1)
 {
   IonQ q = ion_q(c, p, Gamma_1);
   if (q.T < p.tfloor) {
     Real e_sp = p.tfloor * p.k_B / (q.muq * Gamma_1);
-    c.E = q.ke + e_sp * c.d;
+    c.E = c.ke + e_sp * c.d;
   }
   if ((q.T > p.tceil) && (p.tceil > 0)) {
     Real e_sp = p.tceil * p.k_B / (q.muq * Gamma_1);
-    c.E = q.ke + e_sp * c.d;
+    c.E = c.ke + e_sp * c.d;
   }
   Real d_nlim = neutral_lim(c.d, p);
   if (c.s < d_nlim) c.s = d_nlim; else if (c.s > c.d) c.s = c.d;
 }
+
+// Undamped rate of change of the neutral density (compute_chem_rates, ionrad_3d.c:334-341).
+// recomb_rate_coef = 2.59e-13 (T/1e4)^-0.7 and recomb_cool_rate_coef = 6.11e-10 T^-0.89 k_B T
+// (ionrad_chemistry.c:111,:137) share ONE log: T^y = exp(y ln T) (rel. error ~|y ln T| eps ~1e-15);
+// the floored temperature uses the host-computed coefficient.
+AA_DEV Real chem_rate(const IonQ &q, Real ph, const IonPar &p, Real &lnT, bool &cold)
+{
+  cold = (q.T < p.tfloor);
+  Real rec;
+  if (cold) { lnT = 0.0; rec = p.rec_floor; }
+  else { lnT = log(q.T); rec = 2.59e-13*exp(-0.7*(lnT - 9.210340371976184)); }   // ln(1e4)
+  return rec * p.time_unit * q.n_e * q.n_Hplus - ph * q.n_H;
+}
+
+// edot of compute_therm_rates (ionrad_3d.c:460-490); `skip` cells get 0
+AA_DEV Real therm_rate(const IonQ &q, Real ph, Real lnT, const IonPar &p)
+{
+  const Real Tt = q.T;
+  const Real rcool = (Tt < 100.0) ? 0.0 : 6.11e-10*exp(-0.89*lnT)*KB_CHEM*Tt;          // chemistry :137
+  const Real arg = 118348/Tt;
+  const Real lya = (arg > 745.2) ? 0.0 : -7.5e-19*q.n_e*q.n_H*exp(-arg);              // :350, call at ionrad_3d.c:484
+  return ph * p.e_gamma * q.n_H - rcool * p.time_unit * q.n_Hplus * q.n_e + lya * p.time_unit;
+}
+
+AA_DEV Real damp(Real nHdot, int sign_count)          // ionrad_3d.c:360-363
+{ for (int n = MAXSIGNCOUNT; n < sign_count; n++) nHdot *= DAMPFACTOR; return nHdot; }
 
 AA_DEV bool ratio_ge(Real a, Real b, Real L)
 { return (a > 0.0 && b > 0.0) ? (a >= L*b) : (a / b >= L); }
@@ -86,12 +117,15 @@ AA_DEV bool active_cell(const DevGrid &g, long lin, long &m)
 }
 
 // ---- entry of ion_radtransfer_3d: floors + save_energy_and_x (:896-905, :162-196) -------------
+// also freezes ke and max_d |v_d|
 __global__ void __launch_bounds__(256)
 k_ion_begin(DevGrid g, IonPar p)
 {
   long m;
   if (!active_cell(g, (long)blockIdx.x*blockDim.x + threadIdx.x, m)) return;
-  CellState c = load_cell(g, m);
+  const Real d = Uq(g,0)[m], M1 = Uq(g,1)[m], M2 = Uq(g,2)[m], M3 = Uq(g,3)[m];
+  const Real di = 1.0/d;
+  Cell c; c.d = d; c.ke = 0.5 * (M1*M1 + M2*M2 + M3*M3) * di; c.E = Uq(g,4)[m]; c.s = Uq(g,5)[m];
   const Real E0 = c.E, s0 = c.s;
   floors(c, p, g.Gamma_1);
   if (c.E != E0) Uq(g,4)[m] = c.E;
@@ -101,11 +135,31 @@ k_ion_begin(DevGrid g, IonPar p)
   g.e_th_init[m] = q.e_th;
   g.x_init[m] = q.x;
   g.sign[m] = make_int2(0, 0);
+  g.kin[m] = c.ke;
+  // compute_dt_hydro takes max_d (|v_d| + a)/dx_d with one sound speed a: for dx1=dx2=dx3 that is
+  // (max_d|v_d| + a)/dx exactly, so one frozen number per zone replaces the three momenta
+  g.vmax[m] = rmax(rmax(fabs(M1*di), fabs(M2*di)), fabs(M3*di));
+}
+
+// ---- block reductions --------------------------------------------------------------------------
+AA_DEV void block_min_to(unsigned long long *addr, Real v, Real *red)
+{
+  red[threadIdx.x] = v;
+  __syncthreads();
+  for (int s = blockDim.x/2; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) red[threadIdx.x] = rmin(red[threadIdx.x], red[threadIdx.x + s]);
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) atomicMin(addr, (unsigned long long)__double_as_longlong(red[0]));
+  __syncthreads();
 }
 
 // ---- ray sweep --------------------------------------------------------------------------------
+#ifndef RS_CH
+#define RS_CH 32
+#endif
 #define RS_RAYS 64
-#define RS_CH 64
+#define RS_PASS (RS_RAYS*RS_CH/256)      /* cells per thread per tile */
 __global__ void __launch_bounds__(256)
 k_ray_sweep(DevGrid g, IonPar p, Real flux0)
 {
@@ -118,7 +172,8 @@ k_ray_sweep(DevGrid g, IonPar p, Real flux0)
   const int j0 = g.js + blockIdx.x*RS_RAYS;                 // rays: 64 consecutive j at one k
   const int k = g.ks + blockIdx.y;
   const int nrays = min(RS_RAYS, g.je - j0 + 1);
-  const int col = tid & 63, rsub = tid >> 6;                 // 4 ray-rows per pass, 16 passes
+  const int col = tid % RS_CH, rsub = tid / RS_CH;           // 256/RS_CH ray-rows per pass
+  constexpr int RSTEP = 256/RS_CH;
   const long efp = (long)(g.Nx1 + 1), efrow = (long)(g.Nx2 + 1)*efp;
   if (tid < RS_RAYS) { s_flux[tid] = flux0; s_dead[tid] = (tid < nrays) ? 0 : 1; }
   if (tid == 0) s_nalive = nrays;
@@ -128,11 +183,11 @@ k_ray_sweep(DevGrid g, IonPar p, Real flux0)
     const bool incol = (i <= g.ie);
     const int ncol = min(RS_CH, g.ie - c0 + 1);
     const bool alive = (s_nalive > 0);                        // block-uniform
-    Real nH[RS_RAYS/4];
+    Real nH[RS_PASS];
     if (alive) {
 #pragma unroll
-      for (int q = 0; q < RS_RAYS/4; q++) {
-        const int r = rsub + 4*q;
+      for (int q = 0; q < RS_PASS; q++) {
+        const int r = rsub + RSTEP*q;
         nH[q] = 1.0;
         if (incol && r < nrays) {
           const long m = (long)k*g.sK + (long)(j0 + r)*g.sJ + i;
@@ -158,8 +213,8 @@ k_ray_sweep(DevGrid g, IonPar p, Real flux0)
     }
     __syncthreads();
 #pragma unroll
-    for (int q = 0; q < RS_RAYS/4; q++) {
-      const int r = rsub + 4*q;
+    for (int q = 0; q < RS_PASS; q++) {
+      const int r = rsub + RSTEP*q;
       if (incol && r < nrays) {
         const long m = (long)k*g.sK + (long)(j0 + r)*g.sJ + i;
         Real kph = 0.0, fin = 0.0;
@@ -177,51 +232,21 @@ k_ray_sweep(DevGrid g, IonPar p, Real flux0)
     g.edgeflux[(long)(k - g.ks)*efrow + (long)(j0 + tid - g.js)*efp + g.Nx1] = s_dead[tid] ? 0.0 : s_flux[tid];
 }
 
-// bvals_ionrad.c:63 / outflow_flux_ix1 :308: EdgeFlux[k][j][0] = flux_i for k<=Nx3, j<=Nx2
-__global__ void k_edgeflux_bc(DevGrid g, Real flux_i)
-{
-  const long lin = (long)blockIdx.x*blockDim.x + threadIdx.x;
-  const long n = (long)(g.Nx2 + 1)*(g.Nx3 + 1);
-  if (lin >= n) return;
-  g.edgeflux[lin*(long)(g.Nx1 + 1)] = flux_i;
-}
-
-// ---- rates ------------------------------------------------------------------------------------
-AA_DEV void block_min_to(unsigned long long *addr, Real v, Real *red)
-{
-  red[threadIdx.x] = v;
-  __syncthreads();
-  for (int s = blockDim.x/2; s > 0; s >>= 1) {
-    if ((int)threadIdx.x < s) red[threadIdx.x] = rmin(red[threadIdx.x], red[threadIdx.x + s]);
-    __syncthreads();
-  }
-  if (threadIdx.x == 0) atomicMin(addr, (unsigned long long)__double_as_longlong(red[0]));
-  __syncthreads();
-}
-
+// ---- rates: compute_chem_rates :334-394 + compute_therm_rates :460-557.  Streams d, ke, E, s0,
+// ph_rate (+ the int2 sign bookkeeping), stores nothing but the sign changes, and reduces the two
+// time-step limits (grid-stride; 2 atomics per block) --------------------------------------------
 __global__ void __launch_bounds__(256)
 k_ion_rates(DevGrid g, IonPar p, DevScalars *sc)
 {
   __shared__ Real red[256];
   long m;
   Real dt_chem_min = DBL_MAX, dt_therm_min = DBL_MAX;
-  // grid-stride: a capped grid keeps the number of same-address atomics at 2 per block
-  // (one word sustains only ~90 atomics/us on MI355X; one block per 256 cells made the two
-  // atomicMin of this kernel cost 12 ms at 512^3)
   for (long lin = (long)blockIdx.x*blockDim.x + threadIdx.x; active_cell(g, lin, m); lin += (long)gridDim.x*blockDim.x) {
-    Real dt_chem = DBL_MAX, dt_therm = DBL_MAX;
-    const CellState c = load_cell(g, m);
-    const IonQ q = ion_q(c, p, g.Gamma_1);
+    Cell c; c.d = Uq(g,0)[m]; c.ke = g.kin[m]; c.E = Uq(g,4)[m]; c.s = Uq(g,5)[m];
     const Real ph = g.ph_rate[m];
-    // compute_chem_rates, ionrad_3d.c:334-394.  recomb_rate_coef = 2.59e-13 (T/1e4)^-0.7 and
-    // recomb_cool_rate_coef = 6.11e-10 T^-0.89 k_B T (ionrad_chemistry.c:111,:137) share ONE log:
-    // T^y = exp(y ln T) (rel. error ~ |y ln T| eps ~ 1e-15), and the floored temperature uses the
-    // host-computed coefficient.
-    const bool cold = (q.T < p.tfloor);
-    Real lnT = 0.0, rec;
-    if (cold) rec = p.rec_floor;
-    else { lnT = log(q.T); rec = 2.59e-13*exp(-0.7*(lnT - 9.210340371976184)); }   // ln(1e4)
-    Real nHdot = rec * p.time_unit * q.n_e * q.n_Hplus - ph * q.n_H;
+    const IonQ iq = ion_q(c, p, g.Gamma_1);
+    Real lnT; bool cold;
+    Real nHdot = chem_rate(iq, ph, p, lnT, cold);
     int2 sg = g.sign[m];
     const int2 sg0 = sg;
     if (nHdot < 0.0) {
@@ -232,54 +257,56 @@ k_ion_rates(DevGrid g, IonPar p, DevScalars *sc)
       sg.x = 1;
     } else { sg.x = 0; sg.y = 0; }
     if (sg.x != sg0.x || sg.y != sg0.y) g.sign[m] = sg;
-    for (int n = MAXSIGNCOUNT; n < sg.y; n++) nHdot *= DAMPFACTOR;
-    g.nHdot[m] = nHdot;
+    nHdot = damp(nHdot, sg.y);
     const Real d_nlim = neutral_lim(c.d, p);
     const Real inv_n = 1.0/nHdot;
     Real dt1, dt2;
     if (nHdot == 0.0) { dt1 = dt2 = DBL_MAX; }
     else if (nHdot > 0.0) {
-      dt1 = p.cx1 * q.n_e * inv_n;               // max_dx_iter/(1+max_dx_iter) * n_e / nHdot
-      dt2 = p.max_dx_iter * q.n_H * inv_n;
+      dt1 = p.cx1 * iq.n_e * inv_n;               // max_dx_iter/(1+max_dx_iter) * n_e / nHdot
+      dt2 = p.max_dx_iter * iq.n_H * inv_n;
     } else if (c.s > 1.0001*d_nlim) {
-      dt1 = -p.max_dx_iter * q.n_e * inv_n;
-      dt2 = -p.cx1 * q.n_H * inv_n;
+      dt1 = -p.max_dx_iter * iq.n_e * inv_n;
+      dt2 = -p.cx1 * iq.n_H * inv_n;
     } else { dt1 = dt2 = DBL_MAX; }
-    dt_chem = (dt1 < dt2) ? dt1 : dt2;
+    Real dt_chem = (dt1 < dt2) ? dt1 : dt2;
     if (dt_chem < 0) { atomicExch(&sc->neg_dt_chem, 1); dt_chem = DBL_MAX; }
-    // compute_therm_rates, :460-557 (uses the un-floored T)
-    Real edot = 0.0;
-    bool skip = cold || ((nHdot < 0) && (c.s < 1.0001*d_nlim));
+    Real dt_therm = DBL_MAX;
+    const bool skip = cold || ((nHdot < 0) && (c.s < 1.0001*d_nlim));
     if (!skip) {
-      const Real Tt = q.T;
-      const Real rcool = (Tt < 100.0) ? 0.0 : 6.11e-10*exp(-0.89*lnT)*KB_CHEM*Tt;          // chemistry :137
-      const Real arg = 118348/Tt;
-      const Real lya = (arg > 745.2) ? 0.0 : -7.5e-19*q.n_e*q.n_H*exp(-arg);              // :350, call at ionrad_3d.c:484
-      edot = ph * p.e_gamma * q.n_H - rcool * p.time_unit * q.n_Hplus * q.n_e + lya * p.time_unit;
+      const Real edot = therm_rate(iq, ph, lnT, p);
       Real t1, t2; bool have = true;
       const Real inv_e = 1.0/edot;
       if (edot == 0.0) { t1 = t2 = DBL_MAX; }
       else if (edot > 0.0) {
         t1 = p.max_de_iter * c.E * inv_e;
-        t2 = p.max_de_therm_iter * q.e_th * inv_e;
+        t2 = p.max_de_therm_iter * iq.e_th * inv_e;
       } else {
-        const Real e_sp_min = p.tfloor * p.k_B / (q.muq * g.Gamma_1);
+        const Real e_sp_min = p.tfloor * p.k_B / (iq.muq * g.Gamma_1);
         const Real e_th_min = e_sp_min * c.d;
-        const Real e_min = q.ke + e_th_min;
-        if ((q.e_th*p.ie1 < e_th_min) && (c.E*p.ie2 < e_min)) have = false;   // e/(1+max_de*_iter)
+        const Real e_min = c.ke + e_th_min;
+        if ((iq.e_th*p.ie1 < e_th_min) && (c.E*p.ie2 < e_min)) have = false;   // e/(1+max_de*_iter)
         t1 = -p.ce2 * c.E * inv_e;
-        t2 = -p.ce1 * q.e_th * inv_e;
+        t2 = -p.ce1 * iq.e_th * inv_e;
       }
       if (have) dt_therm = (t1 < t2) ? t1 : t2;
+      if (!(dt_therm == dt_therm) || dt_therm < 0) dt_therm = DBL_MAX;
     }
-    g.edot[m] = edot;
-    if (!(dt_therm == dt_therm) || dt_therm < 0) dt_therm = DBL_MAX;
     dt_chem_min = rmin(dt_chem_min, dt_chem);
     dt_therm_min = rmin(dt_therm_min, dt_therm);
   }
   // dt values are > 0 (or +DBL_MAX): their bit patterns order like the values
   block_min_to(&sc->dt_chem, dt_chem_min, red);
   block_min_to(&sc->dt_therm, dt_therm_min, red);
+}
+
+// bvals_ionrad.c:63 / outflow_flux_ix1 :308: EdgeFlux[k][j][0] = flux_i for k<=Nx3, j<=Nx2
+__global__ void k_edgeflux_bc(DevGrid g, Real flux_i)
+{
+  const long lin = (long)blockIdx.x*blockDim.x + threadIdx.x;
+  const long n = (long)(g.Nx2 + 1)*(g.Nx3 + 1);
+  if (lin >= n) return;
+  g.edgeflux[lin*(long)(g.Nx1 + 1)] = flux_i;
 }
 
 // ---- update + floors + range check + hydro CFL --------------------------------------------------
@@ -293,14 +320,24 @@ k_ion_update(DevGrid g, IonPar p, Real dt, DevScalars *sc)
   long m;
   Real dti = 0.0;
   unsigned int mycnt = 0;
+  const Real *ke_f = g.kin, *vmx_f = g.vmax;
+  // grid-stride: a capped grid keeps the number of same-address atomics at 2 per block (one
+  // word sustains only ~90 atomics/us on MI355X)
   for (long lin = (long)blockIdx.x*blockDim.x + threadIdx.x; active_cell(g, lin, m); lin += (long)gridDim.x*blockDim.x) {
-    CellState c = load_cell(g, m);
+    Cell c; c.d = Uq(g,0)[m]; c.ke = ke_f[m]; c.E = Uq(g,4)[m]; c.s = Uq(g,5)[m];
     const Real E0 = c.E, s0 = c.s;
-    const Real nHdot = g.nHdot[m];
-    const Real d_nlim = neutral_lim(c.d, p);
-    if ((nHdot > 0) || (c.s > 1.0001*d_nlim)) {          // ionization_update :577-585
-      c.E += g.edot[m] * dt;
-      c.s += nHdot * dt * p.m_H;
+    const Real ph = g.ph_rate[m];
+    {   // the rates ray_rates derived its time-step limits from, re-evaluated (same code path)
+      const IonQ q0 = ion_q(c, p, g.Gamma_1);
+      Real lnT; bool cold;
+      const Real nHdot = damp(chem_rate(q0, ph, p, lnT, cold), g.sign[m].y);
+      const Real d_nlim = neutral_lim(c.d, p);
+      const bool skip = cold || ((nHdot < 0) && (c.s < 1.0001*d_nlim));
+      const Real edot = skip ? 0.0 : therm_rate(q0, ph, lnT, p);
+      if ((nHdot > 0) || (c.s > 1.0001*d_nlim)) {          // ionization_update :577-585
+        c.E += edot * dt;
+        c.s += nHdot * dt * p.m_H;
+      }
     }
     floors(c, p, g.Gamma_1);
     if (c.E != E0) Uq(g,4)[m] = c.E;
@@ -310,7 +347,6 @@ k_ion_update(DevGrid g, IonPar p, Real dt, DevScalars *sc)
     // case; ratios sit near 1, limits at 11), by division otherwise.
     {
       bool counted = false;
-      const Real ph = g.ph_rate[m];
       const bool dtype = (q.n_H > 0.0) ? (ph > 2.0*CION*p.min_area*q.n_H) : (ph / (p.min_area * q.n_H) > 2.0*CION);
       if (!dtype) {
         const Real eth0 = g.e_th_init[m], e0 = g.e_init[m];
@@ -326,16 +362,18 @@ k_ion_update(DevGrid g, IonPar p, Real dt, DevScalars *sc)
     }
     // compute_dt_hydro :609-660 (only compared against dt_done, never used as a time step)
     {
-      const Real v1 = c.M1*q.di, v2 = c.M2*q.di, v3 = c.M3*q.di;
-      const Real qsq = v1*v1 + v2*v2 + v3*v3;
-      const Real pp = rmax(g.Gamma_1*(c.E - 0.5*c.d*qsq), AA_TINY);
+      const Real pp = rmax(g.Gamma_1*(c.E - c.ke), AA_TINY);
       const Real a = sqrt(g.Gamma*pp*q.di);
-      Real t3 = rmax(rmax((fabs(v1) + a)*p.inv_dx[0], (fabs(v2) + a)*p.inv_dx[1]), (fabs(v3) + a)*p.inv_dx[2]);
+      Real t3;
+      if (p.iso) t3 = (vmx_f[m] + a)*p.inv_dx[0];
+      else {                                               // anisotropic zones: per-direction speeds
+        const Real v1 = fabs(Uq(g,1)[m]*q.di), v2 = fabs(Uq(g,2)[m]*q.di), v3 = fabs(Uq(g,3)[m]*q.di);
+        t3 = rmax(rmax((v1 + a)*p.inv_dx[0], (v2 + a)*p.inv_dx[1]), (v3 + a)*p.inv_dx[2]);
+      }
       if (t3 == t3) dti = rmax(dti, t3);
     }
   }
   if (mycnt) atomicAdd(&cnt, mycnt);
-  if (!(dti == dti)) dti = 0.0;
   red[threadIdx.x] = dti;
   __syncthreads();
   for (int s = blockDim.x/2; s > 0; s >>= 1) {

@@ -63,6 +63,13 @@ def load(strict: bool | None = None) -> C.CDLL:
     path = os.path.join(HERE, name)
     if not os.path.exists(path):
         raise AthenaError(f"{path} is missing: run __graft_entry__.build() (no CPU fallback exists)")
+    # One HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64.  If this library pulled
+    # in the system runtime first, a later `import torch` in the same process would find "No HIP
+    # GPUs".  Loading torch first makes both share torch's runtime (same SONAME).
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = C.CDLL(path)
     P = C.c_void_p; D = C.c_double; I = C.c_int; LL = C.c_longlong
     dp = C.POINTER(C.c_double); ip = C.POINTER(C.c_int); llp = C.POINTER(C.c_longlong)

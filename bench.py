@@ -34,12 +34,12 @@ KERNEL_BYTES = {
     "sweep_x1": 8 * (6 + 18), "sweep_x2": 8 * (6 + 18), "sweep_x3": 8 * (6 + 18),
     "correct": 8 * (36 + 18 + 36 + 3), "flux2_x1": 8 * (12 + 3 + 6), "flux2_x2": 8 * (12 + 3 + 6),
     "flux2_x3": 8 * (12 + 3 + 6), "update": 8 * (6 + 18 + 6),
-    "ray_sweep": 8 * (1 + 2), "ion_rates": 8 * (6 + 1 + 2 + 2), "ion_update": 8 * (6 + 6 + 2),
-    "ion_begin": 8 * (6 + 4), "bvals_mhd": 0, "new_dt": 8 * 5, "pinned_cells": 0,
+    "ray_sweep": 8 * (1 + 2), "ion_rates": 8 * (5 + 1), "ion_update": 8 * (5 + 1 + 3 + 0.5 + 2),
+    "ion_begin": 8 * (6 + 6), "bvals_mhd": 0, "new_dt": 8 * 5, "pinned_cells": 0,
 }
 
 
-def cpu_baseline(nx=64, nlim=8):
+def cpu_baseline(nx=64, nlim=40):
     """The REAL reference (oracle/_ref, built from /root/reference by oracle/Makefile.ref) timed
     on one host core on a bounded sample of the same deck; falls back to the CPU restatement."""
     exe = os.path.join(ROOT, "oracle", "_ref", "athena_ioniz_sphere")
