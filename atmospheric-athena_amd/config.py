@@ -49,6 +49,10 @@ class RunConfig:
     ionp: Dict[str, float] = field(default_factory=dict)   # <ionradiation> block
     maxiter: int = 0
     prob: Dict[str, float] = field(default_factory=dict)   # <problem> block, numeric keys
+    # compile-time choice of the reference (configure --with-integrator): "ctu" (+ H-correction, the
+    # README.rst:25 configuration) or "vl" (no H-correction: integrate_2d_vl.c:533 does not compile
+    # with it, so that is the only VL build the reference has)
+    integrator: str = "ctu"
 
     @property
     def dx(self) -> Tuple[float, float, float]:

@@ -235,8 +235,14 @@ static void flux_roe(const C1 *Ul, const C1 *Ur, const P1 *Wl, const P1 *Wr, Rea
  * eigensystem reconstruction/esystem_prim.c:120-199.  Reconstructs cells il-1..iu+1,
  * writing Wl[i+1] and Wr[i] (so interfaces il..iu+1 are complete). */
 
+static void lr_states_x(const P1 *W, Real dt, Real dx, int il, int iu, P1 *Wl, P1 *Wr,
+                        Real Gamma, int nscal, int trace);
 static void lr_states(const P1 *W, Real dt, Real dx, int il, int iu, P1 *Wl, P1 *Wr,
                       Real Gamma, int nscal)
+{ lr_states_x(W, dt, dx, il, iu, Wl, Wr, Gamma, nscal, 1); }
+
+static void lr_states_x(const P1 *W, Real dt, Real dx, int il, int iu, P1 *Wl, P1 *Wr,
+                        Real Gamma, int nscal, int trace)
 {
   const Real dtodx = dt/dx;
   const int nv = NW + nscal;
@@ -289,6 +295,11 @@ static void lr_states(const P1 *W, Real dt, Real dx, int il, int iu, P1 *Wl, P1 
     }
     for (n = 0; n < nv; n++) dW[n] = Wrv[n] - Wlv[n];
 
+    if (!trace) {                                                       /* VL_INTEGRATOR, :250-255 */
+      for (n = 0; n < nv; n++) { pWl[n] = Wrv[n]; pWr[n] = Wlv[n]; }
+      if (!nscal) { pWl[5] = 0.0; pWr[5] = 0.0; }
+      continue;
+    }
     qx = 0.5*MAXR(ev4, 0.0)*dtodx;                                      /* :296-313 */
     for (n = 0; n < nv; n++) pWl[n] = Wrv[n] - qx*dW[n];
     qx = -0.5*MINR(ev0, 0.0)*dtodx;
@@ -377,6 +388,8 @@ static Cons from_sweep(const C1 *c, int d)
 /* ------------------------------------------------------------------------------------ */
 /* 3-D CTU integrator: integrators/integrate_3d_ctu.c:110-3368 */
 
+static void integrate_vl(OrcSim *s);
+
 void orc_integrate(OrcSim *s)
 {
   const int nscal = s->p.nscal, nv = NW + nscal;
@@ -391,6 +404,7 @@ void orc_integrate(OrcSim *s)
   int d, e, n, i, j, k;
   const int grav = (s->p.pot != 0);
 
+  if (s->p.integrator == 1) { free(W); free(Wl); free(Wr); integrate_vl(s); return; }
   for (d = 0; d < 3; d++) {
     l[d] = lo[d] - 2; u[d] = hi[d] + 2;
     dtodx[d] = dt/s->dx[d]; q[d] = 0.5*dtodx[d];
@@ -546,6 +560,113 @@ void orc_integrate(OrcSim *s)
       for (n = 0; n < nv; n++) pu[n] -= dtodx[d]*(f1[n] - f0[n]);
     }
   }
+  free(W); free(Wl); free(Wr);
+}
+
+
+/* ------------------------------------------------------------------------------------ */
+/* 3-D van Leer integrator: integrators/integrate_3d_vl.c:96-, NO_H_CORRECTION */
+
+static void integrate_vl(OrcSim *s)
+{
+  const int nscal = s->p.nscal, nv = NW + nscal;
+  const Real Gamma = s->Gamma, Gamma_1 = s->Gamma_1, dt = s->dt;
+  const int N0 = s->N[0], N1 = s->N[1];
+  const size_t str[3] = {1, (size_t)N0, (size_t)N0*N1};
+  const int lo[3] = {s->is, s->js, s->ks}, hi[3] = {s->ie, s->je, s->ke};
+  const size_t nc = (size_t)s->N[0]*s->N[1]*s->N[2];
+  Cons *Uh = s->Ul[0];                  /* Uhalf lives in an unused face array */
+  Real dtodx[3], q[3];
+  int nmax = MAXR(MAXR(s->N[0], s->N[1]), s->N[2]);
+  P1 *W = (P1*)malloc(nmax*sizeof(P1)), *Wl = (P1*)malloc(nmax*sizeof(P1)), *Wr = (P1*)malloc(nmax*sizeof(P1));
+  int d, e, n, i, j, k;
+  const int grav = (s->p.pot != 0);
+  for (d = 0; d < 3; d++) { dtodx[d] = dt/s->dx[d]; q[d] = 0.5*dtodx[d]; }
+  memcpy(Uh, s->U, nc*sizeof(Cons));                                   /* :132-143 */
+
+  /* steps 1-3: first-order (donor-cell) fluxes over the whole ghost range (:153-305) */
+  for (d = 0; d < 3; d++) {
+    const int d1 = (d+1)%3, d2 = (d+2)%3;
+    int a, b, c, idx[3];
+    for (a = lo[d2]-NGHOST; a <= hi[d2]+NGHOST; a++) for (b = lo[d1]-NGHOST; b <= hi[d1]+NGHOST; b++) {
+      size_t base;
+      idx[d1] = b; idx[d2] = a; idx[d] = 0; base = IDX(s, idx[2], idx[1], idx[0]);
+      for (c = lo[d]-NGHOST; c <= hi[d]+NGHOST; c++) {
+        C1 u1 = to_sweep(&s->U[base + c*str[d]], d);
+        W[c] = cons_to_prim(&u1, Gamma_1, nscal);
+      }
+      for (c = lo[d]-(NGHOST-1); c <= hi[d]+NGHOST; c++) {
+        C1 ul, ur, f;
+        Wl[c] = W[c-1]; Wr[c] = W[c];
+        ul = prim_to_cons(&Wl[c], Gamma_1, nscal); ur = prim_to_cons(&Wr[c], Gamma_1, nscal);
+        flux_roe(&ul, &ur, &Wl[c], &Wr[c], 0.0, Gamma, Gamma_1, nscal, &f);
+        s->F[d][base + c*str[d]] = from_sweep(&f, d);
+      }
+    }
+  }
+  /* step 5: half-step update over [s-3, e+3]^3, x1 then x2 then x3 (:392-470) */
+  for (d = 0; d < 3; d++)
+    for (k = lo[2]-3; k <= hi[2]+3; k++) for (j = lo[1]-3; j <= hi[1]+3; j++) for (i = lo[0]-3; i <= hi[0]+3; i++) {
+      size_t m = IDX(s,k,j,i);
+      Real *pu = (Real*)&Uh[m];
+      const Real *f0 = (const Real*)&s->F[d][m], *f1 = (const Real*)&s->F[d][m + str[d]];
+      for (n = 0; n < nv; n++) pu[n] -= q[d]*(f1[n] - f0[n]);
+    }
+  /* step 6a: gravity predictor (:480-510) */
+  if (grav)
+    for (k = lo[2]-3; k <= hi[2]+3; k++) for (j = lo[1]-3; j <= hi[1]+3; j++) for (i = lo[0]-3; i <= hi[0]+3; i++) {
+      size_t m = IDX(s,k,j,i);
+      Real x[3], phic, phir, phil;
+      cc_pos(s, i, j, k, x);
+      phic = phi_at(s, x, 0, 0.0, 0, 0.0);
+      for (e = 0; e < 3; e++) {
+        phir = phi_at(s, x, e, 0.5, e, 0.0);
+        phil = phi_at(s, x, e, -0.5, e, 0.0);
+        Uh[m].M[e] -= q[e]*(phir-phil)*s->U[m].d;
+        Uh[m].E -= q[e]*(s->F[e][m].d*(phic - phil) + s->F[e][m + str[e]].d*(phir - phic));
+      }
+    }
+  /* steps 7-10: PLM (no tracing) on Uhalf and second-order fluxes, etah = 0 (:560-795) */
+  for (d = 0; d < 3; d++) {
+    const int d1 = (d+1)%3, d2 = (d+2)%3;
+    int a, b, c, idx[3];
+    for (a = lo[d2]-1; a <= hi[d2]+1; a++) for (b = lo[d1]-1; b <= hi[d1]+1; b++) {
+      size_t base;
+      idx[d1] = b; idx[d2] = a; idx[d] = 0; base = IDX(s, idx[2], idx[1], idx[0]);
+      for (c = lo[d]-3; c <= hi[d]+3; c++) {
+        C1 u1 = to_sweep(&Uh[base + c*str[d]], d);
+        W[c] = cons_to_prim(&u1, Gamma_1, nscal);
+      }
+      lr_states_x(W, dt, s->dx[d], lo[d], hi[d], Wl, Wr, Gamma, nscal, 0);
+      for (c = lo[d]; c <= hi[d]+1; c++) {
+        C1 ul = prim_to_cons(&Wl[c], Gamma_1, nscal), ur = prim_to_cons(&Wr[c], Gamma_1, nscal), f;
+        flux_roe(&ul, &ur, &Wl[c], &Wr[c], 0.0, Gamma, Gamma_1, nscal, &f);
+        s->F[d][base + c*str[d]] = from_sweep(&f, d);       /* second-order flux replaces the first-order one */
+      }
+    }
+  }
+  /* step 12a: gravity with d^{n+1/2} = Uhalf.d (:832-860) */
+  if (grav)
+    for (k = s->ks; k <= s->ke; k++) for (j = s->js; j <= s->je; j++) for (i = s->is; i <= s->ie; i++) {
+      size_t m = IDX(s,k,j,i);
+      Real x[3], phic, phir, phil;
+      cc_pos(s, i, j, k, x);
+      phic = phi_at(s, x, 0, 0.0, 0, 0.0);
+      for (e = 0; e < 3; e++) {
+        phir = phi_at(s, x, e, 0.5, e, 0.0);
+        phil = phi_at(s, x, e, -0.5, e, 0.0);
+        s->U[m].M[e] -= dtodx[e]*(phir-phil)*Uh[m].d;
+        s->U[m].E -= dtodx[e]*(s->F[e][m].d*(phic - phil) + s->F[e][m + str[e]].d*(phir - phic));
+      }
+    }
+  /* step 13: update (:880-940) */
+  for (d = 0; d < 3; d++)
+    for (k = s->ks; k <= s->ke; k++) for (j = s->js; j <= s->je; j++) for (i = s->is; i <= s->ie; i++) {
+      size_t m = IDX(s,k,j,i);
+      Real *pu = (Real*)&s->U[m];
+      const Real *f0 = (const Real*)&s->F[d][m], *f1 = (const Real*)&s->F[d][m + str[d]];
+      for (n = 0; n < nv; n++) pu[n] -= dtodx[d]*(f1[n] - f0[n]);
+    }
   free(W); free(Wl); free(Wr);
 }
 

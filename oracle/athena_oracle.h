@@ -36,6 +36,8 @@ typedef struct OrcParams {
   double pot_GM, pot_Rsoft;
   int    userwork;     /* 0: none, 1: ioniz_sphere Userwork_in_loop                   */
   double uw_K, uw_Cp, uw_rho0, uw_rreset2;
+  int    integrator;   /* 0: CTU + H-correction (README.rst:25); 1: VL, no H-correction (the
+                          only VL combination the reference compiles)                  */
 } OrcParams;
 
 typedef struct OrcSim OrcSim;
@@ -66,7 +68,7 @@ void   orc_bvals(OrcSim *s);            /* bvals_mhd.c:174                      
 void   orc_bvals_ionrad(OrcSim *s);     /* bvals_ionrad.c:63                                    */
 double orc_new_dt_local(OrcSim *s);     /* new_dt.c:72-170: returns CourNo/max_dti of this grid */
 void   orc_new_dt(OrcSim *s);           /* new_dt.c:32                                          */
-void   orc_integrate(OrcSim *s);        /* integrate_3d_ctu.c:110                               */
+void   orc_integrate(OrcSim *s);        /* integrate_3d_ctu.c:110 or integrate_3d_vl.c:96       */
 int    orc_ion_radtransfer(OrcSim *s);  /* ionrad_3d.c:862; returns niter                       */
 void   orc_userwork(OrcSim *s);         /* ioniz_sphere.c:255                                   */
 int    orc_step(OrcSim *s);             /* one pass of the main loop (main.c:519-669); niter    */

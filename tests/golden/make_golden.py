@@ -105,6 +105,17 @@ def whole_runs():
                                      ["job/num_domains=1", "job/maxout=1", "output1/dt=1e300"],
                                      "ioniz_sphere", 1, True)
             save(f"ioniz_sphere_{nx[0]}x{nx[1]}x{nx[2]}_n{nlim}", f, l, it, nx, [])
+    # van Leer integrator (NO_H_CORRECTION: the only VL build of the reference that compiles)
+    f, l, it = run_reference("blast_vl", blast, (16, 12, 20), 4,
+                             ["job/num_domains=1", "job/maxout=1", "output1/out_fmt=rst", "output1/dt=1e300"], "Blast", 0, False)
+    save("vl_blast_16x12x20_n4", f, l, it, (16, 12, 20), [])
+    f, l, it = run_reference("ioniz_sphere_vl", sphere, (20, 16, 12), 2,
+                             ["job/num_domains=1", "job/maxout=1", "output1/dt=1e300"], "ioniz_sphere", 1, True)
+    save("vl_ioniz_sphere_20x16x12_n2", f, l, it, (20, 16, 12), [])
+    f, l, it = run_reference("ifront_vl", ifront, (16, 8, 8), 3,
+                             ["job/maxout=3", "output3/out_fmt=rst", "output3/dt=1e300", "output1/dt=1e300",
+                              "output2/dt=1e300"], "ifront", 1, True)
+    save("vl_ifront_16x8x8_n3", f, l, it, (16, 8, 8), [])
     for nx, nlims in (((16, 16, 16), (1, 5)), ((12, 20, 16), (4,))):
         for nlim in nlims:
             f, l, it = run_reference("blast", blast, nx, nlim,

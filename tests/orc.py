@@ -32,6 +32,7 @@ class OrcParams(C.Structure):
         ("pot_GM", C.c_double), ("pot_Rsoft", C.c_double),
         ("userwork", C.c_int),
         ("uw_K", C.c_double), ("uw_Cp", C.c_double), ("uw_rho0", C.c_double), ("uw_rreset2", C.c_double),
+        ("integrator", C.c_int),
     ]
 
 
@@ -93,6 +94,7 @@ def params_from_grid(g) -> OrcParams:
         p.bc[b] = g.bc[b]
     p.nscal = r.nscal; p.ion = 1 if r.ion else 0
     p.gamma = r.gamma; p.cour_no = r.cour_no; p.tlim = r.tlim
+    p.integrator = 1 if getattr(r, "integrator", "ctu") == "vl" else 0
     if r.ionp:
         for k, v in r.ionp.items():
             setattr(p, k, v)
@@ -166,9 +168,10 @@ class Sim:
     def ion_dt_hydro(self): return self.L.orc_ion_dt_hydro(self.h)
 
 
-def make_sim(problem, overrides=None, rank=0, nranks=1):
+def make_sim(problem, overrides=None, rank=0, nranks=1, integrator="ctu"):
     aa = importlib.import_module("atmospheric-athena_amd")
     run = aa.config.load(os.path.join(DECKS, "athinput." + problem), overrides, problem)
+    run.integrator = integrator
     return Sim(aa.config.slab(run, rank, nranks)).problem()
 
 

@@ -44,8 +44,11 @@ RUNS = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLD, "*_
 def test_whole_run_bitwise(name):
     g = np.load(os.path.join(GOLD, name + ".npz"))
     prob = name.rsplit("_", 2)[0]
+    integrator = "ctu"
+    if prob.startswith("vl_"):
+        prob, integrator = prob[3:], "vl"
     nx = g["nx"]
-    s = orc.make_sim(prob, [f"domain1/Nx{d + 1}={int(nx[d])}" for d in range(3)])
+    s = orc.make_sim(prob, [f"domain1/Nx{d + 1}={int(nx[d])}" for d in range(3)], integrator=integrator)
     nv = 5 + s.grid.run.nscal
     assert _same(s.active[..., :nv], g["U0"][..., :nv]), "initial condition"
     s.start()
