@@ -108,8 +108,12 @@ def from_par(par: ParTable, problem: Optional[str] = None) -> RunConfig:
     return cfg
 
 
-def load(path: str, overrides=None, problem: Optional[str] = None) -> RunConfig:
-    return from_par(ParTable.from_file(path).cmdline(overrides), problem)
+def load(path: str, overrides=None, problem: Optional[str] = None, integrator: str = "ctu") -> RunConfig:
+    run = from_par(ParTable.from_file(path).cmdline(overrides), problem)
+    if integrator not in ("ctu", "vl"):
+        raise ParError(f"[integrate_init]: unknown integrator {integrator}")
+    run.integrator = integrator
+    return run
 
 
 def split_cells(n: int, parts: int) -> List[int]:

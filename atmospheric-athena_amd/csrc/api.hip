@@ -334,7 +334,21 @@ int aa_integrate_3d_ctu(aa_grid *g)
   { Scope s(g, "flux2_x1"); launch_flux2(d, ns, 0, g->st); }
   { Scope s(g, "flux2_x2"); launch_flux2(d, ns, 1, g->st); }
   { Scope s(g, "flux2_x3"); launch_flux2(d, ns, 2, g->st); }
-  { Scope s(g, "update");   launch_update(d, ns, dt, g->grav, g->st); }
+  { Scope s(g, "update");   launch_update(d, ns, d.dhalf, dt, g->grav, g->st); }
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+int aa_integrate_3d_vl(aa_grid *g)
+{
+  // integrate_3d_vl.c:96-: donor-cell fluxes -> U^{n+1/2} -> PLM (no tracing) + Roe -> update
+  const DevGrid &d = g->d; const int ns = g->p.nscal; const Real dt = g->dt;
+  { Scope s(g, "vl_flux1"); for (int dir = 0; dir < 3; dir++) launch_vl_flux1(d, ns, dir, g->st); }
+  { Scope s(g, "vl_uhalf"); launch_vl_uhalf(d, ns, dt, g->grav, g->st); }
+  { Scope s(g, "vl_flux2_x1"); launch_vl_flux2(d, ns, 0, dt, g->st); }
+  { Scope s(g, "vl_flux2_x2"); launch_vl_flux2(d, ns, 1, dt, g->st); }
+  { Scope s(g, "vl_flux2_x3"); launch_vl_flux2(d, ns, 2, dt, g->st); }
+  { Scope s(g, "update");   launch_update(d, ns, d.LR, dt, g->grav, g->st); }   // d^{n+1/2} = Uhalf.d
   HIPCHK(hipGetLastError());
   return 0;
 }
@@ -422,7 +436,7 @@ int aa_step(aa_grid *g, int *niter_out)
     if ((rc = aa_ion_radtransfer_3d(g, &niter))) return rc;
     if ((rc = aa_bvals_mhd(g))) return rc;
   }
-  if ((rc = aa_integrate_3d_ctu(g))) return rc;              // :572-585
+  if ((rc = (g->p.integrator == 1 ? aa_integrate_3d_vl(g) : aa_integrate_3d_ctu(g)))) return rc;   // :572-585
   if (g->npin > 0 && (rc = aa_apply_pinned_cells(g))) return rc;   // Userwork_in_loop :597
   g->nstep++; g->time += g->dt;                              // :618-626
   if ((rc = aa_new_dt(g))) return rc;                        // :629

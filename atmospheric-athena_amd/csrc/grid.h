@@ -66,7 +66,10 @@ struct DevScalars {
 void launch_sweep(const DevGrid &g, int nscal, int dir, Real dt, bool grav, hipStream_t st);
 void launch_correct(const DevGrid &g, int nscal, Real dt, bool grav, hipStream_t st);
 void launch_flux2(const DevGrid &g, int nscal, int dir, hipStream_t st);
-void launch_update(const DevGrid &g, int nscal, Real dt, bool grav, hipStream_t st);
+void launch_update(const DevGrid &g, int nscal, const Real *dhalf, Real dt, bool grav, hipStream_t st);
+void launch_vl_flux1(const DevGrid &g, int nscal, int dir, hipStream_t st);
+void launch_vl_uhalf(const DevGrid &g, int nscal, Real dt, bool grav, hipStream_t st);
+void launch_vl_flux2(const DevGrid &g, int nscal, int dir, Real dt, hipStream_t st);
 void launch_bc(const DevGrid &g, int nscal, int dir, int side, int flag, hipStream_t st);
 void launch_cfl(const DevGrid &g, DevScalars *sc, hipStream_t st);
 void launch_aos_to_soa(const DevGrid &g, int nvar, const Real *aos, hipStream_t st);

@@ -48,10 +48,10 @@ AA_DEV void store_sweep(Real *fam, long nc, long m, const Real in[6])
 
 // Face work shared by both sweep kernels (steps 1c-1d): gravity kick on the L/R primitive
 // states, conversion to conserved, first-pass flux (etah = 0), store.
-template <int NS, int D, bool GRAV>
+template <int NS, int D, bool GRAV, bool VL>
 AA_DEV void face_first_pass(const DevGrid &g, long m, Real dtodx, Real wl[6], Real wr[6])
 {
-  if (GRAV) {   // integrate_3d_ctu.c:318-342 (x1), :611-628 (x2), :795-812 (x3)
+  if (GRAV && !VL) {   // integrate_3d_ctu.c:318-342 (x1), :611-628 (x2), :795-812 (x3)
     const long s = stride<D>(g);
     Real phicr = Pf(g, 0)[m], phicl = Pf(g, 0)[m - s], phifc = Pf(g, 1 + D)[m];
     wl[1] -= dtodx*(phifc - phicl);
@@ -61,8 +61,11 @@ AA_DEV void face_first_pass(const DevGrid &g, long m, Real dtodx, Real wl[6], Re
   prim_to_cons<NS>(wl, ul, g.Gamma_1);
   prim_to_cons<NS>(wr, ur, g.Gamma_1);
   flux_roe<NS>(ul, ur, wl, wr, 0.0, g.Gamma, g.Gamma_1, f);
-  store_sweep<D, NS>(LRf(g, D, 0, 0), g.nc, m, ul);
-  store_sweep<D, NS>(LRf(g, D, 1, 0), g.nc, m, ur);
+  if (!VL) {     // CTU keeps the face states for the transverse corrections; VL (integrate_3d_vl.c:
+                 // 751-795, no H-correction) needs only the flux
+    store_sweep<D, NS>(LRf(g, D, 0, 0), g.nc, m, ul);
+    store_sweep<D, NS>(LRf(g, D, 1, 0), g.nc, m, ur);
+  }
   store_sweep<D, NS>(Ff(g, D, 0), g.nc, m, f);
 }
 
@@ -96,9 +99,9 @@ AA_DEV bool decode_zone(const Order o, int ni, int nj, int nk, int &i, int &j, i
 // ---- steps 2,3: x2 / x3 sweeps, register sliding window along the sweep direction ---------
 // One thread owns one (i, transverse) column and a chunk of `chunk` interfaces; lanes are
 // consecutive in i.  Cells reconstructed: l..u = s-2..e+2; interfaces l+1..u (:179-184).
-template <int NS, int D, bool GRAV>
+template <int NS, int D, bool GRAV, bool VL>
 __global__ void __launch_bounds__(256)
-k_sweep_march(DevGrid g, Real dt, int chunk)
+k_sweep_march(DevGrid g, const Real *src, Real dt, int chunk)
 {
   static_assert(D == 1 || D == 2, "march kernel is for the strided directions");
   const int ni = g.ie - g.is + 5;                              // i in [is-2, ie+2]
@@ -117,16 +120,16 @@ k_sweep_march(DevGrid g, Real dt, int chunk)
   const Real dtodx = dt/g.dx[D];
 
   Real wm[6], w[6], wp[6], wl_cur[6], wl_next[6], wr[6], u[6];
-  load_sweep<D, NS>(g.U, g.nc, base + (long)(f0 - 2)*s, u); cons_to_prim<NS>(u, wm, g.Gamma_1);
-  load_sweep<D, NS>(g.U, g.nc, base + (long)(f0 - 1)*s, u); cons_to_prim<NS>(u, w,  g.Gamma_1);
-  load_sweep<D, NS>(g.U, g.nc, base + (long)(f0    )*s, u); cons_to_prim<NS>(u, wp, g.Gamma_1);
-  plm_cell<NS, true>(wm, w, wp, dtodx, g.Gamma, wl_cur, wr);   // cell f0-1 -> Wl[f0]
+  load_sweep<D, NS>(src, g.nc, base + (long)(f0 - 2)*s, u); cons_to_prim<NS>(u, wm, g.Gamma_1);
+  load_sweep<D, NS>(src, g.nc, base + (long)(f0 - 1)*s, u); cons_to_prim<NS>(u, w,  g.Gamma_1);
+  load_sweep<D, NS>(src, g.nc, base + (long)(f0    )*s, u); cons_to_prim<NS>(u, wp, g.Gamma_1);
+  plm_cell<NS, !VL>(wm, w, wp, dtodx, g.Gamma, wl_cur, wr);    // cell f0-1 -> Wl[f0]
   for (int f = f0; f <= f1; f++) {
 #pragma unroll
     for (int n = 0; n < 6; n++) { wm[n] = w[n]; w[n] = wp[n]; }
-    load_sweep<D, NS>(g.U, g.nc, base + (long)(f + 1)*s, u); cons_to_prim<NS>(u, wp, g.Gamma_1);
-    plm_cell<NS, true>(wm, w, wp, dtodx, g.Gamma, wl_next, wr); // cell f -> Wl[f+1], Wr[f]
-    face_first_pass<NS, D, GRAV>(g, base + (long)f*s, dtodx, wl_cur, wr);
+    load_sweep<D, NS>(src, g.nc, base + (long)(f + 1)*s, u); cons_to_prim<NS>(u, wp, g.Gamma_1);
+    plm_cell<NS, !VL>(wm, w, wp, dtodx, g.Gamma, wl_next, wr);  // cell f -> Wl[f+1], Wr[f]
+    face_first_pass<NS, D, GRAV, VL>(g, base + (long)f*s, dtodx, wl_cur, wr);
 #pragma unroll
     for (int n = 0; n < 6; n++) wl_cur[n] = wl_next[n];
   }
@@ -135,9 +138,9 @@ k_sweep_march(DevGrid g, Real dt, int chunk)
 // ---- step 1: x1 sweep, neighbours through LDS ------------------------------------------
 // A block of B threads reconstructs B consecutive cells of one (j,k) row and solves the B-1
 // interfaces between them; blocks overlap by one cell.
-template <int NS, bool GRAV>
+template <int NS, bool GRAV, bool VL>
 __global__ void __launch_bounds__(256)
-k_sweep_x1(DevGrid g, Real dt)
+k_sweep_x1(DevGrid g, const Real *src, Real dt)
 {
   extern __shared__ Real sm[];
   const int B = blockDim.x, t = threadIdx.x;
@@ -149,7 +152,7 @@ k_sweep_x1(DevGrid g, Real dt)
   const int P = B + 2;                                 // LDS pitch per component
   Real u[6], w[6];
   const bool have = (c <= g.ie + 3);                   // cells up to ie+3 feed the stencil
-  if (have) { load_sweep<0, NS>(g.U, g.nc, row + c, u); cons_to_prim<NS>(u, w, g.Gamma_1); }
+  if (have) { load_sweep<0, NS>(src, g.nc, row + c, u); cons_to_prim<NS>(u, w, g.Gamma_1); }
   else {
 #pragma unroll
     for (int n = 0; n < 6; n++) w[n] = 1.0;
@@ -158,13 +161,13 @@ k_sweep_x1(DevGrid g, Real dt)
   for (int n = 0; n < 5 + NS; n++) sm[n*P + t + 1] = w[n];
   if (t == 0) {                                        // lower halo cell c0-1 (>= is-3)
     Real uh[6], wh[6];
-    load_sweep<0, NS>(g.U, g.nc, row + c0 - 1, uh); cons_to_prim<NS>(uh, wh, g.Gamma_1);
+    load_sweep<0, NS>(src, g.nc, row + c0 - 1, uh); cons_to_prim<NS>(uh, wh, g.Gamma_1);
 #pragma unroll
     for (int n = 0; n < 5 + NS; n++) sm[n*P] = wh[n];
   }
   if (t == B - 1) {                                    // upper halo cell c0+B
     Real uh[6], wh[6];
-    if (c + 1 <= g.ie + 3) { load_sweep<0, NS>(g.U, g.nc, row + c + 1, uh); cons_to_prim<NS>(uh, wh, g.Gamma_1); }
+    if (c + 1 <= g.ie + 3) { load_sweep<0, NS>(src, g.nc, row + c + 1, uh); cons_to_prim<NS>(uh, wh, g.Gamma_1); }
     else {
 #pragma unroll
       for (int n = 0; n < 6; n++) wh[n] = 1.0;
@@ -178,7 +181,7 @@ k_sweep_x1(DevGrid g, Real dt)
   for (int n = 0; n < 5 + NS; n++) { wm[n] = sm[n*P + t]; wp[n] = sm[n*P + t + 2]; }
   if (!NS) { wm[5] = 0.0; wp[5] = 0.0; }
   const bool recon = (c <= g.ie + 2);                  // cells l..u
-  if (recon) plm_cell<NS, true>(wm, w, wp, dtodx, g.Gamma, wl_next, wr);
+  if (recon) plm_cell<NS, !VL>(wm, w, wp, dtodx, g.Gamma, wl_next, wr);
   else {
 #pragma unroll
     for (int n = 0; n < 6; n++) { wl_next[n] = 1.0; wr[n] = 1.0; }
@@ -192,7 +195,7 @@ k_sweep_x1(DevGrid g, Real dt)
 #pragma unroll
     for (int n = 0; n < 5 + NS; n++) wl[n] = sm[n*P + t - 1];
     if (!NS) wl[5] = 0.0;
-    face_first_pass<NS, 0, GRAV>(g, row + c, dtodx, wl, wr);
+    face_first_pass<NS, 0, GRAV, VL>(g, row + c, dtodx, wl, wr);
   }
 }
 
@@ -316,7 +319,7 @@ k_flux2(DevGrid g, Order ord)
 // ---- steps 11a, 12: gravity source and conservative update ---------------------------------
 template <int NS, bool GRAV>
 __global__ void __launch_bounds__(256)
-k_update(DevGrid g, Real dt, Order ord)
+k_update(DevGrid g, const Real *dhalf, Real dt, Order ord)
 {
   const int ni = g.ie - g.is + 1, nj = g.je - g.js + 1, nk = g.ke - g.ks + 1;
   int i, j, k;
@@ -331,7 +334,7 @@ k_update(DevGrid g, Real dt, Order ord)
 #pragma unroll
   for (int d = 0; d < 3; d++) dtodx[d] = dt/g.dx[d];
   if (GRAV) {   // :2741-2782
-    const Real phic = Pf(g, 0)[m], dh = g.dhalf[m];
+    const Real phic = Pf(g, 0)[m], dh = dhalf[m];
 #pragma unroll
     for (int e = 0; e < 3; e++) {
       const long se = stride_rt(g, e);
@@ -349,6 +352,71 @@ k_update(DevGrid g, Real dt, Order ord)
   }
 #pragma unroll
   for (int v = 0; v < NV; v++) Uf(g, v)[m] = u[v];
+}
+
+// ---- van Leer integrator (integrators/integrate_3d_vl.c, NO_H_CORRECTION) --------------------
+// steps 1-3: first-order (donor-cell) fluxes, Wl = W[c-1], Wr = W[c], over the whole ghost range
+template <int NS, int D>
+__global__ void __launch_bounds__(256)
+k_vl_flux1(DevGrid g)
+{
+  // faces along D: [s-3, e+4]; transverse: all zones incl. ghosts (:153-305)
+  const int N[3] = {g.N1, g.N2, g.N3};
+  int n[3] = {N[0], N[1], N[2]};
+  n[D] = N[D] - 1;                                         // faces 1 .. N-1  (= s-3 .. e+4)
+  const long lin = (long)blockIdx.x*blockDim.x + threadIdx.x;
+  if (lin >= (long)n[0]*n[1]*n[2]) return;
+  int idx[3];
+  idx[0] = (int)(lin % n[0]); idx[1] = (int)((lin / n[0]) % n[1]); idx[2] = (int)(lin / ((long)n[0]*n[1]));
+  idx[D] += 1;
+  const long m = (long)idx[2]*g.sK + (long)idx[1]*g.sJ + idx[0];
+  const long s = stride<D>(g);
+  Real u[6], wl[6], wr[6], ul[6], ur[6], f[6];
+  load_sweep<D, NS>(g.U, g.nc, m - s, u); cons_to_prim<NS>(u, wl, g.Gamma_1);
+  load_sweep<D, NS>(g.U, g.nc, m, u);     cons_to_prim<NS>(u, wr, g.Gamma_1);
+  prim_to_cons<NS>(wl, ul, g.Gamma_1);                     // the reference round-trips through W (:166-169)
+  prim_to_cons<NS>(wr, ur, g.Gamma_1);
+  flux_roe<NS>(ul, ur, wl, wr, 0.0, g.Gamma, g.Gamma_1, f);
+  store_sweep<D, NS>(Ff(g, D, 0), g.nc, m, f);
+}
+
+// steps 5-6: U^{n+1/2} over [s-3, e+3]^3 (x1, x2, x3 flux differences in that order, then the
+// gravity predictor); stored in the first six face-state arrays
+template <int NS, bool GRAV>
+__global__ void __launch_bounds__(256)
+k_vl_uhalf(DevGrid g, Real dt)
+{
+  const int ni = g.ie - g.is + 7, nj = g.je - g.js + 7, nk = g.ke - g.ks + 7;
+  const long lin = (long)blockIdx.x*blockDim.x + threadIdx.x;
+  if (lin >= (long)ni*nj*nk) return;
+  const int i = g.is - 3 + (int)(lin % ni), j = g.js - 3 + (int)((lin / ni) % nj), k = g.ks - 3 + (int)(lin / ((long)ni*nj));
+  const long m = (long)k*g.sK + (long)j*g.sJ + i;
+  constexpr int NV = 5 + NS;
+  Real u[6], q[3];
+#pragma unroll
+  for (int v = 0; v < NV; v++) u[v] = Uf(g, v)[m];
+  const Real d0 = u[0];
+#pragma unroll
+  for (int d = 0; d < 3; d++) q[d] = 0.5*(dt/g.dx[d]);
+#pragma unroll
+  for (int d = 0; d < 3; d++) {
+    const long sd = stride_rt(g, d);
+#pragma unroll
+    for (int v = 0; v < NV; v++) { const Real *f = Ff(g, d, v); u[v] -= q[d]*(f[m + sd] - f[m]); }
+  }
+  if (GRAV) {   // :480-510
+    const Real phic = Pf(g, 0)[m];
+#pragma unroll
+    for (int e = 0; e < 3; e++) {
+      const long se = stride_rt(g, e);
+      const Real phir = Pf(g, 1 + e)[m + se], phil = Pf(g, 1 + e)[m];
+      const Real *fd = Ff(g, e, 0);
+      u[1 + e] -= q[e]*(phir - phil)*d0;
+      u[4] -= q[e]*(fd[m]*(phic - phil) + fd[m + se]*(phir - phic));
+    }
+  }
+#pragma unroll
+  for (int v = 0; v < NV; v++) LRf(g, 0, 0, v)[m] = u[v];
 }
 
 // ---- physical boundary conditions: bvals_mhd.c reflect :959, outflow :1319, periodic :1637 ---
@@ -502,8 +570,8 @@ static Order zone_order()
 }
 static inline unsigned nblk8(long n, int b) { unsigned x = nblk(n, b); return ((x + 7u)/8u)*8u; }   // for xcd_block()
 
-template <int NS, bool GRAV>
-static void sweep_impl(const DevGrid &g, int dir, Real dt, hipStream_t st)
+template <int NS, bool GRAV, bool VL>
+static void sweep_impl(const DevGrid &g, const Real *src, int dir, Real dt, hipStream_t st)
 {
   if (dir == 0) {
     const int nfaces = (g.ie - g.is + 1) + 3;          // interfaces l+1..u
@@ -513,21 +581,46 @@ static void sweep_impl(const DevGrid &g, int dir, Real dt, hipStream_t st)
     nb = (nfaces + (B - 1) - 1)/(B - 1);
     dim3 grid(nb, g.je - g.js + 5, g.ke - g.ks + 5);
     size_t lds = (size_t)(5 + NS)*(B + 2)*sizeof(Real);
-    hipLaunchKernelGGL((k_sweep_x1<NS, GRAV>), grid, dim3(B), lds, st, g, dt);
+    hipLaunchKernelGGL((k_sweep_x1<NS, GRAV, VL>), grid, dim3(B), lds, st, g, src, dt);
   } else {
     const int chunk = 32;
     const long ni = g.ie - g.is + 5;
     const long nt = (dir == 1 ? g.ke - g.ks : g.je - g.js) + 5;
     const int nfaces = (dir == 1 ? g.je - g.js : g.ke - g.ks) + 1 + 3;
     dim3 grid(nblk(ni*nt, 64), (nfaces + chunk - 1)/chunk);
-    if (dir == 1) hipLaunchKernelGGL((k_sweep_march<NS, 1, GRAV>), grid, dim3(64), 0, st, g, dt, chunk);
-    else          hipLaunchKernelGGL((k_sweep_march<NS, 2, GRAV>), grid, dim3(64), 0, st, g, dt, chunk);
+    if (dir == 1) hipLaunchKernelGGL((k_sweep_march<NS, 1, GRAV, VL>), grid, dim3(64), 0, st, g, src, dt, chunk);
+    else          hipLaunchKernelGGL((k_sweep_march<NS, 2, GRAV, VL>), grid, dim3(64), 0, st, g, src, dt, chunk);
   }
 }
 void launch_sweep(const DevGrid &g, int nscal, int dir, Real dt, bool grav, hipStream_t st)
 {
-  if (nscal) { if (grav) sweep_impl<1, true>(g, dir, dt, st); else sweep_impl<1, false>(g, dir, dt, st); }
-  else       { if (grav) sweep_impl<0, true>(g, dir, dt, st); else sweep_impl<0, false>(g, dir, dt, st); }
+  if (nscal) { if (grav) sweep_impl<1, true, false>(g, g.U, dir, dt, st); else sweep_impl<1, false, false>(g, g.U, dir, dt, st); }
+  else       { if (grav) sweep_impl<0, true, false>(g, g.U, dir, dt, st); else sweep_impl<0, false, false>(g, g.U, dir, dt, st); }
+}
+// VL second-order fluxes: PLM without tracing on U^{n+1/2} (kept in LR[0][L]), etah = 0
+void launch_vl_flux2(const DevGrid &g, int nscal, int dir, Real dt, hipStream_t st)
+{
+  if (nscal) sweep_impl<1, false, true>(g, g.LR, dir, dt, st); else sweep_impl<0, false, true>(g, g.LR, dir, dt, st);
+}
+template <int NS>
+static void vl_flux1_impl(const DevGrid &g, int dir, hipStream_t st)
+{
+  long n[3] = {g.N1, g.N2, g.N3}; n[dir] -= 1;
+  dim3 grid(nblk(n[0]*n[1]*n[2], 256)), blk(256);
+  if (dir == 0) hipLaunchKernelGGL((k_vl_flux1<NS, 0>), grid, blk, 0, st, g);
+  else if (dir == 1) hipLaunchKernelGGL((k_vl_flux1<NS, 1>), grid, blk, 0, st, g);
+  else hipLaunchKernelGGL((k_vl_flux1<NS, 2>), grid, blk, 0, st, g);
+}
+void launch_vl_flux1(const DevGrid &g, int nscal, int dir, hipStream_t st)
+{ if (nscal) vl_flux1_impl<1>(g, dir, st); else vl_flux1_impl<0>(g, dir, st); }
+void launch_vl_uhalf(const DevGrid &g, int nscal, Real dt, bool grav, hipStream_t st)
+{
+  const long n = (long)(g.ie - g.is + 7)*(g.je - g.js + 7)*(g.ke - g.ks + 7);
+  dim3 grid(nblk(n, 256)), blk(256);
+  if (nscal) { if (grav) hipLaunchKernelGGL((k_vl_uhalf<1, true>), grid, blk, 0, st, g, dt);
+               else      hipLaunchKernelGGL((k_vl_uhalf<1, false>), grid, blk, 0, st, g, dt); }
+  else       { if (grav) hipLaunchKernelGGL((k_vl_uhalf<0, true>), grid, blk, 0, st, g, dt);
+               else      hipLaunchKernelGGL((k_vl_uhalf<0, false>), grid, blk, 0, st, g, dt); }
 }
 
 void launch_correct(const DevGrid &g, int nscal, Real dt, bool grav, hipStream_t st)
@@ -552,14 +645,14 @@ static void flux2_impl(const DevGrid &g, int dir, hipStream_t st)
 void launch_flux2(const DevGrid &g, int nscal, int dir, hipStream_t st)
 { if (nscal) flux2_impl<1>(g, dir, st); else flux2_impl<0>(g, dir, st); }
 
-void launch_update(const DevGrid &g, int nscal, Real dt, bool grav, hipStream_t st)
+void launch_update(const DevGrid &g, int nscal, const Real *dhalf, Real dt, bool grav, hipStream_t st)
 {
   const long n = (long)(g.ie - g.is + 1)*(g.je - g.js + 1)*(g.ke - g.ks + 1);
   dim3 grid(nblk8(n, 256)), blk(256);
-  if (nscal) { if (grav) hipLaunchKernelGGL((k_update<1, true>), grid, blk, 0, st, g, dt, zone_order());
-               else      hipLaunchKernelGGL((k_update<1, false>), grid, blk, 0, st, g, dt, zone_order()); }
-  else       { if (grav) hipLaunchKernelGGL((k_update<0, true>), grid, blk, 0, st, g, dt, zone_order());
-               else      hipLaunchKernelGGL((k_update<0, false>), grid, blk, 0, st, g, dt, zone_order()); }
+  if (nscal) { if (grav) hipLaunchKernelGGL((k_update<1, true>), grid, blk, 0, st, g, dhalf, dt, zone_order());
+               else      hipLaunchKernelGGL((k_update<1, false>), grid, blk, 0, st, g, dhalf, dt, zone_order()); }
+  else       { if (grav) hipLaunchKernelGGL((k_update<0, true>), grid, blk, 0, st, g, dhalf, dt, zone_order());
+               else      hipLaunchKernelGGL((k_update<0, false>), grid, blk, 0, st, g, dhalf, dt, zone_order()); }
 }
 
 void launch_bc(const DevGrid &g, int nscal, int dir, int side, int flag, hipStream_t st)

@@ -55,7 +55,7 @@ class HipEngine:
     def bvals_local(self): self.g.bvals_mhd()
     def bvals_ionrad(self): self.g.bvals_ionrad()
     def new_dt_local(self) -> float: return self.g.new_dt_local()
-    def integrate(self): self.g.integrate_3d_ctu()
+    def integrate(self): self.g.integrate()
     def userwork(self): self.g.apply_pinned_cells()
     def ion_begin(self): self.g.ion_begin()
     def ion_rates(self): return self.g.ion_rates()

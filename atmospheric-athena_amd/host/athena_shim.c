@@ -44,6 +44,17 @@ static double *host_block(void) { return (double*)&(PG->U[0][0][0]); }   /* ath_
 static double *host_edgeflux(void) { return (double*)&(PG->EdgeFlux[0][0][0]); }
 #endif
 
+/* configure --with-integrator=vl  <->  -DAA_VL_INTEGRATOR at compile time, or AA_INTEGRATOR=vl */
+static int use_vl(void)
+{
+#ifdef AA_VL_INTEGRATOR
+  return 1;
+#else
+  const char *e = getenv("AA_INTEGRATOR");
+  return (e && strcmp(e, "vl") == 0);
+#endif
+}
+
 static void ensure_grid(MeshS *pM)
 {
   aa_params p; DomainS *pD; int d; const char *env;
@@ -84,6 +95,7 @@ static void ensure_grid(MeshS *pM)
     p.maxiter = (int)par_getd("ionradiation", "maxiter");
   }
   env = getenv("AA_DEVICE"); p.device = env ? atoi(env) : 0;
+  p.integrator = use_vl();
   CHK(aa_create(&p, &G));
   ncell = (size_t)(PG->Nx[0] + 2*AA_NGHOST)*(PG->Nx[1] + 2*AA_NGHOST)*(PG->Nx[2] + 2*AA_NGHOST);
 #if AA_ION_RADPLANE
@@ -119,7 +131,7 @@ static void integrate_3d_ctu_amd(DomainS *pD)
   GridS *pG = pD->Grid;
   to_device();
   CHK(aa_set_mesh_state(G, M->time, pG->dt, M->nstep));
-  CHK(aa_integrate_3d_ctu(G));
+  if (use_vl()) CHK(aa_integrate_3d_vl(G)); else CHK(aa_integrate_3d_ctu(G));
   if (learn && learned) { CHK(aa_apply_pinned_cells(G)); return; }
   to_host();                                    /* Userwork_in_loop reads and may write pG->U */
   host_newer = 1;

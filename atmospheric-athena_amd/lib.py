@@ -32,7 +32,7 @@ class aa_params(C.Structure):
         ("max_de_iter", C.c_double), ("max_de_therm_iter", C.c_double), ("max_dx_iter", C.c_double),
         ("max_de_step", C.c_double), ("max_de_therm_step", C.c_double), ("max_dx_step", C.c_double),
         ("tfloor", C.c_double), ("tceil", C.c_double),
-        ("maxiter", C.c_int), ("device", C.c_int),
+        ("maxiter", C.c_int), ("device", C.c_int), ("integrator", C.c_int),
     ]
 
 
@@ -88,7 +88,7 @@ def load(strict: bool | None = None) -> C.CDLL:
         "aa_set_pinned_cells": (I, [P, LL, llp, dp]), "aa_apply_pinned_cells": (I, [P]),
         "aa_add_radplane_3d": (I, [P, I, D]),
         "aa_bvals_mhd": (I, [P]), "aa_bvals_ionrad": (I, [P]), "aa_new_dt": (I, [P]),
-        "aa_integrate_3d_ctu": (I, [P]), "aa_ion_radtransfer_3d": (I, [P, ip]),
+        "aa_integrate_3d_ctu": (I, [P]), "aa_integrate_3d_vl": (I, [P]), "aa_ion_radtransfer_3d": (I, [P, ip]),
         "aa_start": (I, [P]), "aa_step": (I, [P, ip]),
         "aa_new_dt_local": (I, [P, dp]), "aa_ion_begin": (I, [P]), "aa_ion_rates": (I, [P, dp, dp]),
         "aa_ion_update": (I, [P, D, llp, dp]),
@@ -142,6 +142,7 @@ def params_from_grid(g: GridConfig, device: int = 0) -> aa_params:
         setattr(p, k, v)
     p.maxiter = r.maxiter
     p.device = device
+    p.integrator = 1 if r.integrator == "vl" else 0
     return p
 
 
@@ -230,6 +231,14 @@ class Grid:
     def bvals_ionrad(self): self._chk(self.L.aa_bvals_ionrad(self._h))
     def new_dt(self): self._chk(self.L.aa_new_dt(self._h))
     def integrate_3d_ctu(self): self._chk(self.L.aa_integrate_3d_ctu(self._h))
+    def integrate_3d_vl(self): self._chk(self.L.aa_integrate_3d_vl(self._h))
+
+    def integrate(self):
+        """(*Integrate)(pD): the function pointer integrate_init() selected (integrate.c:63-75)."""
+        if self.cfg.run.integrator == "vl":
+            self.integrate_3d_vl()
+        else:
+            self.integrate_3d_ctu()
     def apply_pinned_cells(self): self._chk(self.L.aa_apply_pinned_cells(self._h))
     def start(self): self._chk(self.L.aa_start(self._h))
 

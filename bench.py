@@ -76,6 +76,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--nx", type=int, default=512, help="zones per direction per GPU (default: the 512^3 workload)")
     ap.add_argument("--problem", default="ioniz_sphere", choices=["ioniz_sphere", "ifront", "blast"])
+    ap.add_argument("--integrator", default="ctu", choices=["ctu", "vl"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-times", action="store_true")
     a = ap.parse_args()
@@ -106,6 +107,7 @@ def main():
     par.cmdline([f"domain1/Nx1={nx}", f"domain1/Nx2={nx}", f"domain1/Nx3={nx * world}",
                  f"domain1/x3max={x3min + (x3max - x3min) * world!r}"])
     run = aa.config.from_par(par, a.problem)
+    run.integrator = a.integrator
     t_setup = time.time()
     drv = driver.Driver(run, None, rank, world, local)
     drv.start()
@@ -147,7 +149,8 @@ def main():
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * elapsed / a.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
             "data": "synthetic (ioniz_sphere deck values on a uniform grid, generated in place)",
-            "config": {"workload": f"{a.problem} {nx}x{nx}x{nx * world} single level, CTU+PLM+Roe+H-correction"
+            "config": {"workload": f"{a.problem} {nx}x{nx}x{nx * world} single level, "
+                                   + ("CTU+PLM+Roe+H-correction" if a.integrator == "ctu" else "VL+PLM+Roe")
                                    + (" + static gravity + plane-parallel ion radiation" if a.problem == "ioniz_sphere"
                                       else (" + plane-parallel ion radiation" if a.problem == "ifront" else "")),
                        "zones_per_gpu": nx ** 3, "partition": f"x3 slabs x{world}", "nvar": 5 + run.nscal,

@@ -39,6 +39,8 @@ typedef struct aa_params {
   double tfloor, tceil;
   int    maxiter;
   int    device;           /* HIP device ordinal                                                */
+  int    integrator;       /* 0: CTU + H-correction (configure default + --enable-h-correction);
+                              1: van Leer, no H-correction (--with-integrator=vl)              */
 } aa_params;
 
 typedef struct aa_grid aa_grid;
@@ -80,6 +82,7 @@ int aa_bvals_mhd(aa_grid *g);                       /* bvals_mhd.c:174 (physical
 int aa_bvals_ionrad(aa_grid *g);                    /* bvals_ionrad.c:63                          */
 int aa_new_dt(aa_grid *g);                          /* new_dt.c:32                                */
 int aa_integrate_3d_ctu(aa_grid *g);                /* integrate_3d_ctu.c:110, dt = Grid dt       */
+int aa_integrate_3d_vl(aa_grid *g);                 /* integrate_3d_vl.c:96 (NO_H_CORRECTION)     */
 int aa_ion_radtransfer_3d(aa_grid *g, int *niter);  /* ionrad_3d.c:862; may shrink the Grid dt    */
 int aa_start(aa_grid *g);                           /* main.c:412-451: bvals, bvals_ionrad, new_dt */
 int aa_step(aa_grid *g, int *niter);                /* one pass of main.c:519-669                 */

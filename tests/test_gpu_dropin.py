@@ -20,6 +20,7 @@ REFBIN = os.path.join(ROOT, "oracle", "_ref")
 
 
 def run(exe, problem, nx, nlim, env_extra=None):
+    problem = problem.replace("_vl", "")
     from make_golden import read_rst
     tmp = tempfile.mkdtemp(prefix="dropin_")
     deck = os.path.join(tmp, "athinput")
@@ -32,7 +33,7 @@ def run(exe, problem, nx, nlim, env_extra=None):
                         stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, cwd=tmp, env=env, timeout=600)
     assert pr.returncode == 0, pr.stdout[-1500:] + pr.stderr[-1500:]
     rsts = sorted(f for f in os.listdir(os.path.join(tmp, "run")) if f.endswith(".rst"))
-    ion = problem != "blast"
+    ion = not problem.startswith("blast")
     out = read_rst(os.path.join(tmp, "run", rsts[-1]), nx, 1 if ion else 0, ion)
     shutil.rmtree(tmp)
     return out, pr.stderr
@@ -43,6 +44,8 @@ def run(exe, problem, nx, nlim, env_extra=None):
     ("ifront", (16, 8, 8), 4, {}),
     ("ioniz_sphere", (32, 32, 32), 3, {}),
     ("ioniz_sphere", (32, 32, 32), 3, {"AA_COHERENCE": "learn"}),
+    ("blast_vl", (24, 16, 20), 4, {}),                  # --with-integrator=vl builds of the reference
+    ("ioniz_sphere_vl", (32, 32, 32), 3, {}),
 ])
 def test_reference_driver_on_gpu_library(problem, nx, nlim, env):
     if not os.path.exists(os.path.join(REFBIN, f"athena_{problem}_amd")):
@@ -52,12 +55,12 @@ def test_reference_driver_on_gpu_library(problem, nx, nlim, env):
     assert "[athena_amd] Grid" in err
     assert gpu["nstep"] == ref["nstep"] == nlim
     assert abs(gpu["time"] / ref["time"] - 1) < 1e-9 and abs(gpu["dt"] / ref["dt"] - 1) < 1e-9
-    nv = 5 if problem == "blast" else 6
+    nv = 5 if problem.startswith("blast") else 6
     a, b = gpu["U"][..., :nv], ref["U"][..., :nv]
     scale = np.abs(b).max(axis=(0, 1, 2))
     diff = np.abs(a - b).max(axis=(0, 1, 2))
     assert np.all(diff[scale == 0] == 0)
     err = (diff[scale > 0] / scale[scale > 0]).max()
     assert err < 1e-8, err                       # north_star bar: 1e-6 on density / ion fraction
-    if problem != "blast":
+    if not problem.startswith("blast"):
         assert np.allclose(gpu["edgeflux"], ref["edgeflux"], rtol=1e-8, atol=1e-8 * np.abs(ref["edgeflux"]).max())

@@ -72,10 +72,10 @@ def test_kernels_vs_reference_vectors(lib, strict, nscal):
 
 
 # ---------------------------------------------------------------------------------------
-def run_pair(aa, lib, problem, nx, nsteps, strict):
+def run_pair(aa, lib, problem, nx, nsteps, strict, integrator="ctu"):
     ov = [f"domain1/Nx{d + 1}={nx[d]}" for d in range(3)]
-    o = orc.make_sim(problem, ov)
-    run = aa.config.load(os.path.join(orc.DECKS, "athinput." + problem), ov, problem)
+    o = orc.make_sim(problem, ov, integrator=integrator)
+    run = aa.config.load(os.path.join(orc.DECKS, "athinput." + problem), ov, problem, integrator)
     g = lib.setup_problem(aa.config.slab(run), 0, strict)
     nv = 5 + run.nscal
     assert np.array_equal(g.host_initial[4:-4, 4:-4, 4:-4, :nv], o.active[..., :nv]), "problem generators disagree"
@@ -164,6 +164,38 @@ def test_ioniz_sphere_vs_oracle(aa, lib, nx, nsteps, strict):
     # fused multiply-adds) moves a few cells by ~1e-6; every other case holds 1e-8.
     tol = 2e-5 if nx == (24, 16, 12) else 1e-8
     assert max(err) < tol, err
+    g.close()
+
+
+@pytest.mark.parametrize("nx,nsteps", [((16, 12, 20), 4), ((40, 24, 32), 3)])
+def test_vl_blast_bitwise_strict(aa, lib, nx, nsteps):
+    """van Leer integrator (integrate_3d_vl.c, NO_H_CORRECTION), hydro only: bit for bit."""
+    o, g, nv, trace = run_pair(aa, lib, "blast", nx, nsteps, True, "vl")
+    for (_, _, dto, dtg, to, tg) in trace:
+        assert dto == dtg and to == tg
+    U = g.download()
+    assert np.array_equal(U[..., :nv], o.U[..., :nv]), relerr(U[..., :nv], o.U[..., :nv])
+    g.close()
+
+
+def test_vl_golden_fixtures(aa, lib):
+    gz = np.load(os.path.join(GOLD, "vl_blast_16x12x20_n4.npz"))
+    o, g, nv, trace = run_pair(aa, lib, "blast", (16, 12, 20), 4, True, "vl")
+    assert np.array_equal(g.download()[4:-4, 4:-4, 4:-4, :nv], gz["U"][..., :nv]) and g.dt == float(gz["dt"])
+    g.close()
+    gz = np.load(os.path.join(GOLD, "vl_ifront_16x8x8_n3.npz"))
+    o, g, nv, trace = run_pair(aa, lib, "ifront", (16, 8, 8), 3, False, "vl")
+    assert [t[1] for t in trace] == [int(x) for x in gz["niter"]]
+    assert max(relerr(g.download()[4:-4, 4:-4, 4:-4, :nv], gz["U"][..., :nv])) < 1e-8
+    g.close()
+
+
+@pytest.mark.parametrize("problem,nx,nsteps", [("ifront", (16, 8, 8), 3), ("ioniz_sphere", (32, 32, 32), 2)])
+def test_vl_ion_problems_vs_oracle(aa, lib, problem, nx, nsteps):
+    o, g, nv, trace = run_pair(aa, lib, problem, nx, nsteps, False, "vl")
+    assert [t[0] for t in trace] == [t[1] for t in trace], trace
+    err = relerr(g.download()[4:-4, 4:-4, 4:-4, :nv], o.active[..., :nv])
+    assert max(err) < 1e-8, err
     g.close()
 
 
