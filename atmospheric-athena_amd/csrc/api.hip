@@ -330,7 +330,9 @@ int aa_integrate_3d_ctu(aa_grid *g)
   { Scope s(g, "sweep_x1"); launch_sweep(d, ns, 0, dt, g->grav, g->st); }
   { Scope s(g, "sweep_x2"); launch_sweep(d, ns, 1, dt, g->grav, g->st); }
   { Scope s(g, "sweep_x3"); launch_sweep(d, ns, 2, dt, g->grav, g->st); }
-  { Scope s(g, "correct");  launch_correct(d, ns, dt, g->grav, g->st); }
+  { Scope s(g, "correct_x1"); launch_correct(d, ns, 0, dt, g->grav, g->st); }
+  { Scope s(g, "correct_x2"); launch_correct(d, ns, 1, dt, g->grav, g->st); }
+  { Scope s(g, "correct_x3"); launch_correct(d, ns, 2, dt, g->grav, g->st); }
   { Scope s(g, "flux2_x1"); launch_flux2(d, ns, 0, g->st); }
   { Scope s(g, "flux2_x2"); launch_flux2(d, ns, 1, g->st); }
   { Scope s(g, "flux2_x3"); launch_flux2(d, ns, 2, g->st); }

@@ -3,9 +3,10 @@
 //
 // Kernel chain of one integrate_3d_ctu() call (reference steps in brackets):
 //   sweep<x1>, sweep<x2>, sweep<x3>   [1-3]  prim conversion + PLM/tracing + gravity kick +
-//                                            first-pass Roe flux; writes Ul,Ur,F of that direction
-//   correct                           [5-8a,9a] transverse flux-gradient corrections of all six
-//                                            face states in place, d^{n+1/2}, eta of every face
+//                                            first-pass Roe flux; writes only F of that direction
+//   correct<x1>, <x2>, <x3>           [5-8a,9a] same sweep, L/R states re-derived instead of read
+//                                            back, transverse flux-gradient corrections, stores the
+//                                            corrected Ul,Ur and eta of the faces (x1 also d^{n+1/2})
 //   flux2<x1>, flux2<x2>, flux2<x3>   [9b-d] etah = max of 9 etas, second-pass Roe flux
 //   update                            [11a,12] gravity source + conservative update of U
 // All arrays are struct-of-arrays with i fastest (grid.h); every global access of a wavefront
@@ -46,172 +47,32 @@ AA_DEV void store_sweep(Real *fam, long nc, long m, const Real in[6])
   for (int n = 0; n < 5 + NS; n++) fam[(long)gv<D>(n)*nc + m] = in[n];
 }
 
-// Face work shared by both sweep kernels (steps 1c-1d): gravity kick on the L/R primitive
-// states, conversion to conserved, first-pass flux (etah = 0), store.
-template <int NS, int D, bool GRAV, bool VL>
-AA_DEV void face_first_pass(const DevGrid &g, long m, Real dtodx, Real wl[6], Real wr[6])
-{
-  if (GRAV && !VL) {   // integrate_3d_ctu.c:318-342 (x1), :611-628 (x2), :795-812 (x3)
-    const long s = stride<D>(g);
-    Real phicr = Pf(g, 0)[m], phicl = Pf(g, 0)[m - s], phifc = Pf(g, 1 + D)[m];
-    wl[1] -= dtodx*(phifc - phicl);
-    wr[1] -= dtodx*(phicr - phifc);
-  }
-  Real ul[6], ur[6], f[6];
-  prim_to_cons<NS>(wl, ul, g.Gamma_1);
-  prim_to_cons<NS>(wr, ur, g.Gamma_1);
-  flux_roe<NS>(ul, ur, wl, wr, 0.0, g.Gamma, g.Gamma_1, f);
-  if (!VL) {     // CTU keeps the face states for the transverse corrections; VL (integrate_3d_vl.c:
-                 // 751-795, no H-correction) needs only the flux
-    store_sweep<D, NS>(LRf(g, D, 0, 0), g.nc, m, ul);
-    store_sweep<D, NS>(LRf(g, D, 1, 0), g.nc, m, ur);
-  }
-  store_sweep<D, NS>(Ff(g, D, 0), g.nc, m, f);
-}
+// What a sweep does at each interface once the L/R primitive states are known.
+//   MODE_FLUX1  CTU steps 1c-1d: gravity kick, conversion to conserved, first-pass flux (etah=0);
+//               only the flux is stored
+//   MODE_CORR   CTU steps 5-7 + 9a: the same L/R states are RE-derived (bit-identical: same code),
+//               corrected with the transverse flux gradients (+ gravity), stored, and the
+//               H-correction eta of the face is computed.  Recomputing PLM here instead of storing
+//               the uncorrected face states in the first pass and reading them back saves
+//               2 x 12 doubles of HBM traffic per zone and direction.
+//   MODE_VL     integrate_3d_vl.c:751-795: no tracing (done in plm_cell), no kick, flux only
+enum { MODE_FLUX1 = 0, MODE_CORR = 1, MODE_VL = 2 };
 
-// Workgroups are dealt round-robin over the 8 XCDs (blockIdx b and b+8 share an XCD and its L2).
-// Stencil kernels want NEIGHBOURING rows in the same L2, so give each XCD one contiguous 1/8 of
-// the linear cell range: logical block = (b % 8)*per + b/8 with the grid rounded up to 8*per.
-AA_DEV long xcd_block(unsigned per) { return (long)(blockIdx.x & 7u)*per + (blockIdx.x >> 3); }
-
-// Zone ordering of the stencil kernels.  `strip` > 0 walks the (i,j,k) box strip-major: j is cut
-// into strips of `strip` rows and each strip is traversed k-plane by k-plane, so the distance
-// between a zone and its k+-1 neighbours is one strip-plane of all streamed fields (tens of MB:
-// resident in the 256 MB Infinity Cache) instead of a full plane (~216 MB at 512^3).
-struct Order { int strip; int xcd; };
-AA_DEV bool decode_zone(const Order o, int ni, int nj, int nk, int &i, int &j, int &k)
-{
-  const long lin = (o.xcd ? xcd_block(gridDim.x >> 3) : (long)blockIdx.x)*blockDim.x + threadIdx.x;
-  if (lin >= (long)ni*nj*nk) return false;
-  if (o.strip <= 0 || o.strip >= nj) {
-    i = (int)(lin % ni); j = (int)((lin / ni) % nj); k = (int)(lin / ((long)ni*nj));
-    return true;
-  }
-  const long per_full = (long)ni*o.strip*nk;          // zones in a full strip
-  const int s = (int)(lin / per_full);
-  const int j0 = s*o.strip;
-  const int sj = (j0 + o.strip <= nj) ? o.strip : nj - j0;   // last strip may be thinner
-  const long r = lin - (long)s*per_full;
-  i = (int)(r % ni); j = j0 + (int)((r / ni) % sj); k = (int)(r / ((long)ni*sj));
-  return true;
-}
-
-// ---- steps 2,3: x2 / x3 sweeps, register sliding window along the sweep direction ---------
-// One thread owns one (i, transverse) column and a chunk of `chunk` interfaces; lanes are
-// consecutive in i.  Cells reconstructed: l..u = s-2..e+2; interfaces l+1..u (:179-184).
-template <int NS, int D, bool GRAV, bool VL>
-__global__ void __launch_bounds__(256)
-k_sweep_march(DevGrid g, const Real *src, Real dt, int chunk)
-{
-  static_assert(D == 1 || D == 2, "march kernel is for the strided directions");
-  const int ni = g.ie - g.is + 5;                              // i in [is-2, ie+2]
-  const int tlo = (D == 1 ? g.ks : g.js) - 2;
-  const int nt  = (D == 1 ? g.ke - g.ks : g.je - g.js) + 5;
-  const long lin = (long)blockIdx.x*blockDim.x + threadIdx.x;
-  if (lin >= (long)ni*nt) return;
-  const int i = g.is - 2 + (int)(lin % ni);
-  const int t = tlo + (int)(lin / ni);
-  const int lo = (D == 1 ? g.js : g.ks), hi = (D == 1 ? g.je : g.ke);
-  const int f0 = lo - 1 + blockIdx.y*chunk;                    // first interface of this chunk
-  int f1 = f0 + chunk - 1; if (f1 > hi + 2) f1 = hi + 2;
-  if (f0 > f1) return;
-  const long s = stride<D>(g);
-  const long base = (D == 1) ? ((long)t*g.sK + i) : ((long)t*g.sJ + i);
-  const Real dtodx = dt/g.dx[D];
-
-  Real wm[6], w[6], wp[6], wl_cur[6], wl_next[6], wr[6], u[6];
-  load_sweep<D, NS>(src, g.nc, base + (long)(f0 - 2)*s, u); cons_to_prim<NS>(u, wm, g.Gamma_1);
-  load_sweep<D, NS>(src, g.nc, base + (long)(f0 - 1)*s, u); cons_to_prim<NS>(u, w,  g.Gamma_1);
-  load_sweep<D, NS>(src, g.nc, base + (long)(f0    )*s, u); cons_to_prim<NS>(u, wp, g.Gamma_1);
-  plm_cell<NS, !VL>(wm, w, wp, dtodx, g.Gamma, wl_cur, wr);    // cell f0-1 -> Wl[f0]
-  for (int f = f0; f <= f1; f++) {
-#pragma unroll
-    for (int n = 0; n < 6; n++) { wm[n] = w[n]; w[n] = wp[n]; }
-    load_sweep<D, NS>(src, g.nc, base + (long)(f + 1)*s, u); cons_to_prim<NS>(u, wp, g.Gamma_1);
-    plm_cell<NS, !VL>(wm, w, wp, dtodx, g.Gamma, wl_next, wr);  // cell f -> Wl[f+1], Wr[f]
-    face_first_pass<NS, D, GRAV, VL>(g, base + (long)f*s, dtodx, wl_cur, wr);
-#pragma unroll
-    for (int n = 0; n < 6; n++) wl_cur[n] = wl_next[n];
-  }
-}
-
-// ---- step 1: x1 sweep, neighbours through LDS ------------------------------------------
-// A block of B threads reconstructs B consecutive cells of one (j,k) row and solves the B-1
-// interfaces between them; blocks overlap by one cell.
-template <int NS, bool GRAV, bool VL>
-__global__ void __launch_bounds__(256)
-k_sweep_x1(DevGrid g, const Real *src, Real dt)
-{
-  extern __shared__ Real sm[];
-  const int B = blockDim.x, t = threadIdx.x;
-  const int j = g.js - 2 + blockIdx.y, k = g.ks - 2 + blockIdx.z;
-  const int c0 = g.is - 2 + blockIdx.x*(B - 1);
-  const int c = c0 + t;
-  const long row = (long)k*g.sK + (long)j*g.sJ;
-  const Real dtodx = dt/g.dx[0];
-  const int P = B + 2;                                 // LDS pitch per component
-  Real u[6], w[6];
-  const bool have = (c <= g.ie + 3);                   // cells up to ie+3 feed the stencil
-  if (have) { load_sweep<0, NS>(src, g.nc, row + c, u); cons_to_prim<NS>(u, w, g.Gamma_1); }
-  else {
-#pragma unroll
-    for (int n = 0; n < 6; n++) w[n] = 1.0;
-  }
-#pragma unroll
-  for (int n = 0; n < 5 + NS; n++) sm[n*P + t + 1] = w[n];
-  if (t == 0) {                                        // lower halo cell c0-1 (>= is-3)
-    Real uh[6], wh[6];
-    load_sweep<0, NS>(src, g.nc, row + c0 - 1, uh); cons_to_prim<NS>(uh, wh, g.Gamma_1);
-#pragma unroll
-    for (int n = 0; n < 5 + NS; n++) sm[n*P] = wh[n];
-  }
-  if (t == B - 1) {                                    // upper halo cell c0+B
-    Real uh[6], wh[6];
-    if (c + 1 <= g.ie + 3) { load_sweep<0, NS>(src, g.nc, row + c + 1, uh); cons_to_prim<NS>(uh, wh, g.Gamma_1); }
-    else {
-#pragma unroll
-      for (int n = 0; n < 6; n++) wh[n] = 1.0;
-    }
-#pragma unroll
-    for (int n = 0; n < 5 + NS; n++) sm[n*P + B + 1] = wh[n];
-  }
-  __syncthreads();
-  Real wm[6], wp[6], wl_next[6], wr[6];
-#pragma unroll
-  for (int n = 0; n < 5 + NS; n++) { wm[n] = sm[n*P + t]; wp[n] = sm[n*P + t + 2]; }
-  if (!NS) { wm[5] = 0.0; wp[5] = 0.0; }
-  const bool recon = (c <= g.ie + 2);                  // cells l..u
-  if (recon) plm_cell<NS, !VL>(wm, w, wp, dtodx, g.Gamma, wl_next, wr);
-  else {
-#pragma unroll
-    for (int n = 0; n < 6; n++) { wl_next[n] = 1.0; wr[n] = 1.0; }
-  }
-  __syncthreads();
-#pragma unroll
-  for (int n = 0; n < 5 + NS; n++) sm[n*P + t] = wl_next[n];
-  __syncthreads();
-  if (t >= 1 && recon) {                               // interface c, between cells c-1 and c
-    Real wl[6];
-#pragma unroll
-    for (int n = 0; n < 5 + NS; n++) wl[n] = sm[n*P + t - 1];
-    if (!NS) wl[5] = 0.0;
-    face_first_pass<NS, 0, GRAV, VL>(g, row + c, dtodx, wl, wr);
-  }
-}
-
-// ---- steps 5-7, 8a, 9a: transverse corrections, d^{n+1/2}, eta -----------------------------
-// One thread per cell (i,j,k) in [s-1, e+2]^3 handles the cell's three LOWER faces.
 template <int NS, int D, bool GRAV>
-AA_DEV void correct_face(const DevGrid &g, long m, int i, int j, int k, const Real q[3])
+AA_DEV void face_correct(const DevGrid &g, long m, int i, int j, int k, Real dt, const Real ul_s[6], const Real ur_s[6])
 {
-  // ranges (integrate_3d_ctu.c:978, :1282, :1691): along D [s-1, e+2], transverse [s-1, e+1]
-  const bool in = (D == 0 || i <= g.ie + 1) && (D == 1 || j <= g.je + 1) && (D == 2 || k <= g.ke + 1);
+  // ranges (integrate_3d_ctu.c:978, :1282, :1691): along D [s-1, e+2] (the sweep's own range),
+  // transverse [s-1, e+1]
+  const bool in = (D == 0 || (i >= g.is - 1 && i <= g.ie + 1)) && (D == 1 || (j >= g.js - 1 && j <= g.je + 1)) &&
+                  (D == 2 || (k >= g.ks - 1 && k <= g.ke + 1));
   if (!in) return;
   constexpr int NV = 5 + NS;
   const long sD = stride<D>(g), ml = m - sD;
-  Real ul[6], ur[6];
+  Real ul[6], ur[6], q[3];
 #pragma unroll
-  for (int v = 0; v < NV; v++) { ul[v] = LRf(g, D, 0, v)[m]; ur[v] = LRf(g, D, 1, v)[m]; }
+  for (int n = 0; n < 6; n++) { ul[gv<D>(n)] = ul_s[n]; ur[gv<D>(n)] = ur_s[n]; }   // to the global frame
+#pragma unroll
+  for (int d = 0; d < 3; d++) q[d] = 0.5*(dt/g.dx[d]);
 #pragma unroll
   for (int e = 0; e < 3; e++) {
     if (e == D) continue;
@@ -256,29 +117,233 @@ AA_DEV void correct_face(const DevGrid &g, long m, int i, int j, int k, const Re
   Real cfr = cfast(sr, g.Gamma, g.Gamma_1), cfl = cfast(sl, g.Gamma, g.Gamma_1);
   Real lambdar = sr[1]/sr[0] + cfr, lambdal = sl[1]/sl[0] - cfl;
   Ef(g, D)[m] = 0.5*fabs(lambdar - lambdal);
-}
-
-template <int NS, bool GRAV>
-__global__ void __launch_bounds__(256)
-k_correct(DevGrid g, Real dt, Order ord)
-{
-  const int ni = g.ie - g.is + 4, nj = g.je - g.js + 4, nk = g.ke - g.ks + 4;   // [s-1, e+2]
-  int i, j, k;
-  if (!decode_zone(ord, ni, nj, nk, i, j, k)) return;
-  i += g.is - 1; j += g.js - 1; k += g.ks - 1;
-  const long m = (long)k*g.sK + (long)j*g.sJ + i;
-  Real q[3];
-#pragma unroll
-  for (int d = 0; d < 3; d++) q[d] = 0.5*(dt/g.dx[d]);
-  if (GRAV && i <= g.ie + 1 && j <= g.je + 1 && k <= g.ke + 1) {       // :2104-2125
+  if (GRAV && D == 0 && i <= g.ie + 1) {       // d^{n+1/2}, :2104-2125 (needs first-pass fluxes)
     g.dhalf[m] = Uf(g, 0)[m]
       - q[0]*(Ff(g, 0, 0)[m + 1]    - Ff(g, 0, 0)[m])
       - q[1]*(Ff(g, 1, 0)[m + g.sJ] - Ff(g, 1, 0)[m])
       - q[2]*(Ff(g, 2, 0)[m + g.sK] - Ff(g, 2, 0)[m]);
   }
-  correct_face<NS, 0, GRAV>(g, m, i, j, k, q);
-  correct_face<NS, 1, GRAV>(g, m, i, j, k, q);
-  correct_face<NS, 2, GRAV>(g, m, i, j, k, q);
+}
+
+template <int NS, int D, bool GRAV, int MODE>
+AA_DEV void face_work(const DevGrid &g, long m, int i, int j, int k, Real dt, Real wl[6], Real wr[6])
+{
+  if (GRAV && MODE != MODE_VL) {   // integrate_3d_ctu.c:318-342 (x1), :611-628 (x2), :795-812 (x3)
+    const long s = stride<D>(g);
+    const Real dtodx = dt/g.dx[D];
+    Real phicr = Pf(g, 0)[m], phicl = Pf(g, 0)[m - s], phifc = Pf(g, 1 + D)[m];
+    wl[1] -= dtodx*(phifc - phicl);
+    wr[1] -= dtodx*(phicr - phifc);
+  }
+  Real ul[6], ur[6];
+  prim_to_cons<NS>(wl, ul, g.Gamma_1);
+  prim_to_cons<NS>(wr, ur, g.Gamma_1);
+  if (MODE == MODE_CORR) { face_correct<NS, D, GRAV>(g, m, i, j, k, dt, ul, ur); return; }
+  Real f[6];
+  flux_roe<NS>(ul, ur, wl, wr, 0.0, g.Gamma, g.Gamma_1, f);
+  store_sweep<D, NS>(Ff(g, D, 0), g.nc, m, f);
+}
+
+// Workgroups are dealt round-robin over the 8 XCDs (blockIdx b and b+8 share an XCD and its L2).
+// Stencil kernels want NEIGHBOURING rows in the same L2, so give each XCD one contiguous 1/8 of
+// the linear cell range: logical block = (b % 8)*per + b/8 with the grid rounded up to 8*per.
+AA_DEV long xcd_block(unsigned per) { return (long)(blockIdx.x & 7u)*per + (blockIdx.x >> 3); }
+
+// Zone ordering of the stencil kernels.  `strip` > 0 walks the (i,j,k) box strip-major: j is cut
+// into strips of `strip` rows and each strip is traversed k-plane by k-plane, so the distance
+// between a zone and its k+-1 neighbours is one strip-plane of all streamed fields (tens of MB:
+// resident in the 256 MB Infinity Cache) instead of a full plane (~216 MB at 512^3).
+struct Order { int strip; int xcd; };
+AA_DEV bool decode_zone(const Order o, int ni, int nj, int nk, int &i, int &j, int &k)
+{
+  const long lin = (o.xcd ? xcd_block(gridDim.x >> 3) : (long)blockIdx.x)*blockDim.x + threadIdx.x;
+  if (lin >= (long)ni*nj*nk) return false;
+  if (o.strip <= 0 || o.strip >= nj) {
+    i = (int)(lin % ni); j = (int)((lin / ni) % nj); k = (int)(lin / ((long)ni*nj));
+    return true;
+  }
+  const long per_full = (long)ni*o.strip*nk;          // zones in a full strip
+  const int s = (int)(lin / per_full);
+  const int j0 = s*o.strip;
+  const int sj = (j0 + o.strip <= nj) ? o.strip : nj - j0;   // last strip may be thinner
+  const long r = lin - (long)s*per_full;
+  i = (int)(r % ni); j = j0 + (int)((r / ni) % sj); k = (int)(r / ((long)ni*sj));
+  return true;
+}
+
+// ---- steps 2,3: x2 / x3 sweeps, register sliding window along the sweep direction ---------
+// One thread owns one (i, transverse) column and a chunk of `chunk` interfaces; lanes are
+// consecutive in i.  Cells reconstructed: l..u = s-2..e+2; interfaces l+1..u (:179-184).
+template <int NS, int D, bool GRAV, int MODE>
+__global__ void __launch_bounds__(256)
+k_sweep_march(DevGrid g, const Real *src, Real dt, int chunk)
+{
+  static_assert(D == 1 || D == 2, "march kernel is for the strided directions");
+  const int ni = g.ie - g.is + 5;                              // i in [is-2, ie+2]
+  const int tlo = (D == 1 ? g.ks : g.js) - 2;
+  const int nt  = (D == 1 ? g.ke - g.ks : g.je - g.js) + 5;
+  const long lin = (long)blockIdx.x*blockDim.x + threadIdx.x;
+  if (lin >= (long)ni*nt) return;
+  const int i = g.is - 2 + (int)(lin % ni);
+  const int t = tlo + (int)(lin / ni);
+  const int lo = (D == 1 ? g.js : g.ks), hi = (D == 1 ? g.je : g.ke);
+  const int f0 = lo - 1 + blockIdx.y*chunk;                    // first interface of this chunk
+  int f1 = f0 + chunk - 1; if (f1 > hi + 2) f1 = hi + 2;
+  if (f0 > f1) return;
+  const long s = stride<D>(g);
+  const long base = (D == 1) ? ((long)t*g.sK + i) : ((long)t*g.sJ + i);
+  const Real dtodx = dt/g.dx[D];
+
+  Real wm[6], w[6], wp[6], wl_cur[6], wl_next[6], wr[6], u[6];
+  load_sweep<D, NS>(src, g.nc, base + (long)(f0 - 2)*s, u); cons_to_prim<NS>(u, wm, g.Gamma_1);
+  load_sweep<D, NS>(src, g.nc, base + (long)(f0 - 1)*s, u); cons_to_prim<NS>(u, w,  g.Gamma_1);
+  load_sweep<D, NS>(src, g.nc, base + (long)(f0    )*s, u); cons_to_prim<NS>(u, wp, g.Gamma_1);
+  plm_cell<NS, MODE != MODE_VL>(wm, w, wp, dtodx, g.Gamma, wl_cur, wr);    // cell f0-1 -> Wl[f0]
+  for (int f = f0; f <= f1; f++) {
+#pragma unroll
+    for (int n = 0; n < 6; n++) { wm[n] = w[n]; w[n] = wp[n]; }
+    load_sweep<D, NS>(src, g.nc, base + (long)(f + 1)*s, u); cons_to_prim<NS>(u, wp, g.Gamma_1);
+    plm_cell<NS, MODE != MODE_VL>(wm, w, wp, dtodx, g.Gamma, wl_next, wr);  // cell f -> Wl[f+1], Wr[f]
+    face_work<NS, D, GRAV, MODE>(g, base + (long)f*s, i, D == 1 ? f : t, D == 1 ? t : f, dt, wl_cur, wr);
+#pragma unroll
+    for (int n = 0; n < 6; n++) wl_cur[n] = wl_next[n];
+  }
+}
+
+// ---- x2 / x3 sweeps on an LDS tile (used for the correct pass) ------------------------------------
+// A block of 64 x BT threads owns 64 independent columns (consecutive i) and BT consecutive cells
+// of each along the sweep direction; W goes through LDS once ([comp][BT+2][64]: a wavefront reads
+// 64 consecutive doubles, conflict-free), neighbours and the Wl hand-off come from LDS, blocks
+// overlap by one cell.  One cell per thread keeps the correct pass at ~130 VGPRs (3 waves/SIMD)
+// where the marching form needs 255 (1 wave/SIMD, latency-bound: 32 ms instead of 9 at 512^3).
+template <int NS, int D, bool GRAV, int MODE, int BT>
+__global__ void __launch_bounds__(64*BT)
+k_sweep_tile(DevGrid g, const Real *src, Real dt)
+{
+  static_assert(D == 1 || D == 2, "tile kernel is for the strided directions");
+  extern __shared__ Real sm[];
+  const int lane = threadIdx.x, t = threadIdx.y;
+  const int ni = g.ie - g.is + 5;
+  const int tlo = (D == 1 ? g.ks : g.js) - 2;
+  const int nt  = (D == 1 ? g.ke - g.ks : g.je - g.js) + 5;
+  const long colid = (long)blockIdx.x*64 + lane;
+  const bool colok = colid < (long)ni*nt;
+  const int i = g.is - 2 + (int)(colid % ni);
+  const int tt = tlo + (int)(colid / ni);
+  const int lo = (D == 1 ? g.js : g.ks), hi = (D == 1 ? g.je : g.ke);
+  const int c0 = lo - 2 + blockIdx.y*(BT - 1);
+  const int c = c0 + t;
+  const long s = stride<D>(g);
+  const long base = (D == 1) ? ((long)tt*g.sK + i) : ((long)tt*g.sJ + i);
+  const Real dtodx = dt/g.dx[D];
+  constexpr int P = (BT + 2)*64;                       // LDS pitch per component
+  Real u[6], w[6];
+  const bool have = colok && (c <= hi + 3);
+  if (have) { load_sweep<D, NS>(src, g.nc, base + (long)c*s, u); cons_to_prim<NS>(u, w, g.Gamma_1); }
+  else {
+#pragma unroll
+    for (int n = 0; n < 6; n++) w[n] = 1.0;
+  }
+#pragma unroll
+  for (int n = 0; n < 5 + NS; n++) sm[n*P + (t + 1)*64 + lane] = w[n];
+  if (t == 0 || t == BT - 1) {                         // halo cells c0-1 and c0+BT
+    const int ch = (t == 0) ? c0 - 1 : c + 1;
+    Real uh[6], wh[6];
+    if (colok && ch <= hi + 3) { load_sweep<D, NS>(src, g.nc, base + (long)ch*s, uh); cons_to_prim<NS>(uh, wh, g.Gamma_1); }
+    else {
+#pragma unroll
+      for (int n = 0; n < 6; n++) wh[n] = 1.0;
+    }
+    const int row = (t == 0) ? 0 : BT + 1;
+#pragma unroll
+    for (int n = 0; n < 5 + NS; n++) sm[n*P + row*64 + lane] = wh[n];
+  }
+  __syncthreads();
+  Real wm[6], wp[6], wl_next[6], wr[6];
+#pragma unroll
+  for (int n = 0; n < 5 + NS; n++) { wm[n] = sm[n*P + t*64 + lane]; wp[n] = sm[n*P + (t + 2)*64 + lane]; }
+  if (!NS) { wm[5] = 0.0; wp[5] = 0.0; }
+  const bool recon = colok && (c <= hi + 2);
+  if (recon) plm_cell<NS, MODE != MODE_VL>(wm, w, wp, dtodx, g.Gamma, wl_next, wr);
+  else {
+#pragma unroll
+    for (int n = 0; n < 6; n++) { wl_next[n] = 1.0; wr[n] = 1.0; }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int n = 0; n < 5 + NS; n++) sm[n*P + t*64 + lane] = wl_next[n];
+  __syncthreads();
+  if (t >= 1 && recon) {
+    Real wl[6];
+#pragma unroll
+    for (int n = 0; n < 5 + NS; n++) wl[n] = sm[n*P + (t - 1)*64 + lane];
+    if (!NS) wl[5] = 0.0;
+    face_work<NS, D, GRAV, MODE>(g, base + (long)c*s, i, D == 1 ? c : tt, D == 1 ? tt : c, dt, wl, wr);
+  }
+}
+
+// ---- step 1: x1 sweep, neighbours through LDS ------------------------------------------
+// A block of B threads reconstructs B consecutive cells of one (j,k) row and solves the B-1
+// interfaces between them; blocks overlap by one cell.
+template <int NS, bool GRAV, int MODE>
+__global__ void __launch_bounds__(256)
+k_sweep_x1(DevGrid g, const Real *src, Real dt)
+{
+  extern __shared__ Real sm[];
+  const int B = blockDim.x, t = threadIdx.x;
+  const int j = g.js - 2 + blockIdx.y, k = g.ks - 2 + blockIdx.z;
+  const int c0 = g.is - 2 + blockIdx.x*(B - 1);
+  const int c = c0 + t;
+  const long row = (long)k*g.sK + (long)j*g.sJ;
+  const Real dtodx = dt/g.dx[0];
+  const int P = B + 2;                                 // LDS pitch per component
+  Real u[6], w[6];
+  const bool have = (c <= g.ie + 3);                   // cells up to ie+3 feed the stencil
+  if (have) { load_sweep<0, NS>(src, g.nc, row + c, u); cons_to_prim<NS>(u, w, g.Gamma_1); }
+  else {
+#pragma unroll
+    for (int n = 0; n < 6; n++) w[n] = 1.0;
+  }
+#pragma unroll
+  for (int n = 0; n < 5 + NS; n++) sm[n*P + t + 1] = w[n];
+  if (t == 0) {                                        // lower halo cell c0-1 (>= is-3)
+    Real uh[6], wh[6];
+    load_sweep<0, NS>(src, g.nc, row + c0 - 1, uh); cons_to_prim<NS>(uh, wh, g.Gamma_1);
+#pragma unroll
+    for (int n = 0; n < 5 + NS; n++) sm[n*P] = wh[n];
+  }
+  if (t == B - 1) {                                    // upper halo cell c0+B
+    Real uh[6], wh[6];
+    if (c + 1 <= g.ie + 3) { load_sweep<0, NS>(src, g.nc, row + c + 1, uh); cons_to_prim<NS>(uh, wh, g.Gamma_1); }
+    else {
+#pragma unroll
+      for (int n = 0; n < 6; n++) wh[n] = 1.0;
+    }
+#pragma unroll
+    for (int n = 0; n < 5 + NS; n++) sm[n*P + B + 1] = wh[n];
+  }
+  __syncthreads();
+  Real wm[6], wp[6], wl_next[6], wr[6];
+#pragma unroll
+  for (int n = 0; n < 5 + NS; n++) { wm[n] = sm[n*P + t]; wp[n] = sm[n*P + t + 2]; }
+  if (!NS) { wm[5] = 0.0; wp[5] = 0.0; }
+  const bool recon = (c <= g.ie + 2);                  // cells l..u
+  if (recon) plm_cell<NS, MODE != MODE_VL>(wm, w, wp, dtodx, g.Gamma, wl_next, wr);
+  else {
+#pragma unroll
+    for (int n = 0; n < 6; n++) { wl_next[n] = 1.0; wr[n] = 1.0; }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int n = 0; n < 5 + NS; n++) sm[n*P + t] = wl_next[n];
+  __syncthreads();
+  if (t >= 1 && recon) {                               // interface c, between cells c-1 and c
+    Real wl[6];
+#pragma unroll
+    for (int n = 0; n < 5 + NS; n++) wl[n] = sm[n*P + t - 1];
+    if (!NS) wl[5] = 0.0;
+    face_work<NS, 0, GRAV, MODE>(g, row + c, c, j, k, dt, wl, wr);
+  }
 }
 
 // ---- steps 9b-d: second-pass fluxes with the H-correction -----------------------------------
@@ -570,7 +635,7 @@ static Order zone_order()
 }
 static inline unsigned nblk8(long n, int b) { unsigned x = nblk(n, b); return ((x + 7u)/8u)*8u; }   // for xcd_block()
 
-template <int NS, bool GRAV, bool VL>
+template <int NS, bool GRAV, int MODE>
 static void sweep_impl(const DevGrid &g, const Real *src, int dir, Real dt, hipStream_t st)
 {
   if (dir == 0) {
@@ -581,26 +646,41 @@ static void sweep_impl(const DevGrid &g, const Real *src, int dir, Real dt, hipS
     nb = (nfaces + (B - 1) - 1)/(B - 1);
     dim3 grid(nb, g.je - g.js + 5, g.ke - g.ks + 5);
     size_t lds = (size_t)(5 + NS)*(B + 2)*sizeof(Real);
-    hipLaunchKernelGGL((k_sweep_x1<NS, GRAV, VL>), grid, dim3(B), lds, st, g, src, dt);
+    hipLaunchKernelGGL((k_sweep_x1<NS, GRAV, MODE>), grid, dim3(B), lds, st, g, src, dt);
+  } else if (MODE == MODE_CORR) {
+    constexpr int BT = 8;
+    const long ni = g.ie - g.is + 5;
+    const long nt = (dir == 1 ? g.ke - g.ks : g.je - g.js) + 5;
+    const int nfaces = (dir == 1 ? g.je - g.js : g.ke - g.ks) + 1 + 3;
+    dim3 grid(nblk(ni*nt, 64), (nfaces + BT - 2)/(BT - 1)), blk(64, BT);
+    const size_t lds = (size_t)(5 + NS)*(BT + 2)*64*sizeof(Real);
+    if (dir == 1) hipLaunchKernelGGL((k_sweep_tile<NS, 1, GRAV, MODE, BT>), grid, blk, lds, st, g, src, dt);
+    else          hipLaunchKernelGGL((k_sweep_tile<NS, 2, GRAV, MODE, BT>), grid, blk, lds, st, g, src, dt);
   } else {
     const int chunk = 32;
     const long ni = g.ie - g.is + 5;
     const long nt = (dir == 1 ? g.ke - g.ks : g.je - g.js) + 5;
     const int nfaces = (dir == 1 ? g.je - g.js : g.ke - g.ks) + 1 + 3;
     dim3 grid(nblk(ni*nt, 64), (nfaces + chunk - 1)/chunk);
-    if (dir == 1) hipLaunchKernelGGL((k_sweep_march<NS, 1, GRAV, VL>), grid, dim3(64), 0, st, g, src, dt, chunk);
-    else          hipLaunchKernelGGL((k_sweep_march<NS, 2, GRAV, VL>), grid, dim3(64), 0, st, g, src, dt, chunk);
+    if (dir == 1) hipLaunchKernelGGL((k_sweep_march<NS, 1, GRAV, MODE>), grid, dim3(64), 0, st, g, src, dt, chunk);
+    else          hipLaunchKernelGGL((k_sweep_march<NS, 2, GRAV, MODE>), grid, dim3(64), 0, st, g, src, dt, chunk);
   }
 }
 void launch_sweep(const DevGrid &g, int nscal, int dir, Real dt, bool grav, hipStream_t st)
 {
-  if (nscal) { if (grav) sweep_impl<1, true, false>(g, g.U, dir, dt, st); else sweep_impl<1, false, false>(g, g.U, dir, dt, st); }
-  else       { if (grav) sweep_impl<0, true, false>(g, g.U, dir, dt, st); else sweep_impl<0, false, false>(g, g.U, dir, dt, st); }
+  if (nscal) { if (grav) sweep_impl<1, true, MODE_FLUX1>(g, g.U, dir, dt, st); else sweep_impl<1, false, MODE_FLUX1>(g, g.U, dir, dt, st); }
+  else       { if (grav) sweep_impl<0, true, MODE_FLUX1>(g, g.U, dir, dt, st); else sweep_impl<0, false, MODE_FLUX1>(g, g.U, dir, dt, st); }
+}
+// CTU steps 5-7, 8a, 9a for the faces of one direction (after all three first-pass sweeps)
+void launch_correct(const DevGrid &g, int nscal, int dir, Real dt, bool grav, hipStream_t st)
+{
+  if (nscal) { if (grav) sweep_impl<1, true, MODE_CORR>(g, g.U, dir, dt, st); else sweep_impl<1, false, MODE_CORR>(g, g.U, dir, dt, st); }
+  else       { if (grav) sweep_impl<0, true, MODE_CORR>(g, g.U, dir, dt, st); else sweep_impl<0, false, MODE_CORR>(g, g.U, dir, dt, st); }
 }
 // VL second-order fluxes: PLM without tracing on U^{n+1/2} (kept in LR[0][L]), etah = 0
 void launch_vl_flux2(const DevGrid &g, int nscal, int dir, Real dt, hipStream_t st)
 {
-  if (nscal) sweep_impl<1, false, true>(g, g.LR, dir, dt, st); else sweep_impl<0, false, true>(g, g.LR, dir, dt, st);
+  if (nscal) sweep_impl<1, false, MODE_VL>(g, g.LR, dir, dt, st); else sweep_impl<0, false, MODE_VL>(g, g.LR, dir, dt, st);
 }
 template <int NS>
 static void vl_flux1_impl(const DevGrid &g, int dir, hipStream_t st)
@@ -621,16 +701,6 @@ void launch_vl_uhalf(const DevGrid &g, int nscal, Real dt, bool grav, hipStream_
                else      hipLaunchKernelGGL((k_vl_uhalf<1, false>), grid, blk, 0, st, g, dt); }
   else       { if (grav) hipLaunchKernelGGL((k_vl_uhalf<0, true>), grid, blk, 0, st, g, dt);
                else      hipLaunchKernelGGL((k_vl_uhalf<0, false>), grid, blk, 0, st, g, dt); }
-}
-
-void launch_correct(const DevGrid &g, int nscal, Real dt, bool grav, hipStream_t st)
-{
-  const long n = (long)(g.ie - g.is + 4)*(g.je - g.js + 4)*(g.ke - g.ks + 4);
-  dim3 grid(nblk8(n, 256)), blk(256);
-  if (nscal) { if (grav) hipLaunchKernelGGL((k_correct<1, true>), grid, blk, 0, st, g, dt, zone_order());
-               else      hipLaunchKernelGGL((k_correct<1, false>), grid, blk, 0, st, g, dt, zone_order()); }
-  else       { if (grav) hipLaunchKernelGGL((k_correct<0, true>), grid, blk, 0, st, g, dt, zone_order());
-               else      hipLaunchKernelGGL((k_correct<0, false>), grid, blk, 0, st, g, dt, zone_order()); }
 }
 
 template <int NS>

@@ -31,8 +31,10 @@ HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/s mea
 # Compulsory bytes per cell of each kernel = distinct doubles it must read + write per zone
 # (NVAR=6): the figures are derived in DESIGN.md section 4.
 KERNEL_BYTES = {
-    "sweep_x1": 8 * (6 + 18), "sweep_x2": 8 * (6 + 18), "sweep_x3": 8 * (6 + 18),
-    "correct": 8 * (36 + 18 + 36 + 3), "flux2_x1": 8 * (12 + 3 + 6), "flux2_x2": 8 * (12 + 3 + 6),
+    "sweep_x1": 8 * (6 + 6), "sweep_x2": 8 * (6 + 6), "sweep_x3": 8 * (6 + 6),
+    "correct_x1": 8 * (6 + 12 + 12 + 1), "correct_x2": 8 * (6 + 12 + 12 + 1), "correct_x3": 8 * (6 + 12 + 12 + 1),
+    "vl_flux1": 8 * (6 + 18), "vl_uhalf": 8 * (6 + 18 + 6), "vl_flux2_x1": 8 * 12, "vl_flux2_x2": 8 * 12,
+    "vl_flux2_x3": 8 * 12, "flux2_x1": 8 * (12 + 3 + 6), "flux2_x2": 8 * (12 + 3 + 6),
     "flux2_x3": 8 * (12 + 3 + 6), "update": 8 * (6 + 18 + 6),
     "ray_sweep": 8 * (1 + 2), "ion_rates": 8 * (5 + 1), "ion_update": 8 * (5 + 1 + 3 + 0.5 + 2),
     "ion_begin": 8 * (6 + 6), "bvals_mhd": 0, "new_dt": 8 * 5, "pinned_cells": 0,
