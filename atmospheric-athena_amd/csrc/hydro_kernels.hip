@@ -217,7 +217,7 @@ k_sweep_march(DevGrid g, const Real *src, Real dt, int chunk)
 // overlap by one cell.  One cell per thread keeps the correct pass at ~130 VGPRs (3 waves/SIMD)
 // where the marching form needs 255 (1 wave/SIMD, latency-bound: 32 ms instead of 9 at 512^3).
 template <int NS, int D, bool GRAV, int MODE, int BT>
-__global__ void __launch_bounds__(64*BT)
+__global__ void __launch_bounds__(64*BT, 4)
 k_sweep_tile(DevGrid g, const Real *src, Real dt)
 {
   static_assert(D == 1 || D == 2, "tile kernel is for the strided directions");
@@ -286,7 +286,7 @@ k_sweep_tile(DevGrid g, const Real *src, Real dt)
 // A block of B threads reconstructs B consecutive cells of one (j,k) row and solves the B-1
 // interfaces between them; blocks overlap by one cell.
 template <int NS, bool GRAV, int MODE>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, 4)
 k_sweep_x1(DevGrid g, const Real *src, Real dt)
 {
   extern __shared__ Real sm[];
@@ -648,7 +648,7 @@ static void sweep_impl(const DevGrid &g, const Real *src, int dir, Real dt, hipS
     size_t lds = (size_t)(5 + NS)*(B + 2)*sizeof(Real);
     hipLaunchKernelGGL((k_sweep_x1<NS, GRAV, MODE>), grid, dim3(B), lds, st, g, src, dt);
   } else if (MODE == MODE_CORR) {
-    constexpr int BT = 8;
+    constexpr int BT = 8;     // 8 beats 16 (12.0 ms) despite the 10-rows-for-7-faces halo: more blocks in flight
     const long ni = g.ie - g.is + 5;
     const long nt = (dir == 1 ? g.ke - g.ks : g.je - g.js) + 5;
     const int nfaces = (dir == 1 ? g.je - g.js : g.ke - g.ks) + 1 + 3;
