@@ -165,7 +165,7 @@ def main():
             dom = max(prof, key=lambda k: prof[k][0])
             ms, n = prof[dom]
             ncell = nx ** 3
-            bpl = KERNEL_BYTES.get(dom, 0) * ncell
+            bpl = KERNEL_BYTES.get(dom, 0) * ncell * ((5 + run.nscal) / 6.0 if not dom.startswith("ion") and dom != "ray_sweep" else 1.0)
             ach = bpl / (ms / n * 1e-3) / 1e9 if n else 0.0
             out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": ach / HBM_PEAK_GBS, "traffic": None, "bytes_per_launch": bpl,

@@ -199,6 +199,23 @@ def test_vl_ion_problems_vs_oracle(aa, lib, problem, nx, nsteps):
     g.close()
 
 
+@pytest.mark.parametrize("problem,nx,integrator", [("blast", (4, 4, 4), "ctu"), ("blast", (5, 6, 7), "ctu"),
+                                                   ("blast", (7, 4, 5), "vl"), ("ifront", (4, 5, 6), "ctu"),
+                                                   ("blast", (65, 4, 4), "ctu"), ("blast", (4, 4, 67), "ctu"),
+                                                   ("ifront", (70, 4, 66), "ctu")])
+def test_tiny_and_awkward_grids(aa, lib, problem, nx, integrator):
+    """Grids as thin as nghost, sizes straddling the 64-lane / 256-thread / 32-cell tile edges."""
+    strict = problem == "blast"
+    o, g, nv, trace = run_pair(aa, lib, problem, nx, 2, strict, integrator)
+    U = g.download()[4:-4, 4:-4, 4:-4, :nv]
+    if strict:
+        assert np.array_equal(U, o.active[..., :nv])
+    else:
+        assert [t[0] for t in trace] == [t[1] for t in trace]
+        assert max(relerr(U, o.active[..., :nv])) < 1e-9
+    g.close()
+
+
 def test_round_trip_and_bc(aa, lib):
     """upload -> download is the identity; ghost zones after bvals_mhd equal the oracle's for
     reflect/outflow (ifront deck) and periodic (blast deck)."""
