@@ -167,8 +167,17 @@ def main():
             ncell = nx ** 3
             bpl = KERNEL_BYTES.get(dom, 0) * ncell * ((5 + run.nscal) / 6.0 if not dom.startswith("ion") and dom != "ray_sweep" else 1.0)
             ach = bpl / (ms / n * 1e-3) / 1e9 if n else 0.0
+            # measured HBM bytes per launch of that kernel: from the committed rocprofv3 PMC passes of
+            # this same command (profiles/r01_traffic.json); only valid for the workload it was taken on
+            traffic = None
+            try:
+                tj = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
+                if tj.get("workload") == f"{a.problem} {nx}x{nx}x{nx}" and a.integrator == "ctu":
+                    traffic = tj["kernels"].get(dom)
+            except Exception:
+                pass
             out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                               "frac": ach / HBM_PEAK_GBS, "traffic": None, "bytes_per_launch": bpl,
+                               "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "bytes_per_launch": bpl,
                                "avg_launch_ms": ms / n if n else None}
             out["kernel_ms_per_step"] = {k: v[0] / a.steps for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])}
             out["kernel_launches_per_step"] = {k: v[1] / a.steps for k, v in prof.items()}
