@@ -212,7 +212,7 @@ int aa_set_mesh_state(aa_grid *g, double time, double dt, int nstep)
 int aa_set_static_grav_tables(aa_grid *g, const double *pc, const double *p1, const double *p2, const double *p3)
 {
   if (!pc) { g->grav = false; return 0; }
-  const size_t nb = (size_t)g->d.nc*sizeof(Real);
+  const size_t nb = (size_t)g->d.sK*g->d.N3*sizeof(Real);
   const double *src[4] = {pc, p1, p2, p3};
   for (int w = 0; w < 4; w++) HIPCHK(hipMemcpyAsync(g->d.phi + (size_t)w*g->d.nc, src[w], nb, hipMemcpyHostToDevice, g->st));
   HIPCHK(hipStreamSynchronize(g->st));
@@ -327,10 +327,10 @@ int aa_new_dt(aa_grid *g)
 int aa_integrate_3d_ctu(aa_grid *g)
 {
   const DevGrid &d = g->d; const int ns = g->p.nscal; const Real dt = g->dt;
-  { Scope s(g, "sweep_x1"); launch_sweep(d, ns, 0, dt, g->grav, g->st); }
+  // x2 and x3 first, so that the x1 sweep can do its first pass and its correct pass in one go
   { Scope s(g, "sweep_x2"); launch_sweep(d, ns, 1, dt, g->grav, g->st); }
   { Scope s(g, "sweep_x3"); launch_sweep(d, ns, 2, dt, g->grav, g->st); }
-  { Scope s(g, "correct_x1"); launch_correct(d, ns, 0, dt, g->grav, g->st); }
+  { Scope s(g, "sweep_correct_x1"); launch_sweep_correct_x1(d, ns, dt, g->grav, g->st); }
   { Scope s(g, "correct_x2"); launch_correct(d, ns, 1, dt, g->grav, g->st); }
   { Scope s(g, "correct_x3"); launch_correct(d, ns, 2, dt, g->grav, g->st); }
   { Scope s(g, "flux2_x1"); launch_flux2(d, ns, 0, g->st); }

@@ -65,6 +65,7 @@ struct DevScalars {
 // ---- launch wrappers (hydro_kernels.hip) ------------------------------------------
 void launch_sweep(const DevGrid &g, int nscal, int dir, Real dt, bool grav, hipStream_t st);
 void launch_correct(const DevGrid &g, int nscal, int dir, Real dt, bool grav, hipStream_t st);
+void launch_sweep_correct_x1(const DevGrid &g, int nscal, Real dt, bool grav, hipStream_t st);
 void launch_flux2(const DevGrid &g, int nscal, int dir, hipStream_t st);
 void launch_update(const DevGrid &g, int nscal, const Real *dhalf, Real dt, bool grav, hipStream_t st);
 void launch_vl_flux1(const DevGrid &g, int nscal, int dir, hipStream_t st);

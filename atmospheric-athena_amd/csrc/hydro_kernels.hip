@@ -56,7 +56,9 @@ AA_DEV void store_sweep(Real *fam, long nc, long m, const Real in[6])
 //               the uncorrected face states in the first pass and reading them back saves
 //               2 x 12 doubles of HBM traffic per zone and direction.
 //   MODE_VL     integrate_3d_vl.c:751-795: no tracing (done in plm_cell), no kick, flux only
-enum { MODE_FLUX1 = 0, MODE_CORR = 1, MODE_VL = 2 };
+//   MODE_BOTH   FLUX1 and CORR in one pass: used for x1, which runs after the x2/x3 first passes
+//               (their fluxes are all its correction needs), saving one x1 reconstruction sweep
+enum { MODE_FLUX1 = 0, MODE_CORR = 1, MODE_VL = 2, MODE_BOTH = 3 };
 
 template <int NS, int D, bool GRAV>
 AA_DEV void face_correct(const DevGrid &g, long m, int i, int j, int k, Real dt, const Real ul_s[6], const Real ur_s[6])
@@ -117,7 +119,8 @@ AA_DEV void face_correct(const DevGrid &g, long m, int i, int j, int k, Real dt,
   Real cfr = cfast(sr, g.Gamma, g.Gamma_1), cfl = cfast(sl, g.Gamma, g.Gamma_1);
   Real lambdar = sr[1]/sr[0] + cfr, lambdal = sl[1]/sl[0] - cfl;
   Ef(g, D)[m] = 0.5*fabs(lambdar - lambdal);
-  if (GRAV && D == 0 && i <= g.ie + 1) {       // d^{n+1/2}, :2104-2125 (needs first-pass fluxes)
+  if (GRAV && D == 1 && j <= g.je + 1) {       // d^{n+1/2}, :2104-2125 (needs all first-pass fluxes:
+                                               // done in the x2 correct pass, which runs after them)
     g.dhalf[m] = Uf(g, 0)[m]
       - q[0]*(Ff(g, 0, 0)[m + 1]    - Ff(g, 0, 0)[m])
       - q[1]*(Ff(g, 1, 0)[m + g.sJ] - Ff(g, 1, 0)[m])
@@ -142,6 +145,7 @@ AA_DEV void face_work(const DevGrid &g, long m, int i, int j, int k, Real dt, Re
   Real f[6];
   flux_roe<NS>(ul, ur, wl, wr, 0.0, g.Gamma, g.Gamma_1, f);
   store_sweep<D, NS>(Ff(g, D, 0), g.nc, m, f);
+  if (MODE == MODE_BOTH) face_correct<NS, D, GRAV>(g, m, i, j, k, dt, ul, ur);
 }
 
 // Workgroups are dealt round-robin over the 8 XCDs (blockIdx b and b+8 share an XCD and its L2).
@@ -670,6 +674,12 @@ void launch_sweep(const DevGrid &g, int nscal, int dir, Real dt, bool grav, hipS
 {
   if (nscal) { if (grav) sweep_impl<1, true, MODE_FLUX1>(g, g.U, dir, dt, st); else sweep_impl<1, false, MODE_FLUX1>(g, g.U, dir, dt, st); }
   else       { if (grav) sweep_impl<0, true, MODE_FLUX1>(g, g.U, dir, dt, st); else sweep_impl<0, false, MODE_FLUX1>(g, g.U, dir, dt, st); }
+}
+// x1 first pass + x1 correct pass in one sweep (must run after the x2 and x3 first passes)
+void launch_sweep_correct_x1(const DevGrid &g, int nscal, Real dt, bool grav, hipStream_t st)
+{
+  if (nscal) { if (grav) sweep_impl<1, true, MODE_BOTH>(g, g.U, 0, dt, st); else sweep_impl<1, false, MODE_BOTH>(g, g.U, 0, dt, st); }
+  else       { if (grav) sweep_impl<0, true, MODE_BOTH>(g, g.U, 0, dt, st); else sweep_impl<0, false, MODE_BOTH>(g, g.U, 0, dt, st); }
 }
 // CTU steps 5-7, 8a, 9a for the faces of one direction (after all three first-pass sweeps)
 void launch_correct(const DevGrid &g, int nscal, int dir, Real dt, bool grav, hipStream_t st)

@@ -327,7 +327,7 @@ k_ion_update(DevGrid g, IonPar p, Real dt, DevScalars *sc)
     Cell c; c.d = Uq(g,0)[m]; c.ke = ke_f[m]; c.E = Uq(g,4)[m]; c.s = Uq(g,5)[m];
     const Real E0 = c.E, s0 = c.s;
     const Real ph = g.ph_rate[m];
-    {   // the rates ray_rates derived its time-step limits from, re-evaluated (same code path)
+    {   // the rates ion_rates derived its time-step limits from, re-evaluated (same code path)
       const IonQ q0 = ion_q(c, p, g.Gamma_1);
       Real lnT; bool cold;
       const Real nHdot = damp(chem_rate(q0, ph, p, lnT, cold), g.sign[m].y);
