@@ -124,6 +124,29 @@ def whole_runs():
             save(f"blast_{nx[0]}x{nx[1]}x{nx[2]}_n{nlim}", f, l, it, nx, [])
 
 
+def developed_states():
+    """Pairs of reference states (step A, step B > A) of developed flows: the tests load state A
+    (U, time, dt, nstep -- everything a restart carries, restart.c:531-560) and must arrive at B."""
+    sphere = os.path.join(REF, "tst/massloss/athinput.ioniz_sphere_hires")
+    blast = os.path.join(REF, "tst/3D-hydro/athinput.blast")
+    ifront = os.path.join(REF, "tst/ionradiation/athinput.ifront")
+    cases = [("blast", "blast", blast, (24, 24, 24), 30, 34,
+              ["job/num_domains=1", "job/maxout=1", "output1/out_fmt=rst", "output1/dt=1e300"], 0, False),
+             ("ioniz_sphere", "ioniz_sphere", sphere, (32, 32, 32), 12, 15,    # NaN-free at this resolution
+              ["job/num_domains=1", "job/maxout=1", "output1/dt=1e300"], 1, True),
+             ("ifront", "ifront", ifront, (24, 8, 8), 40, 44,
+              ["job/maxout=3", "output3/out_fmt=rst", "output3/dt=1e300", "output1/dt=1e300", "output2/dt=1e300"], 1, True)]
+    for name, cfg, deck, nx, A, B, extra, nscal, ion in cases:
+        _, a, ita = run_reference(cfg, deck, nx, A, extra, name, nscal, ion)
+        _, b, itb = run_reference(cfg, deck, nx, B, extra, name, nscal, ion)
+        d = dict(nx=np.array(nx), UA=a["U"], nstepA=a["nstep"], timeA=a["time"], dtA=a["dt"],
+                 UB=b["U"], nstepB=b["nstep"], timeB=b["time"], dtB=b["dt"], niter=np.array(itb[A:], dtype=np.int64))
+        if b["edgeflux"] is not None:
+            d["edgefluxB"] = b["edgeflux"]
+        np.savez_compressed(os.path.join(HERE, f"dev_{name}_{nx[0]}x{nx[1]}x{nx[2]}_s{A}_s{B}.npz"), **d)
+        print(f"dev_{name}: steps {A}->{B}, t {a['time']:.6g}->{b['time']:.6g}, niter {itb[A:]}")
+
+
 # ------------------------------------------------------------------------------------
 def dp(a):
     return a.ctypes.data_as(C.POINTER(C.c_double))
@@ -203,4 +226,5 @@ if __name__ == "__main__":
     if not os.path.isdir(REF) or not os.path.isdir(REFBIN):
         sys.exit("needs /root/reference and oracle/_ref (make -C oracle ref)")
     whole_runs()
+    developed_states()
     kernel_vectors()
