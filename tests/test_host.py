@@ -94,3 +94,24 @@ def test_host_problem_files_match_oracle(aa, problem, nx):
         assert n > 0 and np.array_equal(V.reshape(o.U.shape), o.U)
         # potential: same function as the oracle's (first step with gravity is bitwise in the gpu tests)
         assert np.isfinite(H.aa_planet_pot(1e9, 2e9, -3e9))
+
+
+def test_restart_round_trip(aa, tmp_path):
+    """restart.py writes what it reads (layout of src/restart.c; byte-identical rewrite of a real
+    reference dump is checked in the build container, see restart.py)."""
+    R = aa.restart
+    rng = np.random.default_rng(3)
+    nx = (6, 5, 4)
+    U = rng.uniform(0.1, 2.0, (nx[2], nx[1], nx[0], 6)); ef = rng.uniform(0, 1, (nx[2] + 1, nx[1] + 1, nx[0] + 1))
+    par = aa.athinput.ParTable.from_file(os.path.join(PKGDIR, "decks", "athinput.ifront"))
+    p = str(tmp_path / "x.rst")
+    R.write_rst(p, R.par_dump(par), 17, 1.25e8, 3.5e6, U, ef)
+    r = R.read_rst(p, nx, 1, True)
+    assert r["nstep"] == 17 and r["time"] == 1.25e8 and r["dt"] == 3.5e6
+    assert np.array_equal(r["U"], U) and np.array_equal(r["edgeflux"], ef)
+    assert r["par"].getd("ionradiation", "sigma_ph") == 6.3e-18
+    R.write_rst(p, R.par_dump(par), 3, 0.5, 0.25, U[..., :5], None)          # NSCALARS=0, no ion radiation
+    r = R.read_rst(p, nx, 0, False)
+    assert np.array_equal(r["U"], U[..., :5]) and r["edgeflux"] is None
+    with pytest.raises(ValueError):
+        R.read_rst(p, nx, 1, True)
