@@ -71,6 +71,7 @@ class GridConfig:
     bc: Tuple[int, int, int, int, int, int]           # 0 where a neighbour Grid fills the ghosts
     lx3: int                                          # neighbour rank below (-1: physical BC)
     rx3: int                                          # neighbour rank above
+    level: int = 0                                    # DomainS.Level (static mesh refinement)
 
 
 def from_par(par: ParTable, problem: Optional[str] = None) -> RunConfig:
@@ -145,3 +146,51 @@ def slab(run: RunConfig, rank: int = 0, nranks: int = 1) -> GridConfig:
                       Nx=(run.rootNx[0], run.rootNx[1], nx3[rank]),
                       disp=(0, 0, disp3), MinX=(run.xmin[0], run.xmin[1], minx3),
                       bc=tuple(bc), lx3=lx3, rx3=rx3)
+
+
+def levels(par: ParTable, run: RunConfig) -> List[GridConfig]:
+    """The nested Domains of a static-mesh-refinement deck, one per level, root first
+    (init_mesh.c:170-295).  Level l has dx = root dx / 2^l; ``disp`` is <domainN> iDisp/jDisp/kDisp
+    in zones of that level; its lower edge is ``root_xmin + Disp*dx_l`` (:281-286); sides that are
+    not on the root boundary get bc = 0 (bvals_mhd.c:193-361, ProlongateLater)."""
+    nd = par.geti_def("job", "num_domains", 1)
+    doms = {}
+    for n in range(1, nd + 1):
+        blk = f"domain{n}"
+        lev = par.geti(blk, "level")
+        if lev in doms:
+            raise ParError(f"[config]: more than one Domain on level {lev} is not supported")
+        doms[lev] = blk
+    if sorted(doms) != list(range(len(doms))):
+        raise ParError("[init_mesh]: levels must be contiguous from 0")
+    out = [slab(run, 0, 1)]
+    for lev in range(1, len(doms)):
+        blk = doms[lev]
+        irefine = 2 ** lev
+        Nx = tuple(par.geti(blk, f"Nx{d}") for d in (1, 2, 3))
+        disp = tuple(par.geti(blk, k) for k in ("iDisp", "jDisp", "kDisp"))
+        for d in range(3):
+            if Nx[d] % irefine:
+                raise ParError(f"[init_mesh]: {blk}/Nx{d + 1} = {Nx[d]} must be divisible by {irefine}")
+            if disp[d] % irefine:
+                raise ParError(f"[init_mesh]: {blk}/Disp{d + 1} = {disp[d]} must be divisible by {irefine}")
+        # init_mesh.c:320-360: a child may touch its parent's edge only where that is the root boundary
+        pNx, pdisp = out[-1].Nx, (out[-1].disp if lev > 1 else (0, 0, 0))
+        for d in range(3):
+            lo, hi = disp[d] // 2, (disp[d] + Nx[d]) // 2
+            if lo < pdisp[d] or hi > pdisp[d] + pNx[d]:
+                raise ParError(f"[init_mesh]: {blk} is not inside the Domain of level {lev - 1}")
+            if (lo == pdisp[d] and disp[d] != 0) or \
+               (hi == pdisp[d] + pNx[d] and (disp[d] + Nx[d]) // irefine != run.rootNx[d]):
+                raise ParError(f"[init_mesh]: child Domain {blk} touches its parent in x{d + 1}")
+        dxl = tuple(run.dx[d] / float(irefine) for d in range(3))
+        MinX = tuple(run.xmin[d] if disp[d] == 0 else run.xmin[d] + float(disp[d]) * dxl[d] for d in range(3))
+        bc = list(run.bc)
+        for d in range(3):
+            if disp[d] != 0:
+                bc[2 * d] = 0
+            if (disp[d] + Nx[d]) // irefine != run.rootNx[d]:
+                bc[2 * d + 1] = 0
+        out.append(GridConfig(run=run, rank=0, nranks=1, Nx=Nx, disp=disp, MinX=MinX, bc=tuple(bc),
+                              lx3=-1, rx3=-1, level=lev))
+    return out

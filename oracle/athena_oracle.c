@@ -60,6 +60,7 @@ struct OrcSim {
   Real *ph_rate, *edot, *nHdot, *e_init, *e_th_init, *x_init;
   int *last_sign, *sign_count;
   int niter_last, nchem_last, ntherm_last;
+  int level;            /* DomainS.Level: 0 unless the sim is a level of an OrcMesh */
 };
 
 #define IDX(s,k,j,i) (((size_t)(k)*(s)->N[1] + (j))*(s)->N[0] + (i))
@@ -728,10 +729,11 @@ void orc_bvals_ionrad(OrcSim *s)
 /* ------------------------------------------------------------------------------------ */
 /* CFL: new_dt.c:32-198 */
 
-double orc_new_dt_local(OrcSim *s)
+/* new_dt.c:72-140 for one Grid; max_v and max_dti are carried from Grid to Grid (:33, never reset) */
+static void cfl_accumulate(OrcSim *s, Real max_v[3], Real *pmax_dti)
 {
   const Real Gamma = s->Gamma, Gamma_1 = s->Gamma_1;
-  Real max_v[3] = {0.0, 0.0, 0.0}, max_dti = 0.0;
+  Real max_dti = *pmax_dti;
   int i, j, k, d;
   for (k = s->ks; k <= s->ke; k++) for (j = s->js; j <= s->je; j++) for (i = s->is; i <= s->ie; i++) {
     const Cons *u = &s->U[IDX(s,k,j,i)];
@@ -743,6 +745,13 @@ double orc_new_dt_local(OrcSim *s)
     for (d = 0; d < 3; d++) if (s->p.Nx[d] > 1) max_v[d] = MAXR(max_v[d], fabs(v[d]) + sqrt(asq));
   }
   for (d = 0; d < 3; d++) if (s->p.Nx[d] > 1) max_dti = MAXR(max_dti, max_v[d]/s->dx[d]);
+  *pmax_dti = max_dti;
+}
+
+double orc_new_dt_local(OrcSim *s)
+{
+  Real max_v[3] = {0.0, 0.0, 0.0}, max_dti = 0.0;
+  cfl_accumulate(s, max_v, &max_dti);
   return s->p.cour_no/max_dti;
 }
 
@@ -825,7 +834,9 @@ static void get_ph_rate_plane(OrcSim *s)
   int i, j, k, ii;
   for (k = s->ks; k <= s->ke; k++) for (j = s->js; j <= s->je; j++) {
     Real *ef = &s->EdgeFlux[((size_t)(k-s->ks)*n1 + (j-s->js))*n0];
-    Real flux = s->flux_i*(5.*(erf((s->time - 1.2e5)/8e4)+1)+0.1);     /* :265 */
+    /* :264-270: the root level carries the time ramp, finer levels start from the flux their
+     * parent left at the shared face (ionrad_prolong_rcv) */
+    Real flux = (s->level == 0) ? s->flux_i*(5.*(erf((s->time - 1.2e5)/8e4)+1)+0.1) : ef[0];
     Real flux_frac = 0.0;
     for (i = st; i <= e; i++) {
       size_t m = IDX(s,k,j,i);
@@ -1060,6 +1071,420 @@ int orc_step(OrcSim *s)
   orc_new_dt(s);
   orc_bvals(s);
   return niter;
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* Static mesh refinement: smr.c, ionradiation/ionrad_smr.c, the SMR branches of main.c,
+ * new_dt.c and ionrad_3d.c.  One Domain (= one Grid) per level, each nested in the level below.
+ * Level l is an ordinary OrcSim with dx = root dx / 2^l; this section only adds what the
+ * reference adds between the levels.  No send/receive buffers: values are taken from the
+ * other level directly, in the reference's summation order.                                */
+
+#define ORC_MAXLEV 8
+struct OrcMesh {
+  int nl;
+  OrcSim *lev[ORC_MAXLEV];
+  int disp[ORC_MAXLEV][3];   /* DomainS.Disp, in zones of its own level (init_mesh.c:252-267)   */
+  /* overlap of level l+1 on level l in level-l indices (init_grid.c: CGrid.ijks/ijke) */
+  int cs[ORC_MAXLEV][3], ce[ORC_MAXLEV][3];
+  int side[ORC_MAXLEV][6];   /* level l+1 has a fine/coarse boundary on this side (myFlx != NULL) */
+  Real *ionflx[ORC_MAXLEV];  /* CGrid.ionFlx[0] of level l: (n3+1) x (n2+1)                     */
+  Cons *box[ORC_MAXLEV];     /* Prolongate: level-l zones around child l+1, taken at "send" time */
+  Cons *rU[ORC_MAXLEV];      /* RestrictCorrect: restricted solution of level l+1 (send_bufRC)   */
+  Cons *rF[ORC_MAXLEV][6];   /*                  restricted boundary fluxes of level l+1          */
+  Real tcoarse;              /* ionrad_3d.c:44 */
+  Real time, dt; int nstep;  /* MeshS */
+};
+
+static Cons *cz(size_t n) { return (Cons*)calloc(n ? n : 1, sizeof(Cons)); }
+
+OrcMesh *orc_mesh_create(int nlevels, const OrcParams *p, const int *disp)
+{
+  OrcMesh *m; int l, d;
+  if (nlevels < 1 || nlevels > ORC_MAXLEV) return NULL;
+  m = (OrcMesh*)calloc(1, sizeof(OrcMesh));
+  m->nl = nlevels;
+  for (l = 0; l < nlevels; l++) {
+    OrcSim *s = orc_create(&p[l]);
+    s->level = l;
+    for (d = 0; d < 3; d++) {
+      s->dx[d] = s->rootdx[d]/(Real)(1 << l);                       /* init_mesh.c:245 */
+      m->disp[l][d] = disp[3*l + d];
+    }
+    m->lev[l] = s;
+  }
+  for (l = 0; l + 1 < nlevels; l++) {
+    const OrcSim *P = m->lev[l], *Cc = m->lev[l+1];
+    const int lo[3] = {P->is, P->js, P->ks};
+    int n[3], irefine = 1 << (l+1);
+    for (d = 0; d < 3; d++) {
+      /* init_grid.c: G3 = child extent/2 clipped to this Grid; the child must be nested */
+      int a = m->disp[l+1][d]/2 - m->disp[l][d], b = (m->disp[l+1][d] + Cc->p.Nx[d])/2 - m->disp[l][d];
+      if ((m->disp[l+1][d] & 1) || (Cc->p.Nx[d] & 1) || a < 0 || b > P->p.Nx[d]) {
+        fprintf(stderr, "[orc_mesh_create]: level %d is not nested in level %d along x%d\n", l+1, l, d+1);
+        return NULL;
+      }
+      m->cs[l][d] = a + lo[d]; m->ce[l][d] = b + lo[d] - 1;
+      n[d] = b - a;
+      m->side[l][2*d]   = (m->disp[l+1][d] != 0);
+      m->side[l][2*d+1] = ((m->disp[l+1][d] + Cc->p.Nx[d])/irefine != Cc->p.rootNx[d]);
+    }
+    /* ionrad_smr.c:97-98 mixes an index local to the parent Grid with the child's root-relative Disp:
+     * only meaningful while the parent is not displaced across the rays */
+    if (p[0].ion && (m->disp[l][1] || m->disp[l][2])) {
+      fprintf(stderr, "[orc_mesh_create]: radiation across a displaced parent (level %d) is undefined in the reference\n", l);
+      return NULL;
+    }
+    m->ionflx[l] = (Real*)calloc((size_t)(n[2]+1)*(n[1]+1), sizeof(Real));
+    m->box[l] = cz((size_t)(n[0]+6)*(n[1]+6)*(n[2]+6));
+    m->rU[l] = cz((size_t)n[0]*n[1]*n[2]);
+    for (d = 0; d < 3; d++) {
+      size_t nf = (size_t)n[(d+1)%3]*n[(d+2)%3];
+      m->rF[l][2*d] = cz(nf); m->rF[l][2*d+1] = cz(nf);
+    }
+  }
+  return m;
+}
+
+void orc_mesh_destroy(OrcMesh *m)
+{
+  int l, d;
+  if (!m) return;
+  for (l = 0; l < m->nl; l++) {
+    orc_destroy(m->lev[l]); free(m->ionflx[l]); free(m->box[l]); free(m->rU[l]);
+    for (d = 0; d < 6; d++) free(m->rF[l][d]);
+  }
+  free(m);
+}
+
+OrcSim *orc_mesh_level(OrcMesh *m, int l) { return (l >= 0 && l < m->nl) ? m->lev[l] : NULL; }
+double orc_mesh_time(const OrcMesh *m) { return m->time; }
+double orc_mesh_dt(const OrcMesh *m) { return m->dt; }
+int    orc_mesh_nstep(const OrcMesh *m) { return m->nstep; }
+
+/* smr.c:1391-1458 (Step 3a): conservative average of the 2x2x2 fine zones under one coarse zone */
+static Cons restrict_zone(const OrcSim *F, int i, int j, int k)
+{
+  const size_t s1 = 1, s2 = F->N[0], s3 = (size_t)F->N[0]*F->N[1];
+  const size_t m0 = IDX(F,k,j,i);
+  Cons r; int n;
+  for (n = 0; n < 6; n++) {
+    const Real *a = ((const Real*)&F->U[m0]) + n;
+#define A(off) a[6*(off)]
+    Real v = A(0) + A(s1);
+    v += A(s2) + A(s2+s1);
+    v += A(s3) + A(s3+s1) + A(s3+s2) + A(s3+s2+s1);
+    v *= 0.125;
+#undef A
+    ((Real*)&r)[n] = v;
+  }
+  return r;
+}
+
+/* smr.c:1464-1640 (Step 3c): average of the 2x2 fine fluxes on one coarse face.  dir = normal
+ * direction; (a,b) = fine indices along the two transverse directions in the reference's loop
+ * order: x1-faces [k][j], x2-faces [k][i], x3-faces [j][i] (fast index second). */
+static Cons restrict_flux(const OrcSim *F, int dir, int nidx, int slow, int fast)
+{
+  const size_t str[3] = {1, (size_t)F->N[0], (size_t)F->N[0]*F->N[1]};
+  const int dslow = (dir == 2) ? 1 : 2, dfast = (dir == 0) ? 1 : 0;
+  const size_t m0 = (size_t)nidx*str[dir] + (size_t)slow*str[dslow] + (size_t)fast*str[dfast];
+  Cons r; int n;
+  for (n = 0; n < 6; n++) {
+    const Real *a = ((const Real*)&F->F[dir][m0]) + n;
+    Real v = a[0] + a[6*str[dfast]];
+    v += a[6*str[dslow]] + a[6*(str[dslow] + str[dfast])];
+    v *= 0.25;
+    ((Real*)&r)[n] = v;
+  }
+  return r;
+}
+
+/* smr.c:1207 RestrictCorrect.  first != 0: the call before the first step (main.c:401), when all
+ * myFlx arrays are still zero and the flux correction vanishes. */
+static void restrict_correct(OrcMesh *m, int first)
+{
+  int l, i, j, k, n, dim;
+  for (l = m->nl - 1; l >= 0; l--) {
+    OrcSim *G = m->lev[l];
+    const size_t str[3] = {1, (size_t)G->N[0], (size_t)G->N[0]*G->N[1]};
+    /* Steps 1-2: this level takes the restricted solution and fluxes of its child */
+    if (l + 1 < m->nl) {
+      const int *cs = m->cs[l], *ce = m->ce[l];
+      const int nn[3] = {ce[0]-cs[0]+1, ce[1]-cs[1]+1, ce[2]-cs[2]+1};
+      const Cons *r = m->rU[l];
+      for (k = cs[2]; k <= ce[2]; k++) for (j = cs[1]; j <= ce[1]; j++) for (i = cs[0]; i <= ce[0]; i++)
+        G->U[IDX(G,k,j,i)] = *r++;                                              /* Step 1b :1256-1269 */
+      if (!first) for (dim = 0; dim < 6; dim++) {                                /* Step 2a :1277-1340 */
+        const int d = dim/2, d1 = (d == 0) ? 1 : 0, d2 = (d == 2) ? 1 : 2;       /* fast, slow */
+        Real q; int a, b, idx[3];
+        if (!m->side[l][dim]) continue;
+        if (dim & 1) { idx[d] = ce[d]+1; q =  (G->dt/G->dx[d]); }
+        else         { idx[d] = cs[d]-1; q = -(G->dt/G->dx[d]); }
+        for (b = 0; b < nn[d2]; b++) for (a = 0; a < nn[d1]; a++) {
+          size_t mc, mf; Real *u; const Real *mine, *fine;
+          idx[d1] = cs[d1] + a; idx[d2] = cs[d2] + b;
+          mc = IDX(G, idx[2], idx[1], idx[0]);
+          /* this level's own flux through the shared face (Step 12e of the integrator, :3072) */
+          idx[d] = (dim & 1) ? ce[d]+1 : cs[d];
+          mf = IDX(G, idx[2], idx[1], idx[0]);
+          idx[d] = (dim & 1) ? ce[d]+1 : cs[d]-1;
+          u = (Real*)&G->U[mc]; mine = (const Real*)&G->F[d][mf];
+          fine = (const Real*)&m->rF[l][dim][(size_t)b*nn[d1] + a];
+          for (n = 0; n < 6; n++) u[n] -= q*(mine[n] - fine[n]);
+        }
+      }
+      (void)str;
+    }
+    /* Step 3: restrict this level for its parent */
+    if (l > 0) {
+      const OrcSim *F = G;
+      Cons *r = m->rU[l-1];
+      for (k = F->ks; k <= F->ke; k += 2) for (j = F->js; j <= F->je; j += 2) for (i = F->is; i <= F->ie; i += 2)
+        *r++ = restrict_zone(F, i, j, k);
+      for (dim = 0; dim < 6; dim++) {
+        const int d = dim/2;
+        Cons *rf = m->rF[l-1][dim];
+        if (!m->side[l-1][dim]) continue;
+        if (d == 0) { const int ii = (dim & 1) ? F->ie+1 : F->is;
+          for (k = F->ks; k <= F->ke; k += 2) for (j = F->js; j <= F->je; j += 2) *rf++ = restrict_flux(F, 0, ii, k, j); }
+        if (d == 1) { const int jj = (dim & 1) ? F->je+1 : F->js;
+          for (k = F->ks; k <= F->ke; k += 2) for (i = F->is; i <= F->ie; i += 2) *rf++ = restrict_flux(F, 1, jj, k, i); }
+        if (d == 2) { const int kk = (dim & 1) ? F->ke+1 : F->ks;
+          for (j = F->js; j <= F->je; j += 2) for (i = F->is; i <= F->ie; i += 2) *rf++ = restrict_flux(F, 2, kk, j, i); }
+      }
+    }
+  }
+}
+
+/* smr.c:85 ionradRestrictCorrect: E and s[0] only, after the radiation step */
+static void ion_restrict_correct(OrcMesh *m)
+{
+  int l, i, j, k;
+  for (l = m->nl - 1; l >= 0; l--) {
+    OrcSim *G = m->lev[l];
+    if (l + 1 < m->nl) {
+      const int *cs = m->cs[l], *ce = m->ce[l];
+      const Cons *r = m->rU[l];
+      for (k = cs[2]; k <= ce[2]; k++) for (j = cs[1]; j <= ce[1]; j++) for (i = cs[0]; i <= ce[0]; i++, r++) {
+        Cons *u = &G->U[IDX(G,k,j,i)];
+        u->E = r->E; u->s = r->s;
+      }
+    }
+    if (l > 0) {
+      Cons *r = m->rU[l-1];
+      for (k = G->ks; k <= G->ke; k += 2) for (j = G->js; j <= G->je; j += 2) for (i = G->is; i <= G->ie; i += 2)
+        *r++ = restrict_zone(G, i, j, k);
+    }
+  }
+}
+
+/* smr.c:3478 */
+static Real mcd_slope(const Real vl, const Real vc, const Real vr)
+{
+  Real dvl = (vc - vl), dvr = (vr - vc), dv, dvm;
+  if (dvl > 0.0 && dvr > 0.0) {
+    dv = 2.0*(dvl < dvr ? dvl : dvr); dvm = 0.5*(dvl + dvr);
+    return (dvm < dv ? dvm : dv);
+  } else if (dvl < 0.0 && dvr < 0.0) {
+    dv = 2.0*(dvl > dvr ? dvl : dvr); dvm = 0.5*(dvl + dvr);
+    return (dvm > dv ? dvm : dv);
+  }
+  return 0.0;
+}
+
+static Real eint(const Cons *u) { return u->E - 0.5*(SQR(u->M[0]) + SQR(u->M[1]) + SQR(u->M[2]))/u->d; }
+
+/* smr.c:3068 ProCon: 2x2x2 prolongation with monotonized slopes; the internal energy, not E, is
+ * interpolated (:3146-3168) */
+static void pro_con(const Cons *im1, const Cons *c, const Cons *ip1, const Cons *jm1, const Cons *jp1,
+                    const Cons *km1, const Cons *kp1, Cons P[2][2][2])
+{
+  int i, j, k, n;
+  static const int fld[5] = {0, 1, 2, 3, 5};     /* d, M1, M2, M3, s[0] as doubles inside Cons */
+  Real dq1, dq2, dq3, Pi;
+  for (n = 0; n < 5; n++) {
+    const int f = fld[n];
+#define V(u) (((const Real*)(u))[f])
+    dq1 = mcd_slope(V(im1), V(c), V(ip1));
+    dq2 = mcd_slope(V(jm1), V(c), V(jp1));
+    dq3 = mcd_slope(V(km1), V(c), V(kp1));
+    for (k = 0; k < 2; k++) for (j = 0; j < 2; j++) for (i = 0; i < 2; i++)
+      ((Real*)&P[k][j][i])[f] = V(c) + (0.5*i - 0.25)*dq1 + (0.5*j - 0.25)*dq2 + (0.5*k - 0.25)*dq3;
+#undef V
+  }
+  Pi = eint(c);
+  dq1 = mcd_slope(eint(im1), Pi, eint(ip1));
+  dq2 = mcd_slope(eint(jm1), Pi, eint(jp1));
+  dq3 = mcd_slope(eint(km1), Pi, eint(kp1));
+  for (k = 0; k < 2; k++) for (j = 0; j < 2; j++) for (i = 0; i < 2; i++) {
+    Cons *q = &P[k][j][i];
+    q->E = Pi + (0.5*i - 0.25)*dq1 + (0.5*j - 0.25)*dq2 + (0.5*k - 0.25)*dq3;
+    q->E += 0.5*(SQR(q->M[0]) + SQR(q->M[1]) + SQR(q->M[2]))/q->d;
+  }
+}
+
+/* smr.c:2359 Prolongate.  Level by level from the root: a level first hands its zones around the
+ * child to the child ("send", Step 1: before its own ghost zones are refreshed in this call),
+ * then fills its own ghost zones from what its parent handed over (Steps 2-3). */
+static void prolongate(OrcMesh *m)
+{
+  int l, i, j, k, dim;
+  for (l = 0; l < m->nl; l++) {
+    OrcSim *G = m->lev[l];
+    if (l + 1 < m->nl) {                                           /* Step 1 :2397-2470 */
+      const int *cs = m->cs[l], *ce = m->ce[l];
+      Cons *b = m->box[l];
+      for (k = cs[2]-3; k <= ce[2]+3; k++) for (j = cs[1]-3; j <= ce[1]+3; j++) for (i = cs[0]-3; i <= ce[0]+3; i++)
+        *b++ = G->U[IDX(G,k,j,i)];
+    }
+    if (l > 0) {                                                   /* Steps 2-3 :2520-2900 */
+      const int *cs = m->cs[l-1], *ce = m->ce[l-1];
+      const int bn0 = ce[0]-cs[0]+7, bn1 = ce[1]-cs[1]+7;
+      const Cons *box = m->box[l-1];
+      const int lo[3] = {G->is, G->js, G->ks}, hi[3] = {G->ie, G->je, G->ke};
+#define BOX(kc,jc,ic) box[((size_t)(kc)*bn1 + (jc))*bn0 + (ic)]
+      for (dim = 0; dim < 6; dim++) {
+        int ps[3], pe[3], d;
+        if (!m->side[l-1][dim]) continue;
+        for (d = 0; d < 3; d++) { ps[d] = lo[d] - NGHOST; pe[d] = hi[d] + NGHOST; }
+        if (dim & 1) ps[dim/2] = hi[dim/2] + 1; else pe[dim/2] = lo[dim/2] - 1;
+        for (k = ps[2]; k <= pe[2]; k += 2) for (j = ps[1]; j <= pe[1]; j += 2) for (i = ps[0]; i <= pe[0]; i += 2) {
+          /* coarse zone under fine zones (i,i+1)x(j,j+1)x(k,k+1), as an index into the box whose
+           * origin is the coarse zone cs-3: fine lo-4 lies in coarse cs-2 */
+          const int ic = (i - (lo[0] - NGHOST))/2 + 1, jc = (j - (lo[1] - NGHOST))/2 + 1, kc = (k - (lo[2] - NGHOST))/2 + 1;
+          Cons P[2][2][2]; int a, b2, c2;
+          pro_con(&BOX(kc,jc,ic-1), &BOX(kc,jc,ic), &BOX(kc,jc,ic+1), &BOX(kc,jc-1,ic), &BOX(kc,jc+1,ic),
+                  &BOX(kc-1,jc,ic), &BOX(kc+1,jc,ic), P);
+          for (c2 = 0; c2 < 2; c2++) for (b2 = 0; b2 < 2; b2++) for (a = 0; a < 2; a++)
+            G->U[IDX(G,k+c2,j+b2,i+a)] = P[c2][b2][a];
+        }
+      }
+#undef BOX
+    }
+  }
+}
+
+/* ionrad_smr.c:345 ionrad_prolong_snd (dim 0: rays along +x1): the flux this level left at the
+ * upstream face of its child, one value per coarse ray plus one extra row and column */
+static void ionrad_prolong_snd(OrcMesh *m, int l)
+{
+  const OrcSim *G; const int *cs, *ce; int j, k, n0, n1, fixed, w;
+  if (l + 1 >= m->nl || !m->side[l][0]) return;
+  G = m->lev[l]; cs = m->cs[l]; ce = m->ce[l];
+  n0 = G->p.Nx[0]+1; n1 = G->p.Nx[1]+1;
+  fixed = cs[0] - NGHOST; w = ce[1] - cs[1] + 2;
+  for (k = cs[2] - NGHOST; k <= ce[2]+1 - NGHOST; k++) for (j = cs[1] - NGHOST; j <= ce[1]+1 - NGHOST; j++)
+    m->ionflx[l][(size_t)(k-(cs[2]-NGHOST))*w + j-(cs[1]-NGHOST)] = G->EdgeFlux[((size_t)k*n1 + j)*n0 + fixed];
+}
+
+/* ionrad_smr.c:34 ionrad_prolong_rcv: piecewise-constant copy onto the 2x2 fine rays */
+static void ionrad_prolong_rcv(OrcMesh *m, int l)
+{
+  OrcSim *G = m->lev[l]; const int *cs, *ce; int j, k, n0, n1, w;
+  const int fixed = 0;      /* (PGrid.ijks[0] - nghost)*2 with the child nested: ijks[0] = is */
+  if (l == 0 || !m->side[l-1][0]) return;
+  cs = m->cs[l-1]; ce = m->ce[l-1];
+  n0 = G->p.Nx[0]+1; n1 = G->p.Nx[1]+1; w = ce[1] - cs[1] + 2;
+#define EF(kk,jj) G->EdgeFlux[((size_t)(kk)*n1 + (jj))*n0 + fixed]
+  for (k = cs[2] - NGHOST; k <= ce[2]+1 - NGHOST; k++) for (j = cs[1] - NGHOST; j <= ce[1]+1 - NGHOST; j++) {
+    const Real v = m->ionflx[l-1][(size_t)(k-(cs[2]-NGHOST))*w + j-(cs[1]-NGHOST)];
+    /* fine index of coarse ray (j,k): coarse active index is relative to the PARENT Grid, Disp of the
+     * child is relative to the root, both in the reference (ionrad_smr.c:97-98) */
+    const int ks = k*2 - m->disp[l][2], js = j*2 - m->disp[l][1];
+    EF(ks,js) = v;
+    if (j < ce[1]+1 - NGHOST) {
+      if (k < ce[2]+1 - NGHOST) { EF(ks+1,js+1) = v; EF(ks,js+1) = v; EF(ks+1,js) = v; }
+      else EF(ks,js+1) = v;
+    } else if (k < ce[2]+1 - NGHOST) EF(ks+1,js) = v;
+  }
+#undef EF
+}
+
+/* ionrad_3d.c:862 ion_radtransfer_3d with STATIC_MESH_REFINEMENT: the root sub-cycles to its own
+ * stopping criteria and publishes the time it covered (tcoarse); finer levels sub-cycle until
+ * they have covered exactly that time (:919-1040) */
+static int ion_radtransfer_level(OrcMesh *m, int l)
+{
+  OrcSim *s = m->lev[l];
+  const int finegrid = (l != 0);
+  Real dt_chem, dt_therm, dt_hydro, dt, dt_done = 0.0;
+  int niter = 0, hydro_done = 0, coarsetime_done = 0, nchem = 0, ntherm = 0;
+  if (finegrid) ionrad_prolong_rcv(m, l); else m->tcoarse = 0;
+  orc_ion_begin(s);
+  while (finegrid || !hydro_done) {
+    orc_ion_rates(s, &dt_chem, &dt_therm);
+    if (dt_chem < dt_therm) nchem++; else ntherm++;
+    dt = MINR(dt_therm, dt_chem);
+    if (!finegrid) {
+      if (dt_done + dt > s->dt) { dt = s->dt - dt_done; hydro_done = 1; }
+    } else {
+      if (dt_done + dt > m->tcoarse) { dt = m->tcoarse - dt_done; coarsetime_done = 1; }
+    }
+    orc_ion_update(s, dt);
+    dt_done += dt;
+    niter++;
+    if (!finegrid) {
+      if (orc_ion_check_range_count(s) > MAXCELLCOUNT) { s->dt = dt_done; break; }
+      if (hydro_done) break;
+      dt_hydro = orc_ion_dt_hydro(s);
+      if (dt_hydro < dt_done) { s->dt = dt_done; break; }
+    } else if (coarsetime_done) { s->dt = dt_done; break; }
+  }
+  if (!finegrid) {
+    if (niter == s->p.maxiter) s->dt = dt_done;
+    m->tcoarse = dt_done;
+  }
+  m->dt = s->dt;                                                   /* :1030 pMesh->dt = pGrid->dt */
+  ionrad_prolong_snd(m, l);
+  s->niter_last = niter; s->nchem_last = nchem; s->ntherm_last = ntherm;
+  return niter;
+}
+
+/* new_dt.c:32 with several levels: one CFL reduction over all Grids, the same dt everywhere */
+static void mesh_new_dt(OrcMesh *m)
+{
+  Real max_v[3] = {0.0, 0.0, 0.0}, max_dti = 0.0, dtc; int l;
+  const OrcParams *p = &m->lev[0]->p;
+  for (l = 0; l < m->nl; l++) cfl_accumulate(m->lev[l], max_v, &max_dti);
+  dtc = p->cour_no/max_dti;
+  if (m->nstep == 0) m->dt = dtc; else m->dt = MINR(2.0*m->dt, dtc);
+  if ((m->time < p->tlim) && ((p->tlim - m->time) < m->dt)) m->dt = p->tlim - m->time;
+  for (l = 0; l < m->nl; l++) m->lev[l]->dt = m->dt;
+}
+
+/* main.c:395-447: after problem() ran on every level */
+void orc_mesh_start(OrcMesh *m)
+{
+  int l;
+  restrict_correct(m, 1);
+  for (l = 0; l < m->nl; l++) { orc_bvals(m->lev[l]); orc_bvals_ionrad(m->lev[l]); }
+  prolongate(m);
+  mesh_new_dt(m);
+}
+
+/* main.c:519-669 with STATIC_MESH_REFINEMENT; niter[l] = radiation sub-cycles of level l */
+void orc_mesh_step(OrcMesh *m, int *niter)
+{
+  int l;
+  OrcSim *root = m->lev[0];
+  if (root->p.ion && root->nradplane > 0) {                        /* :546-562 */
+    for (l = 0; l < m->nl; l++) {
+      int n = ion_radtransfer_level(m, l);
+      if (niter) niter[l] = n;
+      orc_bvals(m->lev[l]);
+    }
+    ion_restrict_correct(m);
+  } else if (niter) for (l = 0; l < m->nl; l++) niter[l] = 0;
+  for (l = 0; l < m->nl; l++) orc_integrate(m->lev[l]);            /* :572-585 */
+  restrict_correct(m, 0);                                          /* :591 */
+  for (l = 0; l < m->nl; l++) orc_userwork(m->lev[l]);             /* :597 */
+  m->nstep++;
+  m->time += m->dt;                                                /* :618-626 */
+  for (l = 0; l < m->nl; l++) { m->lev[l]->time = m->time; m->lev[l]->nstep = m->nstep; }
+  mesh_new_dt(m);                                                  /* :629 */
+  for (l = 0; l < m->nl; l++) orc_bvals(m->lev[l]);                /* :635-644 */
+  prolongate(m);                                                   /* :647 */
 }
 
 /* ------------------------------------------------------------------------------------ */

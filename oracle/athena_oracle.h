@@ -80,6 +80,21 @@ void   orc_ion_update(OrcSim *s, double dt);                       /* :965-971  
 long   orc_ion_check_range_count(OrcSim *s);                       /* :206-264            */
 double orc_ion_dt_hydro(OrcSim *s);                                /* :593-669            */
 
+/* Static mesh refinement (smr.c, ionrad_smr.c, the SMR branches of main.c / new_dt.c / ionrad_3d.c):
+ * nlevels nested levels, one Domain each.  p[l] describes level l as a Grid of its own (Nx, MinX,
+ * bc = 0 on fine/coarse sides; rootNx/xmin/xmax are those of the ROOT); disp[3*l+d] = <domainN>
+ * iDisp/jDisp/kDisp in zones of level l.  Run the problem generator on every orc_mesh_level()
+ * before orc_mesh_start(). */
+typedef struct OrcMesh OrcMesh;
+OrcMesh *orc_mesh_create(int nlevels, const OrcParams *p, const int *disp);
+void     orc_mesh_destroy(OrcMesh *m);
+OrcSim  *orc_mesh_level(OrcMesh *m, int l);
+void     orc_mesh_start(OrcMesh *m);               /* main.c:395-447 */
+void     orc_mesh_step(OrcMesh *m, int *niter);    /* main.c:519-669; niter[nlevels] */
+double   orc_mesh_time(const OrcMesh *m);
+double   orc_mesh_dt(const OrcMesh *m);
+int      orc_mesh_nstep(const OrcMesh *m);
+
 /* function-level kernels, array-in/array-out, NV = 5+nscal doubles per state */
 void orc_cons_to_prim(int n, int nscal, double gamma, const double *U, double *W);
 void orc_cfast(int n, int nscal, double gamma, const double *U, double *c);

@@ -10,7 +10,7 @@ through oracle/_ref/libref_<cfg>.so to produce function-level known-answer vecto
 
 Fixtures are DATA (arrays + the scalar trace of each run); no reference text is stored.
 
-usage: python tests/golden/make_golden.py
+usage: python tests/golden/make_golden.py [whole] [dev] [kernels] [smr]
 """
 import ctypes as C
 import os
@@ -147,6 +147,86 @@ def developed_states():
         print(f"dev_{name}: steps {A}->{B}, t {a['time']:.6g}->{b['time']:.6g}, niter {itb[A:]}")
 
 
+def read_rst_levels(path, nxs, nscal, ion):
+    """Restart dump of a static-mesh-refinement run: one header, then the Domains' blocks one after
+    the other, root first (restart.c:531-770 loops over levels)."""
+    b = open(path, "rb").read()
+    pos = b.index(b"N_STEP\n") + 7; nstep = struct.unpack_from("<i", b, pos)[0]
+    pos = b.index(b"\nTIME\n", pos) + 6; time = struct.unpack_from("<d", b, pos)[0]
+    pos = b.index(b"\nTIME_STEP\n", pos) + 11; dt = struct.unpack_from("<d", b, pos)[0]
+    levels = []
+    for nx in nxs:
+        n = nx[0] * nx[1] * nx[2]
+        U = np.zeros((nx[2], nx[1], nx[0], 6)); ef = None
+        for c, lab in enumerate(LABELS):
+            tag = b"\n" + lab.encode() + b"\n"; pos = b.index(tag, pos) + len(tag)
+            U[..., c] = np.frombuffer(b, "<f8", n, pos).reshape(nx[2], nx[1], nx[0]); pos += 8 * n
+        if ion:
+            tag = b"\nEDGEFLUX\n"; pos = b.index(tag, pos) + len(tag)
+            ne = (nx[0] + 1) * (nx[1] + 1) * (nx[2] + 1)
+            ef = np.frombuffer(b, "<f8", ne, pos).reshape(nx[2] + 1, nx[1] + 1, nx[0] + 1).copy(); pos += 8 * ne
+        if nscal:
+            tag = b"\nSCALAR 0\n"; pos = b.index(tag, pos) + len(tag)
+            U[..., 5] = np.frombuffer(b, "<f8", n, pos).reshape(nx[2], nx[1], nx[0]); pos += 8 * n
+        levels.append((U, ef))
+    return dict(nstep=nstep, time=time, dt=dt, levels=levels)
+
+
+def smr_runs():
+    """Static mesh refinement (reference built with STATIC_MESH_REFINEMENT, serial): nested levels,
+    one Domain each, from the reference's own decks (they carry <domain2..> blocks) plus overrides.
+    The fixture keeps the overrides: the tests apply the same ones to our decks."""
+    sphere = os.path.join(REF, "tst/massloss/athinput.ioniz_sphere_hires")
+    blast = os.path.join(REF, "tst/3D-hydro/athinput.blast")
+
+    def dom(n, nx, disp=None):
+        o = [f"domain{n}/Nx{d + 1}={nx[d]}" for d in range(3)]
+        if disp:
+            o += [f"domain{n}/{k}Disp={disp[d]}" for d, k in enumerate("ijk")]
+        return o
+
+    cases = [
+        # 2 levels, radiation + gravity + Userwork; planet large enough to stay NaN-free
+        ("smr_ioniz_sphere_2lev_s4", "ioniz_sphere_smr", sphere, ["job/maxout=1", "output1/dt=1e300"], 4, 1, True,
+         ["job/num_domains=2"] + dom(1, (32, 32, 32)) + dom(2, (32, 28, 24), (16, 18, 20)) + ["problem/rp=2.1e10"]),
+        # the deck's own planet at this resolution: NaN zones appear in step 2 (order-sensitive MAX chains)
+        ("smr_ioniz_sphere_2lev_nan_s2", "ioniz_sphere_smr", sphere, ["job/maxout=1", "output1/dt=1e300"], 2, 1, True,
+         ["job/num_domains=2"] + dom(1, (32, 32, 32)) + dom(2, (24, 24, 24), (20, 20, 20))),
+        # 3 levels, hydro only, every level displaced, periodic root
+        ("smr_blast_3lev_s6", "blast_smr", blast, ["job/maxout=1", "output1/out_fmt=rst", "output1/dt=1e300"], 6, 0, False,
+         ["job/num_domains=3"] + dom(1, (16, 24, 16)) + dom(2, (12, 16, 20), (8, 20, 6)) + dom(3, (12, 8, 16), (20, 48, 16))),
+        # 3 levels touching the root boundary (outflow / reflecting), level 2 two zones from level 1's edge
+        ("smr_blast_3lev_edge_s8", "blast_smr", blast, ["job/maxout=1", "output1/out_fmt=rst", "output1/dt=1e300"], 8, 0, False,
+         ["job/num_domains=3"] + dom(1, (16, 16, 16)) + dom(2, (20, 16, 20), (0, 16, 6)) + dom(3, (16, 12, 16), (0, 36, 16))
+         + ["domain1/bc_ix1=2", "domain1/bc_ox1=2", "domain1/bc_ix2=2", "domain1/bc_ox2=2", "domain1/bc_ix3=1",
+            "domain1/bc_ox3=1", "domain1/x2min=-0.5", "domain1/x2max=0.5", "problem/radius=0.3"]),
+    ]
+    for name, cfg, deck, refextra, nlim, nscal, ion, over in cases:
+        nlev = int(over[0].split("=")[1])
+        nxs = [tuple(int(next(o for o in over if o.startswith(f"domain{n}/Nx{d}=")).split("=")[1]) for d in (1, 2, 3))
+               for n in range(1, nlev + 1)]
+        tmp = tempfile.mkdtemp(prefix="golden_")
+        rundir = os.path.join(tmp, "run")
+        pr = subprocess.run([os.path.join(REFBIN, "athena_" + cfg), "-i", deck, "-d", rundir, f"time/nlim={nlim}"] + refextra + over,
+                            stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, cwd=tmp)
+        if pr.returncode != 0:
+            raise RuntimeError(pr.stdout[-2000:] + pr.stderr[-2000:])
+        niter = [int(m) for m in re.findall(r"Radiation done in (\d+) iterations", pr.stderr)]
+        rsts = sorted(f for f in os.listdir(rundir) if f.endswith(".rst"))
+        first = read_rst_levels(os.path.join(rundir, rsts[0]), nxs, nscal, ion)
+        last = read_rst_levels(os.path.join(rundir, rsts[-1]), nxs, nscal, ion)
+        shutil.rmtree(tmp)
+        d = dict(overrides=np.array(over), nlevels=nlev, nstep=last["nstep"], time=last["time"], dt=last["dt"],
+                 dt0=first["dt"], niter=np.array(niter, dtype=np.int64))
+        for l, (U, ef) in enumerate(last["levels"]):
+            d[f"U{l}"] = U
+            if ef is not None:
+                d[f"edgeflux{l}"] = ef
+        np.savez_compressed(os.path.join(HERE, name + ".npz"), **d)
+        print(f"{name}: nstep={last['nstep']} time={last['time']:.17g} dt={last['dt']:.17g} niter={niter} "
+              f"nan={[int(np.isnan(U).sum()) for U, _ in last['levels']]}")
+
+
 # ------------------------------------------------------------------------------------
 def dp(a):
     return a.ctypes.data_as(C.POINTER(C.c_double))
@@ -225,6 +305,12 @@ def kernel_vectors():
 if __name__ == "__main__":
     if not os.path.isdir(REF) or not os.path.isdir(REFBIN):
         sys.exit("needs /root/reference and oracle/_ref (make -C oracle ref)")
-    whole_runs()
-    developed_states()
-    kernel_vectors()
+    which = sys.argv[1:] or ["whole", "dev", "kernels", "smr"]
+    if "whole" in which:
+        whole_runs()
+    if "dev" in which:
+        developed_states()
+    if "kernels" in which:
+        kernel_vectors()
+    if "smr" in which:
+        smr_runs()

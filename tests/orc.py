@@ -71,6 +71,14 @@ def lib():
         L.orc_ion_rates.argtypes = [P, dp, dp]
         L.orc_ion_update.argtypes = [P, D]
         L.orc_ion_check_range_count.restype = C.c_long; L.orc_ion_check_range_count.argtypes = [P]
+        L.orc_mesh_create.restype = P; L.orc_mesh_create.argtypes = [C.c_int, C.POINTER(OrcParams), C.POINTER(C.c_int)]
+        L.orc_mesh_destroy.argtypes = [P]
+        L.orc_mesh_level.restype = P; L.orc_mesh_level.argtypes = [P, C.c_int]
+        L.orc_mesh_start.argtypes = [P]; L.orc_mesh_start.restype = None
+        L.orc_mesh_step.argtypes = [P, C.POINTER(C.c_int)]; L.orc_mesh_step.restype = None
+        L.orc_mesh_time.restype = D; L.orc_mesh_time.argtypes = [P]
+        L.orc_mesh_dt.restype = D; L.orc_mesh_dt.argtypes = [P]
+        L.orc_mesh_nstep.restype = C.c_int; L.orc_mesh_nstep.argtypes = [P]
         L.orc_cons_to_prim.argtypes = [C.c_int, C.c_int, D, dp, dp]
         L.orc_cfast.argtypes = [C.c_int, C.c_int, D, dp, dp]
         L.orc_fluxes.argtypes = [C.c_int, C.c_int, D, dp, dp, dp, dp]
@@ -105,11 +113,12 @@ def params_from_grid(g) -> OrcParams:
 class Sim:
     """One oracle Grid.  `U` is a live numpy view [N3][N2][N1][6] (d,M1,M2,M3,E,s0)."""
 
-    def __init__(self, grid):
+    def __init__(self, grid, handle=None):
         self.grid = grid
         self.L = lib()
         self.params = params_from_grid(grid)
-        self.h = self.L.orc_create(C.byref(self.params))
+        self.owned = handle is None        # levels of a Mesh belong to the Mesh
+        self.h = self.L.orc_create(C.byref(self.params)) if handle is None else handle
         n = (C.c_int * 3)()
         self.L.orc_dims(self.h, n)
         self.N = (n[0], n[1], n[2])
@@ -120,7 +129,8 @@ class Sim:
 
     def __del__(self):
         try:
-            self.L.orc_destroy(self.h)
+            if self.owned:
+                self.L.orc_destroy(self.h)
         except Exception:
             pass
 
@@ -173,6 +183,52 @@ def make_sim(problem, overrides=None, rank=0, nranks=1, integrator="ctu"):
     run = aa.config.load(os.path.join(DECKS, "athinput." + problem), overrides, problem)
     run.integrator = integrator
     return Sim(aa.config.slab(run, rank, nranks)).problem()
+
+
+class Mesh:
+    """Nested static-mesh-refinement levels (one Domain per level) on the oracle."""
+
+    def __init__(self, grids):
+        self.L = lib()
+        n = len(grids)
+        pa = (OrcParams * n)(*[params_from_grid(g) for g in grids])
+        da = (C.c_int * (3 * n))(*[g.disp[d] if g.level else 0 for g in grids for d in range(3)])
+        self.h = self.L.orc_mesh_create(n, pa, da)
+        if not self.h:
+            raise ValueError("orc_mesh_create failed (levels not nested?)")
+        self.lev = [Sim(g, handle=self.L.orc_mesh_level(self.h, l)) for l, g in enumerate(grids)]
+
+    def __del__(self):
+        try:
+            self.lev = []
+            self.L.orc_mesh_destroy(self.h)
+        except Exception:
+            pass
+
+    def problem(self):
+        for s in self.lev:
+            s.problem()
+        return self
+
+    def start(self):
+        self.L.orc_mesh_start(self.h); return self
+
+    def step(self):
+        it = (C.c_int * len(self.lev))()
+        self.L.orc_mesh_step(self.h, it)
+        return list(it)
+
+    time = property(lambda s: s.L.orc_mesh_time(s.h))
+    dt = property(lambda s: s.L.orc_mesh_dt(s.h))
+    nstep = property(lambda s: s.L.orc_mesh_nstep(s.h))
+
+
+def make_mesh(problem, deck_path=None, overrides=None, integrator="ctu"):
+    aa = importlib.import_module("atmospheric-athena_amd")
+    par = aa.athinput.ParTable.from_file(deck_path or os.path.join(DECKS, "athinput." + problem)).cmdline(overrides)
+    run = aa.config.from_par(par, problem)
+    run.integrator = integrator
+    return Mesh(aa.config.levels(par, run)).problem()
 
 
 # ---- function-level kernels ---------------------------------------------------------

@@ -82,3 +82,30 @@ def test_developed_state_pairs_bitwise(name):
         assert niter == [int(x) for x in g["niter"]]
     assert s.time == float(g["timeB"]) and s.dt == float(g["dtB"])
     assert _same(s.active[..., :nv], g["UB"][..., :nv])
+
+
+SMR = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLD, "smr_*.npz")))
+
+
+@pytest.mark.parametrize("name", SMR)
+def test_smr_runs_bitwise(name):
+    """Static mesh refinement (smr.c RestrictCorrect / Prolongate, ionrad_smr.c, the SMR branches of
+    main.c, new_dt.c and ionrad_3d.c): nested levels against runs of the reference built with
+    STATIC_MESH_REFINEMENT, bit for bit on every level."""
+    g = np.load(os.path.join(GOLD, name + ".npz"))
+    prob = "ioniz_sphere" if "ioniz_sphere" in name else "blast"
+    m = orc.make_mesh(prob, None, [str(o) for o in g["overrides"]])
+    assert len(m.lev) == int(g["nlevels"])
+    nv = 5 + m.lev[0].grid.run.nscal
+    m.start()
+    assert m.dt == float(g["dt0"])
+    niter = []
+    for _ in range(int(g["nstep"])):
+        niter += m.step()
+    if m.lev[0].grid.run.ion:
+        assert niter == [int(x) for x in g["niter"]], "radiation sub-cycle counts, level by level"
+    assert m.time == float(g["time"]) and m.dt == float(g["dt"]) and m.nstep == int(g["nstep"])
+    for l, s in enumerate(m.lev):
+        assert _same(s.active[..., :nv], g[f"U{l}"][..., :nv]), f"level {l}"
+        if f"edgeflux{l}" in g.files:
+            assert _same(s.edgeflux, g[f"edgeflux{l}"]), f"EdgeFlux level {l}"
