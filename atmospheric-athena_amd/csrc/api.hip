@@ -12,56 +12,18 @@
 #include <string>
 #include <thread>
 #include <vector>
-#include "../../include/athena_amd.h"
-#include "grid.h"
+#include "api_internal.h"
 
 using namespace aa;
 
 static thread_local char g_err[1024] = "";
-static int fail(int code, const char *fmt, ...)
+int aa_fail(int code, const char *fmt, ...)
 {
   va_list ap; va_start(ap, fmt); vsnprintf(g_err, sizeof g_err, fmt, ap); va_end(ap);
   return code;
 }
-#define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) \
-  return fail(-2, "[athena_amd] HIP error %s at %s:%d: %s", #x, __FILE__, __LINE__, hipGetErrorString(e_)); } while (0)
+#define fail aa_fail
 
-#define MAXCELLCOUNT 20   /* ionrad.h:38 */
-
-struct ProfEntry { std::string name; std::vector<hipEvent_t> ev; double total_ms = 0; long long launches = 0; };
-
-struct aa_grid {
-  aa_params p;
-  DevGrid d;
-  IonPar ion;
-  hipStream_t st = nullptr; bool own_stream = false;
-  Real *pool = nullptr; size_t pool_doubles = 0;
-  DevScalars *sc = nullptr;        // device
-  DevScalars *sc_host = nullptr;   // pinned
-  long long *pin_idx = nullptr; Real *pin_val = nullptr; long long npin = 0;
-  bool grav = false;
-  int rad_dir = 0, nradplane = 0; Real flux_i = 0;
-  double time = 0, dt = 0; int nstep = 0;
-  long long bytes = 0;
-  bool prof = false;
-  std::vector<ProfEntry> pe;
-};
-
-// ---- profiling: an event pair around every kernel-chain stage, on the launch stream ----------
-struct Scope {
-  aa_grid *g; int id; hipEvent_t a = nullptr, b = nullptr;
-  Scope(aa_grid *g_, const char *name) : g(g_), id(-1) {
-    if (!g->prof) return;
-    for (size_t i = 0; i < g->pe.size(); i++) if (g->pe[i].name == name) { id = (int)i; break; }
-    if (id < 0) { g->pe.push_back(ProfEntry()); id = (int)g->pe.size() - 1; g->pe[id].name = name; }
-    hipEventCreate(&a); hipEventCreate(&b); hipEventRecord(a, g->st);
-  }
-  ~Scope() {
-    if (id < 0) return;
-    hipEventRecord(b, g->st);
-    g->pe[id].ev.push_back(a); g->pe[id].ev.push_back(b); g->pe[id].launches++;
-  }
-};
 static void prof_drain(aa_grid *g)
 {
   hipStreamSynchronize(g->st);
@@ -100,7 +62,13 @@ int aa_create(const aa_params *p, aa_grid **out)
   d.is = d.js = d.ks = AA_NGHOST;
   d.ie = d.is + d.Nx1 - 1; d.je = d.js + d.Nx2 - 1; d.ke = d.ks + d.Nx3 - 1;
   d.sJ = d.N1; d.sK = (long)d.N1*d.N2; d.nc = d.sK*d.N3;
-  for (int a = 0; a < 3; a++) d.dx[a] = (p->xmax[a] - p->xmin[a])/(Real)(p->rootNx[a]);   // init_mesh.c:225
+  if (p->level < 0 || p->level > 7) { delete g; return fail(-1, "[aa_create]: level %d out of range", p->level); }
+  g->level = p->level;
+  Real rootdx[3];
+  for (int a = 0; a < 3; a++) {
+    rootdx[a] = (p->xmax[a] - p->xmin[a])/(Real)(p->rootNx[a]);   // init_mesh.c:225
+    d.dx[a] = rootdx[a]/(Real)(1 << p->level);                    // :245
+  }
   d.Gamma = p->gamma; d.Gamma_1 = p->gamma - 1.0;
   // one pool: U 6 | LR 36 | F 18 | eta 3 | dhalf 1 | phi 4 | ion 6 + sign(1) | edgeflux
   const size_t nc = (size_t)d.nc;
@@ -127,10 +95,10 @@ int aa_create(const aa_params *p, aa_grid **out)
     ip.tfloor = p->tfloor; ip.tceil = p->tceil; ip.cour_no = p->cour_no;
     // ionrad.c:112-131: smallest face area and the "low" neutral density, from the ROOT dx
     // (the reference's fallback at :129 is dx[1], reproduced as is)
-    Real a1 = d.dx[0]*d.dx[1], a2 = d.dx[0]*d.dx[2], a3 = d.dx[1]*d.dx[2];
+    Real a1 = rootdx[0]*rootdx[1], a2 = rootdx[0]*rootdx[2], a3 = rootdx[1]*rootdx[2];
     if (a1 < a2) ip.min_area = (a1 < a3) ? a1 : a3; else ip.min_area = (a2 < a3) ? a2 : a3;
-    Real maxdx = d.dx[0] > d.dx[1] ? d.dx[0] : d.dx[1];
-    maxdx = maxdx > d.dx[2] ? maxdx : d.dx[1];
+    Real maxdx = rootdx[0] > rootdx[1] ? rootdx[0] : rootdx[1];
+    maxdx = maxdx > rootdx[2] ? maxdx : rootdx[1];
     ip.d_nlo = 1.0e-4 * p->m_H / (p->sigma_ph * maxdx);      // MINOPTDEPTH, ionrad.h:29
     ip.inv_mH = 1.0/p->m_H; ip.inv_kB = 1.0/p->k_B; ip.aC14 = p->alpha_C/(14.0*p->m_H);
     ip.rec_floor = 2.59e-13*pow(p->tfloor/1.0e4, -0.7);      // recomb_rate_coef(tfloor), ionrad_chemistry.c:111
@@ -295,14 +263,13 @@ int aa_bvals_ionrad(aa_grid *g)
   return 0;
 }
 
-static int fetch_scalars(aa_grid *g)
+int aa_fetch_scalars(aa_grid *g)
 {
   HIPCHK(hipMemcpyAsync(g->sc_host, g->sc, sizeof(DevScalars), hipMemcpyDeviceToHost, g->st));
   HIPCHK(hipStreamSynchronize(g->st));
   return 0;
 }
-static inline double bits_to_double(unsigned long long b) { double x; memcpy(&x, &b, 8); return x; }
-static inline unsigned long long double_to_bits(double x) { unsigned long long b; memcpy(&b, &x, 8); return b; }
+#define fetch_scalars aa_fetch_scalars
 
 int aa_new_dt_local(aa_grid *g, double *dt_cfl)
 {
@@ -376,7 +343,8 @@ int aa_ion_rates(aa_grid *g, double *dt_chem, double *dt_therm)
     // host (it is the same for every ray of the root level)
     const Real flux0 = g->flux_i*(5.*(erf((g->time - 1.2e5)/8e4)+1)+0.1);
     Scope s(g, "ray_sweep");
-    launch_ray_sweep(g->d, g->ion, flux0, g->st);
+    // :264-271: a refined level starts every ray from the flux its parent left in EdgeFlux[..][..][0]
+    launch_ray_sweep(g->d, g->ion, flux0, g->level > 0, g->st);
   } else {
     HIPCHK(hipMemsetAsync(g->d.ph_rate, 0, (size_t)g->d.nc*sizeof(Real), g->st));
   }

@@ -86,7 +86,7 @@ void launch_test_lr(int nscal, Real gamma, int n, const Real *W, Real dt, Real d
 
 // ---- launch wrappers (ion_kernels.hip) ---------------------------------------------
 void launch_ion_begin(const DevGrid &g, const IonPar &p, hipStream_t st);
-void launch_ray_sweep(const DevGrid &g, const IonPar &p, Real flux0, hipStream_t st);
+void launch_ray_sweep(const DevGrid &g, const IonPar &p, Real flux0, bool from_edgeflux, hipStream_t st);
 void launch_ion_rates(const DevGrid &g, const IonPar &p, DevScalars *sc, hipStream_t st);
 void launch_ion_update(const DevGrid &g, const IonPar &p, Real dt, DevScalars *sc, hipStream_t st);
 void launch_edgeflux_bc(const DevGrid &g, Real flux_i, hipStream_t st);

@@ -161,11 +161,12 @@ AA_DEV void block_min_to(unsigned long long *addr, Real v, Real *red)
 #define RS_RAYS 64
 #define RS_PASS (RS_RAYS*RS_CH/256)      /* cells per thread per tile */
 __global__ void __launch_bounds__(256)
-k_ray_sweep(DevGrid g, IonPar p, Real flux0)
+k_ray_sweep(DevGrid g, IonPar p, Real flux0, int from_edgeflux)
 {
   __shared__ Real s_etau[RS_RAYS][RS_CH + 1];
   __shared__ Real s_fin[RS_RAYS][RS_CH + 1];
   __shared__ Real s_flux[RS_RAYS];
+  __shared__ Real s_f0[RS_RAYS];                              // flux entering the ray (denominator of :299)
   __shared__ int  s_dead[RS_RAYS];
   __shared__ int  s_nalive;
   const int tid = threadIdx.x;
@@ -175,7 +176,12 @@ k_ray_sweep(DevGrid g, IonPar p, Real flux0)
   const int col = tid % RS_CH, rsub = tid / RS_CH;           // 256/RS_CH ray-rows per pass
   constexpr int RSTEP = 256/RS_CH;
   const long efp = (long)(g.Nx1 + 1), efrow = (long)(g.Nx2 + 1)*efp;
-  if (tid < RS_RAYS) { s_flux[tid] = flux0; s_dead[tid] = (tid < nrays) ? 0 : 1; }
+  if (tid < RS_RAYS) {
+    Real f0 = flux0;
+    if (from_edgeflux && tid < nrays)                          // :271 refined level: the parent's flux
+      f0 = g.edgeflux[(long)(k - g.ks)*efrow + (long)(j0 + tid - g.js)*efp];
+    s_flux[tid] = f0; s_f0[tid] = f0; s_dead[tid] = (tid < nrays) ? 0 : 1;
+  }
   if (tid == 0) s_nalive = nrays;
   __syncthreads();
   for (int c0 = g.is; c0 <= g.ie; c0 += RS_CH) {
@@ -206,7 +212,7 @@ k_ray_sweep(DevGrid g, IonPar p, Real flux0)
         if (dead) { s_fin[r][cc] = 0.0; continue; }
         s_fin[r][cc] = flux;                                  // EdgeFlux[..][i-s] = flux  (:279)
         flux *= s_etau[r][cc];                                // :298
-        const Real flux_frac = flux / (flux0 + 1e-12);        // :299
+        const Real flux_frac = flux / (s_f0[r] + 1e-12);      // :299
         if (flux_frac < MINFLUXFRAC) { dead = 1; flux = 0.0; atomicSub(&s_nalive, 1); }   // :300-306
       }
       s_flux[r] = flux; s_dead[r] = dead;
@@ -391,8 +397,8 @@ static inline unsigned nblk(long n, int b) { return (unsigned)((n + b - 1)/b); }
 
 void launch_ion_begin(const DevGrid &g, const IonPar &p, hipStream_t st)
 { const long n = (long)g.Nx1*g.Nx2*g.Nx3; hipLaunchKernelGGL(k_ion_begin, dim3(nblk(n, 256)), dim3(256), 0, st, g, p); }
-void launch_ray_sweep(const DevGrid &g, const IonPar &p, Real flux0, hipStream_t st)
-{ hipLaunchKernelGGL(k_ray_sweep, dim3((g.Nx2 + RS_RAYS - 1)/RS_RAYS, g.Nx3), dim3(256), 0, st, g, p, flux0); }
+void launch_ray_sweep(const DevGrid &g, const IonPar &p, Real flux0, bool from_edgeflux, hipStream_t st)
+{ hipLaunchKernelGGL(k_ray_sweep, dim3((g.Nx2 + RS_RAYS - 1)/RS_RAYS, g.Nx3), dim3(256), 0, st, g, p, flux0, from_edgeflux ? 1 : 0); }
 void launch_ion_rates(const DevGrid &g, const IonPar &p, DevScalars *sc, hipStream_t st)
 { const long n = (long)g.Nx1*g.Nx2*g.Nx3; unsigned nb = nblk(n, 256); if (nb > 4096) nb = 4096;
   hipLaunchKernelGGL(k_ion_rates, dim3(nb), dim3(256), 0, st, g, p, sc); }

@@ -1,0 +1,454 @@
+// smr.hip -- static mesh refinement: the nested levels of a Mesh resident on one GPU.
+//
+// Every level is an ordinary aa_grid (its own SoA pool, dx = root dx / 2^level).  This unit adds
+// what the reference adds between the levels, as kernels that read one level's arrays and write
+// the other's directly in HBM -- there are no send/receive buffers (smr.c packs them only to
+// feed MPI):
+//   restriction + flux correction   smr.c:1207  RestrictCorrect
+//   restriction of E and s[0]       smr.c:85    ionradRestrictCorrect
+//   prolongation into ghost zones   smr.c:2359  Prolongate, :3068 ProCon, :3478 mcd_slope
+//   radiation hand-off to the child ionrad_smr.c:345/:34  ionrad_prolong_snd / _rcv
+// and the host control flow of the SMR branches of main.c:519-669, new_dt.c:32 and
+// ionrad_3d.c:862.  The fluxes the reference copies into CGrid/PGrid.myFlx in Step 12e of the
+// integrator (integrate_3d_ctu.c:3072) are read straight from each level's flux arrays, which
+// keep the second-pass fluxes until the next integrator call.
+//
+// Summation orders follow the reference term by term, so the strict (-ffp-contract=off) build
+// reproduces the CPU results bit for bit.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+#include "api_internal.h"
+
+using namespace aa;
+
+#define NG AA_NGHOST
+#define AA_MAXLEV 8
+
+namespace {
+
+struct Link {                 // level l+1 seen from level l (init_grid.c: CGrid.ijks/ijke, myFlx != NULL)
+  int cs[3], ce[3];           // overlap on the parent, parent indices incl. ghost offset
+  int n[3];                   // overlap size in parent zones
+  int side[6];                // the child has a fine/coarse boundary on this side
+  int cdisp[3];               // child's Disp (zones of the child's level)
+};
+
+__device__ __forceinline__ Real *fld(const DevGrid &g, Real *base, int v) { return base + (long)v*g.nc; }
+
+// ---- restriction: 2x2x2 fine zones -> one parent zone, summed as smr.c:1391-1458 -------------
+// varmask bit v = restrict variable v (RestrictCorrect: all; ionradRestrictCorrect: E and s0)
+__global__ void __launch_bounds__(256)
+k_restrict(DevGrid f, DevGrid c, Link L, unsigned varmask)
+{
+  const long n = (long)L.n[0]*L.n[1]*L.n[2];
+  const long lin = (long)blockIdx.x*blockDim.x + threadIdx.x;
+  if (lin >= n) return;
+  const int a = (int)(lin % L.n[0]), b = (int)((lin / L.n[0]) % L.n[1]), cc = (int)(lin / ((long)L.n[0]*L.n[1]));
+  const long mc = (long)(L.cs[2] + cc)*c.sK + (long)(L.cs[1] + b)*c.sJ + (L.cs[0] + a);
+  const long mf = (long)(f.ks + 2*cc)*f.sK + (long)(f.js + 2*b)*f.sJ + (f.is + 2*a);
+  for (int v = 0; v < 6; v++) {
+    if (!(varmask >> v & 1u)) continue;
+    const Real *q = fld(f, f.U, v) + mf;
+    Real s = q[0] + q[1];
+    s += q[f.sJ] + q[f.sJ + 1];
+    s += q[f.sK] + q[f.sK + 1] + q[f.sK + f.sJ] + q[f.sK + f.sJ + 1];
+    s *= 0.125;
+    fld(c, c.U, v)[mc] = s;
+  }
+}
+
+// ---- flux correction (smr.c:1277-1340) on the parent zones just outside the child, one side per
+// launch; the child's flux through a parent face is the average of its 2x2 faces (:1464-1640) ----
+__global__ void __launch_bounds__(256)
+k_flux_correct(DevGrid f, DevGrid c, Link L, int dim, int nvar, Real dt)
+{
+  const int d = dim >> 1, d1 = (d == 0) ? 1 : 0, d2 = (d == 2) ? 1 : 2;      // fast, slow transverse
+  const long n = (long)L.n[d1]*L.n[d2];
+  const long lin = (long)blockIdx.x*blockDim.x + threadIdx.x;
+  if (lin >= n) return;
+  const int a = (int)(lin % L.n[d1]), b = (int)(lin / L.n[d1]);
+  const long sc[3] = {1, c.sJ, c.sK}, sf[3] = {1, f.sJ, f.sK};
+  const int flo[3] = {f.is, f.js, f.ks}, fhi[3] = {f.ie, f.je, f.ke};
+  int ic[3]; ic[d1] = L.cs[d1] + a; ic[d2] = L.cs[d2] + b;
+  Real q;
+  long mface_c, mcell, mface_f;
+  if (dim & 1) { ic[d] = L.ce[d] + 1; q =  (dt/c.dx[d]); }
+  else         { ic[d] = L.cs[d] - 1; q = -(dt/c.dx[d]); }
+  mcell = ic[2]*sc[2] + ic[1]*sc[1] + ic[0];
+  ic[d] = (dim & 1) ? L.ce[d] + 1 : L.cs[d];
+  mface_c = ic[2]*sc[2] + ic[1]*sc[1] + ic[0];
+  {
+    int jf[3]; jf[d1] = flo[d1] + 2*a; jf[d2] = flo[d2] + 2*b; jf[d] = (dim & 1) ? fhi[d] + 1 : flo[d];
+    mface_f = jf[2]*sf[2] + jf[1]*sf[1] + jf[0];
+  }
+  for (int v = 0; v < nvar; v++) {
+    const Real mine = fld(c, c.F, d*6 + v)[mface_c];
+    const Real *qf = fld(f, f.F, d*6 + v) + mface_f;
+    Real fine = qf[0] + qf[sf[d1]];
+    fine += qf[sf[d2]] + qf[sf[d2] + sf[d1]];
+    fine *= 0.25;
+    fld(c, c.U, v)[mcell] -= q*(mine - fine);
+  }
+}
+
+// ---- prolongation ----------------------------------------------------------------------------
+// snapshot of the parent zones cs-3 .. ce+3 around the child, taken when the parent "sends"
+// (smr.c:2397-2470: before the parent's own ghost zones are refreshed in the same call)
+__global__ void __launch_bounds__(256)
+k_box_copy(DevGrid c, Link L, Real *box)
+{
+  const int b0 = L.n[0] + 6, b1 = L.n[1] + 6, b2 = L.n[2] + 6;
+  const long nb = (long)b0*b1*b2;
+  const long lin = (long)blockIdx.x*blockDim.x + threadIdx.x;
+  if (lin >= nb) return;
+  const int i = (int)(lin % b0), j = (int)((lin / b0) % b1), k = (int)(lin / ((long)b0*b1));
+  const long m = (long)(L.cs[2] - 3 + k)*c.sK + (long)(L.cs[1] - 3 + j)*c.sJ + (L.cs[0] - 3 + i);
+  for (int v = 0; v < 6; v++) box[(long)v*nb + lin] = fld(c, c.U, v)[m];
+}
+
+__device__ __forceinline__ Real mcd_slope(const Real vl, const Real vc, const Real vr)   // smr.c:3478
+{
+  const Real dvl = (vc - vl), dvr = (vr - vc);
+  if (dvl > 0.0 && dvr > 0.0) {
+    const Real dv = 2.0*(dvl < dvr ? dvl : dvr), dvm = 0.5*(dvl + dvr);
+    return (dvm < dv ? dvm : dv);
+  } else if (dvl < 0.0 && dvr < 0.0) {
+    const Real dv = 2.0*(dvl > dvr ? dvl : dvr), dvm = 0.5*(dvl + dvr);
+    return (dvm > dv ? dvm : dv);
+  }
+  return 0.0;
+}
+
+// one thread = one parent zone under 2x2x2 ghost zones of the child (ProCon, smr.c:3068); one
+// launch per boundary side, in the reference's order of sides (regions overlap at edges and
+// corners with identical values)
+__global__ void __launch_bounds__(128)
+k_prolong(DevGrid f, Link L, const Real *box, int dim, int nvar)
+{
+  const int lo[3] = {f.is, f.js, f.ks}, hi[3] = {f.ie, f.je, f.ke};
+  int ps[3], cnt[3];
+  for (int d = 0; d < 3; d++) { ps[d] = lo[d] - NG; cnt[d] = (hi[d] - lo[d] + 1 + 2*NG)/2; }
+  if (dim & 1) ps[dim >> 1] = hi[dim >> 1] + 1;
+  cnt[dim >> 1] = NG/2;
+  const long n = (long)cnt[0]*cnt[1]*cnt[2];
+  const long lin = (long)blockIdx.x*blockDim.x + threadIdx.x;
+  if (lin >= n) return;
+  const int a = (int)(lin % cnt[0]), b = (int)((lin / cnt[0]) % cnt[1]), cc = (int)(lin / ((long)cnt[0]*cnt[1]));
+  const int i = ps[0] + 2*a, j = ps[1] + 2*b, k = ps[2] + 2*cc;              // lower fine zone of the 2x2x2 block
+  const int b0 = L.n[0] + 6, b1 = L.n[1] + 6;
+  const long nb = (long)b0*b1*(L.n[2] + 6);
+  const long sb1 = b0, sb2 = (long)b0*b1;
+  // parent zone in box coordinates: fine lo-4 lies in parent cs-2 = box index 1
+  const long mb = (long)((k - (lo[2] - NG))/2 + 1)*sb2 + (long)((j - (lo[1] - NG))/2 + 1)*sb1 + ((i - (lo[0] - NG))/2 + 1);
+  Real P[6][8];
+  // d, M1, M2, M3, s0: conserved variable + limited slopes
+  for (int v = 0; v < 6; v++) {
+    if (v == 4 || v >= nvar) continue;
+    const Real *q = box + (long)v*nb + mb;
+    const Real uc = q[0];
+    const Real dq1 = mcd_slope(q[-1], uc, q[1]);
+    const Real dq2 = mcd_slope(q[-sb1], uc, q[sb1]);
+    const Real dq3 = mcd_slope(q[-sb2], uc, q[sb2]);
+    for (int kk = 0; kk < 2; kk++) for (int jj = 0; jj < 2; jj++) for (int ii = 0; ii < 2; ii++)
+      P[v][kk*4 + jj*2 + ii] = uc + (0.5*ii - 0.25)*dq1 + (0.5*jj - 0.25)*dq2 + (0.5*kk - 0.25)*dq3;
+  }
+  {  // the internal energy, not E, is interpolated (:3146-3168)
+    const Real *qd = box + mb, *q1 = box + nb + mb, *q2 = box + 2*nb + mb, *q3 = box + 3*nb + mb, *qe = box + 4*nb + mb;
+#define EINT(o) (qe[o] - 0.5*(q1[o]*q1[o] + q2[o]*q2[o] + q3[o]*q3[o])/qd[o])
+    const Real Pi = EINT(0);
+    const Real dq1 = mcd_slope(EINT(-1), Pi, EINT(1));
+    const Real dq2 = mcd_slope(EINT(-sb1), Pi, EINT(sb1));
+    const Real dq3 = mcd_slope(EINT(-sb2), Pi, EINT(sb2));
+#undef EINT
+    for (int kk = 0; kk < 2; kk++) for (int jj = 0; jj < 2; jj++) for (int ii = 0; ii < 2; ii++) {
+      const int o = kk*4 + jj*2 + ii;
+      Real e = Pi + (0.5*ii - 0.25)*dq1 + (0.5*jj - 0.25)*dq2 + (0.5*kk - 0.25)*dq3;
+      e += 0.5*(P[1][o]*P[1][o] + P[2][o]*P[2][o] + P[3][o]*P[3][o])/P[0][o];
+      P[4][o] = e;
+    }
+  }
+  for (int v = 0; v < nvar; v++) {
+    Real *u = fld(f, f.U, v);
+    for (int kk = 0; kk < 2; kk++) for (int jj = 0; jj < 2; jj++) for (int ii = 0; ii < 2; ii++)
+      u[(long)(k + kk)*f.sK + (long)(j + jj)*f.sJ + (i + ii)] = P[v][kk*4 + jj*2 + ii];
+  }
+}
+
+// ---- radiation hand-off (ionrad_smr.c:345 + :34, rays along +x1): the flux the parent left at
+// the upstream face of the child, copied piecewise-constant onto the child's 2x2 rays.  The
+// reference moves it through CGrid.ionFlx; nothing touches the parent's EdgeFlux in between. ----
+__global__ void __launch_bounds__(256)
+k_ionflux_prolong(DevGrid f, DevGrid c, Link L)
+{
+  const int w = L.n[1] + 1, h = L.n[2] + 1;
+  const int lin = blockIdx.x*blockDim.x + threadIdx.x;
+  if (lin >= w*h) return;
+  const int jj = lin % w, kk = lin / w;
+  const int j = L.cs[1] - NG + jj, k = L.cs[2] - NG + kk;                 // parent active indices
+  const long cfp = (long)(c.Nx1 + 1), cfrow = (long)(c.Nx2 + 1)*cfp;
+  const long ffp = (long)(f.Nx1 + 1), ffrow = (long)(f.Nx2 + 1)*ffp;
+  const Real v = c.edgeflux[(long)k*cfrow + (long)j*cfp + (L.cs[0] - NG)];
+  const int ks = k*2 - L.cdisp[2], js = j*2 - L.cdisp[1];                 // :97-98
+#define EF(a,b) f.edgeflux[(long)(a)*ffrow + (long)(b)*ffp]
+  EF(ks, js) = v;
+  if (jj < w - 1) {
+    if (kk < h - 1) { EF(ks+1, js+1) = v; EF(ks, js+1) = v; EF(ks+1, js) = v; }
+    else EF(ks, js+1) = v;
+  } else if (kk < h - 1) EF(ks+1, js) = v;
+#undef EF
+}
+
+inline unsigned nblk(long n, int b) { return (unsigned)((n + b - 1)/b); }
+
+}  // namespace
+
+struct aa_mesh {
+  int nl = 0;
+  aa_grid *lev[AA_MAXLEV];
+  int disp[AA_MAXLEV][3];
+  Link link[AA_MAXLEV];            // link[l]: level l+1 on level l
+  Real *box[AA_MAXLEV];            // prolongation snapshot of level l around level l+1
+  hipStream_t st = nullptr;
+  double tcoarse = 0;              // ionrad_3d.c:44
+  double time = 0, dt = 0; int nstep = 0;   // MeshS
+  bool started = false;
+};
+
+extern "C" {
+
+// init_grid.c (overlap tables) + SMR_init (smr.c:2931).  Takes over the levels' streams: all
+// levels run on one stream so that inter-level kernels are ordered without events.
+int aa_mesh_create(int nlevels, aa_grid **levels, const int *disp, aa_mesh **out)
+{
+  if (!levels || !disp || !out || nlevels < 1 || nlevels > AA_MAXLEV) return aa_fail(-1, "[aa_mesh_create]: bad arguments");
+  aa_mesh *m = new aa_mesh();
+  m->nl = nlevels;
+  for (int l = 0; l < nlevels; l++) {
+    aa_grid *g = levels[l];
+    if (!g || g->level != l) { delete m; return aa_fail(-1, "[aa_mesh_create]: levels[%d] was not created with level=%d", l, l); }
+    if (g->p.device != levels[0]->p.device) { delete m; return aa_fail(-1, "[aa_mesh_create]: all levels must live on one device"); }
+    m->lev[l] = g; m->box[l] = nullptr;
+    for (int d = 0; d < 3; d++) m->disp[l][d] = disp[3*l + d];
+  }
+  for (int l = 0; l + 1 < nlevels; l++) {
+    const aa_grid *P = m->lev[l], *C = m->lev[l + 1];
+    Link &L = m->link[l];
+    const int lo[3] = {P->d.is, P->d.js, P->d.ks};
+    const int irefine = 1 << (l + 1);
+    for (int d = 0; d < 3; d++) {
+      const int a = m->disp[l + 1][d]/2 - m->disp[l][d], b = (m->disp[l + 1][d] + C->p.Nx[d])/2 - m->disp[l][d];
+      if ((m->disp[l + 1][d] & 1) || (C->p.Nx[d] & 1) || a < 0 || b > P->p.Nx[d]) {
+        delete m; return aa_fail(-1, "[aa_mesh_create]: level %d is not nested in level %d along x%d", l + 1, l, d + 1);
+      }
+      L.cs[d] = a + lo[d]; L.ce[d] = b + lo[d] - 1; L.n[d] = b - a; L.cdisp[d] = m->disp[l + 1][d];
+      L.side[2*d]     = (m->disp[l + 1][d] != 0);
+      L.side[2*d + 1] = ((m->disp[l + 1][d] + C->p.Nx[d])/irefine != C->p.rootNx[d]);
+      // init_mesh.c:320-360: a child may touch its parent's edge only on the root boundary
+      if ((a == 0 && L.side[2*d]) || (b == P->p.Nx[d] && L.side[2*d + 1])) {
+        delete m; return aa_fail(-1, "[init_mesh] child Domain of level %d touches its parent in x%d", l + 1, d + 1);
+      }
+    }
+    // ionrad_smr.c:97-98 mixes a parent-local index with the child's root-relative Disp
+    if (P->p.ion && (m->disp[l][1] || m->disp[l][2])) {
+      delete m; return aa_fail(-1, "[aa_mesh_create]: radiation across a displaced parent (level %d) is undefined in the reference", l);
+    }
+  }
+  hipError_t e = hipSetDevice(levels[0]->p.device);
+  if (e == hipSuccess) e = hipStreamCreate(&m->st);
+  if (e != hipSuccess) { delete m; return aa_fail(-2, "[aa_mesh_create]: %s", hipGetErrorString(e)); }
+  for (int l = 0; l < nlevels; l++) aa_set_stream(m->lev[l], (void*)m->st);
+  for (int l = 0; l + 1 < nlevels; l++) {
+    const Link &L = m->link[l];
+    const size_t nb = (size_t)(L.n[0] + 6)*(L.n[1] + 6)*(L.n[2] + 6)*6;
+    if (hipMalloc(&m->box[l], nb*sizeof(Real)) != hipSuccess) return aa_fail(-2, "[aa_mesh_create]: hipMalloc box");
+  }
+  *out = m;
+  return 0;
+}
+
+void aa_mesh_destroy(aa_mesh *m)      // the levels stay alive and go back to the default stream
+{
+  if (!m) return;
+  hipStreamSynchronize(m->st);
+  for (int l = 0; l < m->nl; l++) { m->lev[l]->st = nullptr; m->lev[l]->own_stream = false; if (m->box[l]) hipFree(m->box[l]); }
+  hipStreamDestroy(m->st);
+  delete m;
+}
+
+int aa_mesh_get_state(const aa_mesh *m, double *time, double *dt, int *nstep)
+{ if (time) *time = m->time; if (dt) *dt = m->dt; if (nstep) *nstep = m->nstep; return 0; }
+
+// smr.c:1207.  Before the first step (main.c:401) the myFlx arrays are zero: no flux correction.
+int aa_mesh_restrict_correct(aa_mesh *m)
+{
+  for (int l = m->nl - 2; l >= 0; l--) {       // child l+1 -> parent l, finest pair first
+    aa_grid *P = m->lev[l], *C = m->lev[l + 1];
+    const Link &L = m->link[l];
+    const int nvar = 5 + P->p.nscal;
+    Scope s(P, "smr_restrict_correct");
+    // flux correction needs the child's (already corrected) fluxes and solution; the reference
+    // restricts the child (Step 3 of the child's pass) before the parent applies Steps 1-2
+    hipLaunchKernelGGL(k_restrict, dim3(nblk((long)L.n[0]*L.n[1]*L.n[2], 256)), dim3(256), 0, m->st,
+                       C->d, P->d, L, (1u << nvar) - 1u);
+    if (m->started) for (int dim = 0; dim < 6; dim++) {
+      if (!L.side[dim]) continue;
+      const int d = dim >> 1, d1 = (d == 0) ? 1 : 0, d2 = (d == 2) ? 1 : 2;
+      hipLaunchKernelGGL(k_flux_correct, dim3(nblk((long)L.n[d1]*L.n[d2], 256)), dim3(256), 0, m->st,
+                         C->d, P->d, L, dim, nvar, (Real)P->dt);
+    }
+  }
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+// smr.c:85: E and s[0] only, after the radiation step
+int aa_mesh_ionrad_restrict_correct(aa_mesh *m)
+{
+  for (int l = m->nl - 2; l >= 0; l--) {
+    aa_grid *P = m->lev[l], *C = m->lev[l + 1];
+    const Link &L = m->link[l];
+    Scope s(P, "smr_ion_restrict");
+    hipLaunchKernelGGL(k_restrict, dim3(nblk((long)L.n[0]*L.n[1]*L.n[2], 256)), dim3(256), 0, m->st,
+                       C->d, P->d, L, (1u << 4) | (1u << 5));
+  }
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+// smr.c:2359
+int aa_mesh_prolongate(aa_mesh *m)
+{
+  for (int l = 0; l < m->nl; l++) {
+    if (l + 1 < m->nl) {                       // Step 1: hand the zones around the child over
+      const Link &L = m->link[l];
+      const long nb = (long)(L.n[0] + 6)*(L.n[1] + 6)*(L.n[2] + 6);
+      hipLaunchKernelGGL(k_box_copy, dim3(nblk(nb, 256)), dim3(256), 0, m->st, m->lev[l]->d, L, m->box[l]);
+    }
+    if (l > 0) {                               // Steps 2-3: own ghost zones from the parent's zones
+      aa_grid *C = m->lev[l];
+      const Link &L = m->link[l - 1];
+      const int nvar = 5 + C->p.nscal;
+      Scope s(C, "smr_prolongate");
+      for (int dim = 0; dim < 6; dim++) {
+        if (!L.side[dim]) continue;
+        long cnt = 1;
+        for (int d = 0; d < 3; d++) cnt *= (d == (dim >> 1)) ? NG/2 : (C->p.Nx[d] + 2*NG)/2;
+        hipLaunchKernelGGL(k_prolong, dim3(nblk(cnt, 128)), dim3(128), 0, m->st, C->d, L, m->box[l - 1], dim, nvar);
+      }
+    }
+  }
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+// new_dt.c:32 over all levels: max_v is carried from Grid to Grid (:33), one dt for the Mesh
+int aa_mesh_new_dt(aa_mesh *m)
+{
+  double cum[3] = {0.0, 0.0, 0.0}, max_dti = 0.0;
+  for (int l = 0; l < m->nl; l++) {
+    aa_grid *g = m->lev[l];
+    { Scope s(g, "new_dt");
+      HIPCHK(hipMemsetAsync(g->sc->max_v, 0, 3*sizeof(unsigned long long), g->st));
+      launch_cfl(g->d, g->sc, g->st); }
+    int rc = aa_fetch_scalars(g); if (rc) return rc;
+    for (int d = 0; d < 3; d++) {
+      const double v = bits_to_double(g->sc_host->max_v[d]);
+      cum[d] = (cum[d] > v) ? cum[d] : v;
+    }
+    for (int d = 0; d < 3; d++) { const double q = cum[d]/g->d.dx[d]; max_dti = (max_dti > q) ? max_dti : q; }
+  }
+  const aa_params &p = m->lev[0]->p;
+  const double dtc = p.cour_no/max_dti;
+  if (m->nstep == 0) m->dt = dtc; else m->dt = (2.0*m->dt < dtc) ? 2.0*m->dt : dtc;
+  if ((m->time < p.tlim) && ((p.tlim - m->time) < m->dt)) m->dt = p.tlim - m->time;
+  for (int l = 0; l < m->nl; l++) m->lev[l]->dt = m->dt;
+  return 0;
+}
+
+// ionrad_3d.c:862 with STATIC_MESH_REFINEMENT: the root sub-cycles to its own stopping criteria and
+// publishes the time it covered; a refined level sub-cycles until it has covered exactly that
+int aa_mesh_ion_radtransfer(aa_mesh *m, int l, int *niter_out)
+{
+  aa_grid *g = m->lev[l];
+  const bool finegrid = (l != 0);
+  double dt_chem, dt_therm, dt_hydro = 0, dt, dt_done = 0.0;
+  long long cellcount;
+  int niter = 0, hydro_done = 0, coarsetime_done = 0, rc;
+  if (finegrid) {
+    const Link &L = m->link[l - 1];
+    if (L.side[0])
+      hipLaunchKernelGGL(k_ionflux_prolong, dim3(nblk((long)(L.n[1] + 1)*(L.n[2] + 1), 256)), dim3(256), 0, m->st,
+                         g->d, m->lev[l - 1]->d, L);
+  } else m->tcoarse = 0;
+  if ((rc = aa_ion_begin(g))) return rc;
+  while (finegrid || !hydro_done) {
+    if ((rc = aa_ion_rates(g, &dt_chem, &dt_therm))) return rc;
+    dt = (dt_therm < dt_chem) ? dt_therm : dt_chem;
+    if (!finegrid) { if (dt_done + dt > g->dt) { dt = g->dt - dt_done; hydro_done = 1; } }
+    else           { if (dt_done + dt > m->tcoarse) { dt = m->tcoarse - dt_done; coarsetime_done = 1; } }
+    if ((rc = aa_ion_update(g, dt, &cellcount, &dt_hydro))) return rc;
+    dt_done += dt;
+    niter++;
+    if (!finegrid) {
+      if (cellcount > MAXCELLCOUNT) { g->dt = dt_done; break; }
+      if (hydro_done) break;
+      if (dt_hydro < dt_done) { g->dt = dt_done; break; }
+    } else if (coarsetime_done) { g->dt = dt_done; break; }
+  }
+  if (!finegrid) {
+    if (niter == g->p.maxiter) g->dt = dt_done;
+    m->tcoarse = dt_done;
+  }
+  m->dt = g->dt;                             // :1030 pMesh->dt = pGrid->dt
+  if (niter_out) *niter_out = niter;
+  return 0;
+}
+
+// main.c:395-447 after problem() has filled every level
+int aa_mesh_start(aa_mesh *m)
+{
+  int rc;
+  m->started = false;
+  if ((rc = aa_mesh_restrict_correct(m))) return rc;
+  for (int l = 0; l < m->nl; l++) {
+    if ((rc = aa_bvals_mhd(m->lev[l]))) return rc;
+    if ((rc = aa_bvals_ionrad(m->lev[l]))) return rc;
+  }
+  if ((rc = aa_mesh_prolongate(m))) return rc;
+  if ((rc = aa_mesh_new_dt(m))) return rc;
+  m->started = true;
+  return 0;
+}
+
+// one pass of main.c:519-669 with STATIC_MESH_REFINEMENT; niter[l] = radiation sub-cycles of level l
+int aa_mesh_step(aa_mesh *m, int *niter)
+{
+  int rc;
+  aa_grid *root = m->lev[0];
+  if (root->p.ion && root->nradplane > 0) {                          // :546-562
+    for (int l = 0; l < m->nl; l++) {
+      int n = 0;
+      m->lev[l]->time = m->time;
+      if ((rc = aa_mesh_ion_radtransfer(m, l, &n))) return rc;
+      if (niter) niter[l] = n;
+      if ((rc = aa_bvals_mhd(m->lev[l]))) return rc;
+    }
+    if ((rc = aa_mesh_ionrad_restrict_correct(m))) return rc;
+  } else if (niter) for (int l = 0; l < m->nl; l++) niter[l] = 0;
+  for (int l = 0; l < m->nl; l++) {                                   // :572-585
+    aa_grid *g = m->lev[l];
+    if ((rc = (g->p.integrator == 1 ? aa_integrate_3d_vl(g) : aa_integrate_3d_ctu(g)))) return rc;
+  }
+  if ((rc = aa_mesh_restrict_correct(m))) return rc;                  // :591
+  for (int l = 0; l < m->nl; l++)                                     // :597 Userwork_in_loop
+    if (m->lev[l]->npin > 0 && (rc = aa_apply_pinned_cells(m->lev[l]))) return rc;
+  m->nstep++; m->time += m->dt;                                       // :618-626
+  for (int l = 0; l < m->nl; l++) { m->lev[l]->time = m->time; m->lev[l]->nstep = m->nstep; }
+  if ((rc = aa_mesh_new_dt(m))) return rc;                            // :629
+  for (int l = 0; l < m->nl; l++) if ((rc = aa_bvals_mhd(m->lev[l]))) return rc;   // :635-644
+  return aa_mesh_prolongate(m);                                       // :647
+}
+
+}  // extern "C"

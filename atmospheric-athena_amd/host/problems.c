@@ -22,7 +22,7 @@
 static void centre(const aa_params *p, int i, int j, int k, double x[3])   /* cc_pos.c:36-43 */
 {
   double dx[3]; int d;
-  for (d = 0; d < 3; d++) dx[d] = (p->xmax[d] - p->xmin[d])/(double)p->rootNx[d];
+  for (d = 0; d < 3; d++) dx[d] = (p->xmax[d] - p->xmin[d])/(double)p->rootNx[d]/(double)(1 << p->level);   /* init_mesh.c:225,245 */
   x[0] = p->MinX[0] + ((double)(i - NG) + 0.5)*dx[0];
   x[1] = p->MinX[1] + ((double)(j - NG) + 0.5)*dx[1];
   x[2] = p->MinX[2] + ((double)(k - NG) + 0.5)*dx[2];

@@ -32,7 +32,7 @@ class aa_params(C.Structure):
         ("max_de_iter", C.c_double), ("max_de_therm_iter", C.c_double), ("max_dx_iter", C.c_double),
         ("max_de_step", C.c_double), ("max_de_therm_step", C.c_double), ("max_dx_step", C.c_double),
         ("tfloor", C.c_double), ("tceil", C.c_double),
-        ("maxiter", C.c_int), ("device", C.c_int), ("integrator", C.c_int),
+        ("maxiter", C.c_int), ("device", C.c_int), ("integrator", C.c_int), ("level", C.c_int),
     ]
 
 
@@ -93,6 +93,11 @@ def load(strict: bool | None = None) -> C.CDLL:
         "aa_new_dt_local": (I, [P, dp]), "aa_ion_begin": (I, [P]), "aa_ion_rates": (I, [P, dp, dp]),
         "aa_ion_update": (I, [P, D, llp, dp]),
         "aa_halo_doubles": (LL, [P]), "aa_pack_x3": (I, [P, I, P]), "aa_unpack_x3": (I, [P, I, P]),
+        "aa_mesh_create": (I, [I, C.POINTER(P), ip, C.POINTER(P)]), "aa_mesh_destroy": (None, [P]),
+        "aa_mesh_get_state": (I, [P, dp, dp, ip]),
+        "aa_mesh_restrict_correct": (I, [P]), "aa_mesh_ionrad_restrict_correct": (I, [P]),
+        "aa_mesh_prolongate": (I, [P]), "aa_mesh_new_dt": (I, [P]), "aa_mesh_ion_radtransfer": (I, [P, I, ip]),
+        "aa_mesh_start": (I, [P]), "aa_mesh_step": (I, [P, ip]),
         "aa_test_fluxes": (I, [I, D, I, dp, dp, dp, dp]),
         "aa_test_lr_states": (I, [I, D, I, dp, D, D, I, I, dp, dp]),
         "aa_profile_enable": (I, [P, I]), "aa_profile_reset": (I, [P]), "aa_profile_count": (I, [P]),
@@ -143,6 +148,7 @@ def params_from_grid(g: GridConfig, device: int = 0) -> aa_params:
     p.maxiter = r.maxiter
     p.device = device
     p.integrator = 1 if r.integrator == "vl" else 0
+    p.level = g.level
     return p
 
 
@@ -312,3 +318,61 @@ def setup_problem(grid: GridConfig, device: int = 0, strict: bool | None = None)
         g.add_radplane_3d(-1, pr["flux"])
     g.host_initial = U
     return g
+
+
+class Mesh:
+    """Nested static-mesh-refinement levels on one GPU (MeshS with one Domain per level).  Method
+    names follow the reference: RestrictCorrect, Prolongate (smr.c), new_dt, and the per-level
+    ion_radtransfer_3d with its coarse -> fine EdgeFlux hand-off (ionrad_smr.c)."""
+
+    def __init__(self, grids, device: int = 0, strict: bool | None = None):
+        self.lev = [setup_problem(g, device, strict) for g in grids]
+        self.L = self.lev[0].L
+        n = len(grids)
+        hs = (C.c_void_p * n)(*[g._h for g in self.lev])
+        disp = (C.c_int * (3 * n))(*[g.disp[d] if g.level else 0 for g in grids for d in range(3)])
+        h = C.c_void_p()
+        self._h = None
+        self._chk(self.L.aa_mesh_create(n, hs, disp, C.byref(h)))
+        self._h = h
+
+    def _chk(self, rc: int):
+        if rc != 0:
+            raise AthenaError(self.L.aa_last_error().decode() or f"athena_amd error {rc}")
+
+    def close(self):
+        if self._h is not None:
+            self.L.aa_mesh_destroy(self._h); self._h = None
+        for g in self.lev:
+            g.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def state(self):
+        t = C.c_double(); dt = C.c_double(); n = C.c_int()
+        self.L.aa_mesh_get_state(self._h, C.byref(t), C.byref(dt), C.byref(n))
+        return t.value, dt.value, n.value
+
+    time = property(lambda s: s.state()[0])
+    dt = property(lambda s: s.state()[1])
+    nstep = property(lambda s: s.state()[2])
+
+    def RestrictCorrect(self): self._chk(self.L.aa_mesh_restrict_correct(self._h))
+    def ionradRestrictCorrect(self): self._chk(self.L.aa_mesh_ionrad_restrict_correct(self._h))
+    def Prolongate(self): self._chk(self.L.aa_mesh_prolongate(self._h))
+    def new_dt(self): self._chk(self.L.aa_mesh_new_dt(self._h))
+
+    def ion_radtransfer_3d(self, level: int) -> int:
+        n = C.c_int(); self._chk(self.L.aa_mesh_ion_radtransfer(self._h, level, C.byref(n))); return n.value
+
+    def start(self):
+        self._chk(self.L.aa_mesh_start(self._h)); return self
+
+    def step(self):
+        it = (C.c_int * len(self.lev))()
+        self._chk(self.L.aa_mesh_step(self._h, it))
+        return list(it)

@@ -41,6 +41,8 @@ typedef struct aa_params {
   int    device;           /* HIP device ordinal                                                */
   int    integrator;       /* 0: CTU + H-correction (configure default + --enable-h-correction);
                               1: van Leer, no H-correction (--with-integrator=vl)              */
+  int    level;            /* DomainS.Level (static mesh refinement): dx = root dx / 2^level
+                              (init_mesh.c:245); 0 for a single-level run                      */
 } aa_params;
 
 typedef struct aa_grid aa_grid;
@@ -98,6 +100,26 @@ int aa_ion_update(aa_grid *g, double dt, long long *cellcount, double *dt_hydro)
 long long aa_halo_doubles(const aa_grid *g);
 int aa_pack_x3(aa_grid *g, int side, double *dev_buf);
 int aa_unpack_x3(aa_grid *g, int side, const double *dev_buf);
+
+/* ---- static mesh refinement (reference built with --enable-smr): nested levels, one Domain per
+ *      level, all resident on one GPU.  levels[l] was created with aa_params.level = l, Nx = the
+ *      Domain's zones, MinX = its lower edge (init_mesh.c:281-286), bc = 0 on fine/coarse sides
+ *      (bvals_mhd.c:193-361 ProlongateLater); disp[3*l+d] = <domainN> iDisp/jDisp/kDisp in zones
+ *      of level l.  Fill every level (problem(), hooks) before aa_mesh_start().  The Mesh takes
+ *      over the levels' streams; destroy it before the levels.                               */
+typedef struct aa_mesh aa_mesh;
+int  aa_mesh_create(int nlevels, aa_grid **levels, const int *disp, aa_mesh **out); /* init_grid.c overlap
+                                                          tables (:150-560) + SMR_init (smr.c:2931)  */
+void aa_mesh_destroy(aa_mesh *m);
+int  aa_mesh_get_state(const aa_mesh *m, double *time, double *dt, int *nstep);     /* MeshS          */
+int  aa_mesh_restrict_correct(aa_mesh *m);        /* smr.c:1207 RestrictCorrect                      */
+int  aa_mesh_ionrad_restrict_correct(aa_mesh *m); /* smr.c:85 ionradRestrictCorrect                  */
+int  aa_mesh_prolongate(aa_mesh *m);              /* smr.c:2359 Prolongate                           */
+int  aa_mesh_new_dt(aa_mesh *m);                  /* new_dt.c:32 over all levels                     */
+int  aa_mesh_ion_radtransfer(aa_mesh *m, int level, int *niter); /* ionrad_3d.c:862 on Domain[level],
+                                                     incl. ionrad_prolong_rcv/_snd (ionrad_smr.c)   */
+int  aa_mesh_start(aa_mesh *m);                   /* main.c:395-447                                  */
+int  aa_mesh_step(aa_mesh *m, int *niter);        /* one pass of main.c:519-669; niter[nlevels]      */
 
 /* ---- function-level kernels on device arrays' host mirrors (parity tests): n states of
  *      nvar = 5+nscal doubles each, same conventions as fluxes()/lr_states()              */

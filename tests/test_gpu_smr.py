@@ -1,0 +1,161 @@
+"""Static mesh refinement on the GPU (csrc/smr.hip through the C-ABI aa_mesh_*) against the golden
+fixtures of the reference's own SMR build and against the CPU oracle.
+
+Hydro-only meshes (blast, 3 levels): the strict build must agree BIT FOR BIT on every level --
+restriction, flux correction and prolongation are pure sums and products.  With radiation the
+device exp/log differ from glibc's in the last bits, so the 2-level sphere is held to a tolerance
+(written at the assert; north_star's bar is 1e-6) with identical sub-cycle counts on both levels.
+"""
+import importlib
+import os
+
+import numpy as np
+import pytest
+
+import orc
+
+pytestmark = pytest.mark.gpu
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+@pytest.fixture(scope="module")
+def lib():
+    return importlib.import_module("atmospheric-athena_amd.lib")
+
+
+@pytest.fixture(scope="module")
+def aa():
+    return importlib.import_module("atmospheric-athena_amd")
+
+
+def make_gpu_mesh(aa, lib, problem, overrides, strict):
+    par = aa.athinput.ParTable.from_file(os.path.join(orc.DECKS, "athinput." + problem)).cmdline(overrides)
+    run = aa.config.from_par(par, problem)
+    return lib.Mesh(aa.config.levels(par, run), 0, strict)
+
+
+def relerr(a, b):
+    out = []
+    for c in range(a.shape[-1]):
+        scale = np.nanmax(np.abs(b[..., c]))
+        out.append(0.0 if scale == 0 else float(np.nanmax(np.abs(a[..., c] - b[..., c])) / scale))
+    return out
+
+
+@pytest.mark.parametrize("name", ["smr_blast_3lev_s6", "smr_blast_3lev_edge_s8"])
+@pytest.mark.parametrize("strict", [True, False])
+def test_blast_three_levels_vs_reference(aa, lib, name, strict):
+    g = np.load(os.path.join(GOLD, name + ".npz"))
+    m = make_gpu_mesh(aa, lib, "blast", [str(o) for o in g["overrides"]], strict)
+    try:
+        m.start()
+        assert m.dt == float(g["dt0"]) if strict else abs(m.dt / float(g["dt0"]) - 1) < 1e-13
+        for _ in range(int(g["nstep"])):
+            m.step()
+        assert m.nstep == int(g["nstep"])
+        for l, lev in enumerate(m.lev):
+            U = lev.download()[4:-4, 4:-4, 4:-4, :5]
+            ref = g[f"U{l}"][..., :5]
+            if strict:
+                assert m.time == float(g["time"]) and m.dt == float(g["dt"])
+                assert np.array_equal(U, ref), f"level {l}: {relerr(U, ref)}"
+            else:
+                # fused multiply-adds only: rounding accumulation over 6-8 steps
+                assert max(relerr(U, ref)) < 1e-11, f"level {l}: {relerr(U, ref)}"
+    finally:
+        m.close()
+
+
+def test_ghost_zones_after_prolongation_bitwise(aa, lib):
+    """Prolongate alone: the ghost zones of the refined levels (incl. edges and corners, written by
+    several sides) must equal the oracle's after start(), bit for bit."""
+    g = np.load(os.path.join(GOLD, "smr_blast_3lev_edge_s8.npz"))
+    ov = [str(o) for o in g["overrides"]]
+    o = orc.make_mesh("blast", None, ov).start()
+    m = make_gpu_mesh(aa, lib, "blast", ov, True)
+    try:
+        m.start()
+        for l, lev in enumerate(m.lev):
+            assert np.array_equal(lev.download()[..., :5], o.lev[l].U[..., :5]), f"level {l}"
+    finally:
+        m.close()
+
+
+@pytest.mark.parametrize("strict", [True, False])
+def test_sphere_two_levels_vs_reference(aa, lib, strict):
+    g = np.load(os.path.join(GOLD, "smr_ioniz_sphere_2lev_s4.npz"))
+    m = make_gpu_mesh(aa, lib, "ioniz_sphere", [str(o) for o in g["overrides"]], strict)
+    try:
+        m.start()
+        assert abs(m.dt / float(g["dt0"]) - 1) < 1e-13
+        niter = []
+        for _ in range(int(g["nstep"])):
+            niter += m.step()
+        assert niter == [int(x) for x in g["niter"]], "radiation sub-cycle counts on both levels"
+        assert abs(m.time / float(g["time"]) - 1) < 1e-9 and abs(m.dt / float(g["dt"]) - 1) < 1e-9
+        for l, lev in enumerate(m.lev):
+            U = lev.download()[4:-4, 4:-4, 4:-4, :]
+            err = relerr(U, g[f"U{l}"])
+            assert max(err) < 1e-8, f"level {l}: {err}"            # north_star: 1e-6
+            ef = lev.download_edgeflux(); ref = g[f"edgeflux{l}"]
+            assert np.nanmax(np.abs(ef - ref)) <= 1e-9 * np.nanmax(np.abs(ref)), f"EdgeFlux level {l}"
+    finally:
+        m.close()
+
+
+def test_mesh_phases_match_oracle(aa, lib):
+    """The individual SMR call sites (ionradRestrictCorrect, RestrictCorrect, Prolongate, new_dt) in
+    the order of main.c, each checked against the oracle, on the 2-level sphere."""
+    g = np.load(os.path.join(GOLD, "smr_ioniz_sphere_2lev_s4.npz"))
+    ov = [str(o) for o in g["overrides"]]
+    o = orc.make_mesh("ioniz_sphere", None, ov).start()
+    m = make_gpu_mesh(aa, lib, "ioniz_sphere", ov, True)
+    try:
+        m.start()
+        for l in range(2):
+            assert np.array_equal(m.lev[l].download(), o.lev[l].U), f"after start, level {l}"
+        n_o = o.step()
+        n_g = [0, 0]
+        for l in range(2):
+            m.lev[l].set_mesh_state(m.time, m.lev[l].dt, m.nstep)
+            n_g[l] = m.ion_radtransfer_3d(l)
+            m.lev[l].bvals_mhd()
+        assert n_g == n_o
+        m.ionradRestrictCorrect()
+        for lev in m.lev:
+            lev.integrate()
+        m.RestrictCorrect()
+        for lev in m.lev:
+            lev.apply_pinned_cells()
+        # (time advance happens inside aa_mesh_step; compare the state before new_dt / Prolongate
+        #  through the active zones, which those two do not touch)
+        for l in range(2):
+            U = m.lev[l].download()[4:-4, 4:-4, 4:-4, :]
+            err = relerr(U, o.lev[l].active)
+            assert max(err) < 1e-9, f"level {l}: {err}"
+    finally:
+        m.close()
+
+
+def test_mesh_create_rejects_bad_nesting(aa, lib):
+    g = np.load(os.path.join(GOLD, "smr_blast_3lev_s6.npz"))
+    ov = [str(o) for o in g["overrides"]]
+    bad = [o for o in ov if not o.startswith("domain2/iDisp")] + ["domain2/iDisp=0"]   # touches the periodic root edge: allowed
+    par = aa.athinput.ParTable.from_file(os.path.join(orc.DECKS, "athinput.blast")).cmdline(bad)
+    run = aa.config.from_par(par, "blast")
+    with pytest.raises(aa.athinput.ParError):
+        # level 3 (iDisp=20 -> level-1 zone 10) now lies outside level 2 (zones 0..6 of level 1)
+        aa.config.levels(par, run)
+    # the C-ABI refuses levels that were not created with matching aa_params.level
+    import ctypes as C
+    par = aa.athinput.ParTable.from_file(os.path.join(orc.DECKS, "athinput.blast")).cmdline(ov)
+    run = aa.config.from_par(par, "blast")
+    levels = aa.config.levels(par, run)
+    g0 = lib.setup_problem(levels[0], 0, True); g1 = lib.setup_problem(levels[0], 0, True)
+    try:
+        hs = (C.c_void_p * 2)(g0._h, g1._h); disp = (C.c_int * 6)(0, 0, 0, 8, 20, 6); h = C.c_void_p()
+        assert g0.L.aa_mesh_create(2, hs, disp, C.byref(h)) != 0
+        assert b"level" in g0.L.aa_last_error()
+    finally:
+        g0.close(); g1.close()
