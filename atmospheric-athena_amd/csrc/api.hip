@@ -256,6 +256,14 @@ int aa_bvals_mhd(aa_grid *g)
   return 0;
 }
 
+int aa_bvals_mhd_side(aa_grid *g, int dir, int side)
+{
+  if (dir < 0 || dir > 2 || side < 0 || side > 1) return fail(-1, "[aa_bvals_mhd_side]: dir=%d side=%d", dir, side);
+  const int flag = g->p.bc[2*dir + side];
+  if (flag) { Scope s(g, "bvals_mhd"); launch_bc(g->d, g->p.nscal, dir, side, flag, g->st); }
+  return 0;
+}
+
 int aa_bvals_ionrad(aa_grid *g)
 {
   if (!g->p.ion || g->rad_dir != -1) return 0;
@@ -460,6 +468,23 @@ int aa_test_lr_states(int nscal, double gamma, int n, const double *W, double dt
   HIPCHK(hipDeviceSynchronize());
   HIPCHK(hipMemcpy(Wl, dWl, nb, hipMemcpyDeviceToHost)); HIPCHK(hipMemcpy(Wr, dWr, nb, hipMemcpyDeviceToHost));
   hipFree(d);
+  return 0;
+}
+
+// ---- history sums (dump_history.c:157-200) ---------------------------------------------------
+int aa_history(aa_grid *g, double *sums)
+{
+  // partial rows go through the face-state area, idle outside the integrator
+  const int nb = launch_history(g->d, g->p.nscal, g->d.LR, g->st);
+  std::vector<double> part((size_t)nb*9);
+  HIPCHK(hipMemcpyAsync(part.data(), g->d.LR, part.size()*sizeof(double), hipMemcpyDeviceToHost, g->st));
+  HIPCHK(hipStreamSynchronize(g->st));
+  const double dVol = g->d.dx[0]*g->d.dx[1]*g->d.dx[2];
+  for (int q = 0; q < 9; q++) {
+    double s = 0.0;
+    for (int b = 0; b < nb; b++) s += part[(size_t)b*9 + q];
+    sums[q] = dVol*s;
+  }
   return 0;
 }
 

@@ -73,6 +73,7 @@ void launch_vl_uhalf(const DevGrid &g, int nscal, Real dt, bool grav, hipStream_
 void launch_vl_flux2(const DevGrid &g, int nscal, int dir, Real dt, hipStream_t st);
 void launch_bc(const DevGrid &g, int nscal, int dir, int side, int flag, hipStream_t st);
 void launch_cfl(const DevGrid &g, DevScalars *sc, hipStream_t st);
+int  launch_history(const DevGrid &g, int nscal, Real *partial, hipStream_t st);   // returns the number of partial rows
 void launch_aos_to_soa(const DevGrid &g, int nvar, const Real *aos, hipStream_t st);
 void launch_soa_to_aos(const DevGrid &g, int nvar, Real *aos, hipStream_t st);
 void launch_pinned(const DevGrid &g, int nvar, long long n, const long long *idx, const Real *vals,

@@ -550,6 +550,34 @@ k_cfl(DevGrid g, DevScalars *sc)
   if (threadIdx.x == 0) for (int d = 0; d < 3; d++) atomic_max_pos(&sc->max_v[d], red[d][0]);
 }
 
+// ---- history sums (dump_history.c:157-200): mass, E, momenta, kinetic energies, scalar; one
+// partial row per block, added up on the host in block order (deterministic) ------------------
+__global__ void __launch_bounds__(256)
+k_history(DevGrid g, int nscal, Real *partial)
+{
+  const int ni = g.ie - g.is + 1, nj = g.je - g.js + 1, nk = g.ke - g.ks + 1;
+  const long ntot = (long)ni*nj*nk;
+  Real acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  for (long lin = (long)blockIdx.x*blockDim.x + threadIdx.x; lin < ntot; lin += (long)gridDim.x*blockDim.x) {
+    const int i = g.is + (int)(lin % ni);
+    const int j = g.js + (int)((lin / ni) % nj);
+    const int k = g.ks + (int)(lin / ((long)ni*nj));
+    const long m = (long)k*g.sK + (long)j*g.sJ + i;
+    const Real d = Uf(g, 0)[m], d1 = 1.0/d, M1 = Uf(g, 1)[m], M2 = Uf(g, 2)[m], M3 = Uf(g, 3)[m];
+    acc[0] += d; acc[1] += Uf(g, 4)[m]; acc[2] += M1; acc[3] += M2; acc[4] += M3;
+    acc[5] += 0.5*M1*M1*d1; acc[6] += 0.5*M2*M2*d1; acc[7] += 0.5*M3*M3*d1;
+    if (nscal) acc[8] += Uf(g, 5)[m];
+  }
+  __shared__ Real red[9][256];
+  for (int q = 0; q < 9; q++) red[q][threadIdx.x] = acc[q];
+  __syncthreads();
+  for (int s = blockDim.x/2; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) for (int q = 0; q < 9; q++) red[q][threadIdx.x] += red[q][threadIdx.x + s];
+    __syncthreads();
+  }
+  if (threadIdx.x < 9) partial[(long)blockIdx.x*9 + threadIdx.x] = red[threadIdx.x][0];
+}
+
 // ---- layout conversion, pinned cells, x3 halo pack/unpack ----------------------------------
 __global__ void k_aos_to_soa(DevGrid g, int nvar, const Real *aos)
 {
@@ -748,6 +776,14 @@ void launch_cfl(const DevGrid &g, DevScalars *sc, hipStream_t st)
   const long n = (long)(g.ie - g.is + 1)*(g.je - g.js + 1)*(g.ke - g.ks + 1);
   unsigned nb = nblk(n, 256); if (nb > 4096) nb = 4096;
   hipLaunchKernelGGL(k_cfl, dim3(nb), dim3(256), 0, st, g, sc);
+}
+
+int launch_history(const DevGrid &g, int nscal, Real *partial, hipStream_t st)
+{
+  const long n = (long)(g.ie - g.is + 1)*(g.je - g.js + 1)*(g.ke - g.ks + 1);
+  unsigned nb = nblk(n, 256); if (nb > 1024) nb = 1024;
+  hipLaunchKernelGGL(k_history, dim3(nb), dim3(256), 0, st, g, nscal, partial);
+  return (int)nb;
 }
 
 void launch_aos_to_soa(const DevGrid &g, int nvar, const Real *aos, hipStream_t st)

@@ -74,6 +74,7 @@ class HipEngine:
     def unpack_x3(self, side: int): self.g.unpack_x3(side, self.recv[side].data_ptr())
     def sync(self): self.g.sync()
     def download(self) -> np.ndarray: return self.g.download()
+    def history(self) -> np.ndarray: return self.g.history()
     def close(self): self.g.close()
 
 
@@ -107,6 +108,23 @@ class Driver:
         return t.tolist()
 
     def _min(self, *vals): return self._allreduce(vals, self.dist.ReduceOp.MIN if self.distributed else None)
+
+    def history(self) -> np.ndarray:
+        """dump_history.c:157-260: this slab's volume integrals, added over the slabs of the Domain
+        (the reference's MPI_Reduce(SUM) :257; here an all-reduce so every rank may write)."""
+        s = self.eng.history()
+        if self.distributed:
+            s = np.array(self._allreduce(s, self.dist.ReduceOp.SUM))
+        return s
+
+    def dump_history(self, writer):
+        """One row of the .hst file (history.HistoryWriter); call it where main.c calls data_output."""
+        vol = 1.0
+        for d in range(3):
+            vol *= self.run.xmax[d] - self.run.xmin[d]
+        s = self.history()
+        if self.rank == 0:
+            writer.dump(self.time, self.dt, s, vol, self.run.nscal)
 
     def exchange_x3(self):
         """bvals_mhd.c:423-493 for the x3 direction."""

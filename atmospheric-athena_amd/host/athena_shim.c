@@ -159,13 +159,41 @@ void integrate_destruct(void)
 void bvals_mhd_init(MeshS *pM) { M0 = pM; }   /* main.c:412, before the first bvals_mhd; the
                                                   non-ion DomainS has no Mesh back-pointer */
 
+/* bvals_mhd.c:917: problem() may enrol its own boundary function for a side (it runs on the host
+ * block, like every problem-file hook) */
+void bvals_mhd_fun(DomainS *pD, enum BCDirection dir, VGFun_t prob_bc)
+{
+  switch (dir) {
+  case left_x1:  pD->ix1_BCFun = prob_bc; break;
+  case right_x1: pD->ox1_BCFun = prob_bc; break;
+  case left_x2:  pD->ix2_BCFun = prob_bc; break;
+  case right_x2: pD->ox2_BCFun = prob_bc; break;
+  case left_x3:  pD->ix3_BCFun = prob_bc; break;
+  case right_x3: pD->ox3_BCFun = prob_bc; break;
+  default: ath_error("[bvals_fun]: Unknown direction = %d\n", (int)dir);
+  }
+}
+
 static int after_new_dt = 0, steps_since_sync = 0;
 void bvals_mhd(DomainS *pD)
 {
-  (void)pD;
+  VGFun_t usr[6]; int d, side, any = 0;
   ensure_grid(M0);
   to_device();
-  CHK(aa_bvals_mhd(G));
+  usr[0] = pD->ix1_BCFun; usr[1] = pD->ox1_BCFun; usr[2] = pD->ix2_BCFun;
+  usr[3] = pD->ox2_BCFun; usr[4] = pD->ix3_BCFun; usr[5] = pD->ox3_BCFun;
+  for (d = 0; d < 6; d++) any |= (usr[d] != NULL);
+  if (!any) CHK(aa_bvals_mhd(G));
+  else {
+    /* bvals_mhd.c:196-420: ix1, ox1, ix2, ox2, ix3, ox3 in this order; a user function sees the host
+     * block with everything filled so far and its ghost zones travel back before the next side */
+    for (d = 0; d < 3; d++) for (side = 0; side < 2; side++) {
+      if (usr[2*d + side] == NULL) { CHK(aa_bvals_mhd_side(G, d, side)); continue; }
+      CHK(aa_download_cons(G, host_block()));
+      (*usr[2*d + side])(PG);
+      CHK(aa_upload_cons(G, host_block()));
+    }
+  }
   /* main.c calls bvals_mhd after the ion step (:552; nothing on the host looks at U before
    * Integrate) and after new_dt (:638; data_output() at the top of the next cycle reads the host
    * block): only the latter refreshes the host view */

@@ -87,7 +87,7 @@ def load(strict: bool | None = None) -> C.CDLL:
         "aa_set_static_grav_tables": (I, [P, dp, dp, dp, dp]),
         "aa_set_pinned_cells": (I, [P, LL, llp, dp]), "aa_apply_pinned_cells": (I, [P]),
         "aa_add_radplane_3d": (I, [P, I, D]),
-        "aa_bvals_mhd": (I, [P]), "aa_bvals_ionrad": (I, [P]), "aa_new_dt": (I, [P]),
+        "aa_bvals_mhd": (I, [P]), "aa_bvals_mhd_side": (I, [P, I, I]), "aa_bvals_ionrad": (I, [P]), "aa_new_dt": (I, [P]),
         "aa_integrate_3d_ctu": (I, [P]), "aa_integrate_3d_vl": (I, [P]), "aa_ion_radtransfer_3d": (I, [P, ip]),
         "aa_start": (I, [P]), "aa_step": (I, [P, ip]),
         "aa_new_dt_local": (I, [P, dp]), "aa_ion_begin": (I, [P]), "aa_ion_rates": (I, [P, dp, dp]),
@@ -100,6 +100,7 @@ def load(strict: bool | None = None) -> C.CDLL:
         "aa_mesh_start": (I, [P]), "aa_mesh_step": (I, [P, ip]),
         "aa_test_fluxes": (I, [I, D, I, dp, dp, dp, dp]),
         "aa_test_lr_states": (I, [I, D, I, dp, D, D, I, I, dp, dp]),
+        "aa_history": (I, [P, dp]),
         "aa_profile_enable": (I, [P, I]), "aa_profile_reset": (I, [P]), "aa_profile_count": (I, [P]),
         "aa_profile_name": (C.c_char_p, [P, I]), "aa_profile_get": (I, [P, I, dp, llp]),
     }
@@ -271,6 +272,10 @@ class Grid:
     def halo_doubles(self) -> int: return int(self.L.aa_halo_doubles(self._h))
     def pack_x3(self, side: int, dev_ptr: int): self._chk(self.L.aa_pack_x3(self._h, side, C.c_void_p(dev_ptr)))
     def unpack_x3(self, side: int, dev_ptr: int): self._chk(self.L.aa_unpack_x3(self._h, side, C.c_void_p(dev_ptr)))
+
+    def history(self) -> np.ndarray:
+        """Volume integrals of this Grid in .hst column order (dump_history.c:157-200)."""
+        s = np.zeros(9); self._chk(self.L.aa_history(self._h, _dp(s))); return s
 
     # ---- measurement -------------------------------------------------------------------
     def profile_enable(self, on: bool = True): self.L.aa_profile_enable(self._h, 1 if on else 0)

@@ -81,6 +81,9 @@ int aa_add_radplane_3d(aa_grid *g, int dir, double flux);
 
 /* ---- the reference's per-step call sites */
 int aa_bvals_mhd(aa_grid *g);                       /* bvals_mhd.c:174 (physical BCs only)        */
+int aa_bvals_mhd_side(aa_grid *g, int dir, int side); /* one (*BCFun)(pGrid) call of bvals_mhd.c:196-420:
+                                                        dir 0..2, side 0 inner / 1 outer; for drivers that
+                                                        interleave user boundary functions (bvals_mhd_fun :917) */
 int aa_bvals_ionrad(aa_grid *g);                    /* bvals_ionrad.c:63                          */
 int aa_new_dt(aa_grid *g);                          /* new_dt.c:32                                */
 int aa_integrate_3d_ctu(aa_grid *g);                /* integrate_3d_ctu.c:110, dt = Grid dt       */
@@ -127,6 +130,12 @@ int aa_test_fluxes(int nscal, double gamma, int n, const double *Ul, const doubl
                    const double *etah, double *F);                      /* roe.c:59        */
 int aa_test_lr_states(int nscal, double gamma, int n, const double *W, double dt, double dx,
                       int il, int iu, double *Wl, double *Wr);          /* lr_states_plm.c:62 */
+
+/* ---- dump_history.c:157-200: volume integrals over the active zones of this Grid, in the column
+ *      order of the .hst file: mass, total E, x1/x2/x3 Mom., x1/x2/x3-KE, scalar 0 (0 if NSCALARS=0).
+ *      Sums over Grids (MPI_Reduce :257) and the division by the Domain volume (:271-279) are the
+ *      caller's.                                                                               */
+int aa_history(aa_grid *g, double sums[9]);
 
 /* ---- measurement: per-kernel accumulated device time (hipEvent pairs on the stream) */
 int         aa_profile_enable(aa_grid *g, int on);

@@ -87,7 +87,7 @@ typedef struct Mesh_s {                    /* athena.h:397-425 */
 typedef Real (*GravPotFun_t)(const Real x1, const Real x2, const Real x3);   /* athena.h:540 */
 typedef Real (*CoolingFun_t)(const Real d, const Real p, const Real dt);     /* athena.h:545 */
 
-/* ---- the 14 entry points the reference's driver and problem files link against
+/* ---- the 15 entry points the reference's driver and problem files link against
  *      (SURVEY.md 8b); implemented by host/athena_shim.c on top of include/athena_amd.h ---- */
 void    lr_states_init(MeshS *pM);                 /* reconstruction/prototypes.h:43 */
 void    lr_states_destruct(void);                  /* :42 */
@@ -102,6 +102,8 @@ void    clear_coarse_time(void);                   /* :34 */
 void    add_radplane_3d(GridS *pGrid, int dir, Real flux);   /* :58 */
 void    bvals_mhd_init(MeshS *pM);                 /* prototypes.h:75 */
 void    bvals_mhd(DomainS *pD);                    /* :76 */
+enum BCDirection {left_x1, right_x1, left_x2, right_x2, left_x3, right_x3};   /* athena.h:543 */
+void    bvals_mhd_fun(DomainS *pD, enum BCDirection dir, VGFun_t prob_bc);    /* :77 */
 void    new_dt(MeshS *pM);                         /* :147 */
 
 #endif

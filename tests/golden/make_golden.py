@@ -10,7 +10,7 @@ through oracle/_ref/libref_<cfg>.so to produce function-level known-answer vecto
 
 Fixtures are DATA (arrays + the scalar trace of each run); no reference text is stored.
 
-usage: python tests/golden/make_golden.py [whole] [dev] [kernels] [smr]
+usage: python tests/golden/make_golden.py [whole] [dev] [kernels] [smr] [hst]
 """
 import ctypes as C
 import os
@@ -227,6 +227,31 @@ def smr_runs():
               f"nan={[int(np.isnan(U).sum()) for U, _ in last['levels']]}")
 
 
+def history_runs():
+    """.hst files written by the reference (dump_history.c): the text is the expected output of our
+    history writer for the same run."""
+    sphere = os.path.join(REF, "tst/massloss/athinput.ioniz_sphere_hires")
+    blast = os.path.join(REF, "tst/3D-hydro/athinput.blast")
+    for name, cfg, deck, nx, nlim, extra in (
+            ("hst_blast_16x16x16_s3", "blast", blast, (16, 16, 16), 3,
+             ["job/num_domains=1", "job/maxout=1", "output1/out_fmt=hst", "output1/dt=1e-9"]),
+            ("hst_ioniz_sphere_20x20x20_s2", "ioniz_sphere", sphere, (20, 20, 20), 2,
+             ["job/num_domains=1", "job/maxout=1", "output1/out_fmt=hst", "output1/dt=1e-9"])):
+        tmp = tempfile.mkdtemp(prefix="golden_")
+        rundir = os.path.join(tmp, "run")
+        pr = subprocess.run([os.path.join(REFBIN, "athena_" + cfg), "-i", deck, "-d", rundir, f"time/nlim={nlim}"]
+                            + [f"domain1/Nx{d + 1}={nx[d]}" for d in range(3)] + extra,
+                            stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, cwd=tmp)
+        if pr.returncode != 0:
+            raise RuntimeError(pr.stdout[-2000:] + pr.stderr[-2000:])
+        hst = [f for f in os.listdir(rundir) if f.endswith(".hst")]
+        text = open(os.path.join(rundir, hst[0])).read()
+        shutil.rmtree(tmp)
+        np.savez_compressed(os.path.join(HERE, name + ".npz"), nx=np.array(nx), nstep=nlim, text=np.array(text),
+                            basename=np.array(hst[0][:-4]))
+        print(f"{name}: {len(text.splitlines())} lines in {hst[0]}")
+
+
 # ------------------------------------------------------------------------------------
 def dp(a):
     return a.ctypes.data_as(C.POINTER(C.c_double))
@@ -305,7 +330,9 @@ def kernel_vectors():
 if __name__ == "__main__":
     if not os.path.isdir(REF) or not os.path.isdir(REFBIN):
         sys.exit("needs /root/reference and oracle/_ref (make -C oracle ref)")
-    which = sys.argv[1:] or ["whole", "dev", "kernels", "smr"]
+    which = sys.argv[1:] or ["whole", "dev", "kernels", "smr", "hst"]
+    if "hst" in which:
+        history_runs()
     if "whole" in which:
         whole_runs()
     if "dev" in which:

@@ -49,6 +49,10 @@ class OracleEngine:
 
     def has_radiation(self): return bool(self.cfg.run.ion)
 
+    def history(self):
+        hist = importlib.import_module("atmospheric-athena_amd.history")
+        return hist.sums_from_block(self.s.active, self.cfg.run.dx, self.cfg.run.nscal)
+
     def pack_x3(self, side):
         k0 = 4 if side == 0 else self.N[2] - 8
         blk = self.s.U[k0:k0 + 4, :, :, :self.nv]                  # [kk][j][i][v]
@@ -74,7 +78,7 @@ def _worker(rank, world, port, problem, overrides, nsteps, q):
     d = driver.Driver(run, OracleEngine, rank, world)
     d.start()
     its = [d.step() for _ in range(nsteps)]
-    q.put((rank, d.grid.disp[2], d.grid.Nx[2], d.eng.download()[4:-4, 4:-4, 4:-4].copy(), its, d.time, d.dt))
+    q.put((rank, d.grid.disp[2], d.grid.Nx[2], d.eng.download()[4:-4, 4:-4, 4:-4].copy(), its, d.time, d.dt, d.history()))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -111,10 +115,14 @@ def test_slabs_equal_single_grid(problem, nx, nsteps, world):
     its_ref = [ref.step() for _ in range(nsteps)]
     res = run_slabs(problem, ov, nsteps, world)
     nv = 5 + ref.grid.run.nscal
-    for rank, disp, n3, U, its, t, dt in res:
+    hist = importlib.import_module("atmospheric-athena_amd.history")
+    href = hist.sums_from_block(ref.active, ref.grid.run.dx, ref.grid.run.nscal)
+    for rank, disp, n3, U, its, t, dt, h in res:
         assert its == its_ref
         assert t == ref.time and dt == ref.dt
         assert np.array_equal(U[..., :nv], ref.active[disp:disp + n3, :, :, :nv]), f"slab {rank} differs"
+        # history sums: SUM over slabs == the single-Grid integrals (to summation-order rounding)
+        assert np.array_equal(h, res[0][7]) and np.allclose(h[[0, 1, 5, 6, 7]], href[[0, 1, 5, 6, 7]], rtol=1e-12, atol=0)
 
 
 def test_slab_geometry(aa):

@@ -64,3 +64,38 @@ def test_reference_driver_on_gpu_library(problem, nx, nlim, env):
     assert err < 1e-8, err                       # north_star bar: 1e-6 on density / ion fraction
     if not problem.startswith("blast"):
         assert np.allclose(gpu["edgeflux"], ref["edgeflux"], rtol=1e-8, atol=1e-8 * np.abs(ref["edgeflux"]).max())
+
+
+def test_user_boundary_functions_enrolled_by_problem():
+    """bvals_mhd_fun (bvals_mhd.c:917): a user problem file (tests/fixtures/userbc_blast.c, written
+    against the reference's problem-file API) enrols its own inner-x1 and outer-x2 boundary
+    functions.  The same problem object is linked once into the pure reference and once into the
+    drop-in; the shim must call the user functions in the reference's order between its device
+    boundary kernels."""
+    if not os.path.exists(os.path.join(REFBIN, "athena_userbc_amd")):
+        pytest.skip("oracle/_ref userbc executables not built (make -C oracle -f Makefile.ref userbc)")
+    from make_golden import read_rst
+    nx, nlim = (20, 16, 12), 5
+    outs = {}
+    for exe in ("athena_userbc", "athena_userbc_amd"):
+        tmp = tempfile.mkdtemp(prefix="userbc_")
+        deck = os.path.join(tmp, "athinput")
+        text = open(os.path.join(ROOT, "atmospheric-athena_amd", "decks", "athinput.blast")).read()
+        text = text.replace("maxout      = 0", "maxout      = 1") + "\n<output1>\nout_fmt = rst\ndt = 1e300\n"
+        open(deck, "w").write(text)
+        pr = subprocess.run([os.path.join(REFBIN, exe), "-i", deck, "-d", os.path.join(tmp, "run"),
+                             f"domain1/Nx1={nx[0]}", f"domain1/Nx2={nx[1]}", f"domain1/Nx3={nx[2]}", f"time/nlim={nlim}",
+                             "domain1/bc_ix1=2", "domain1/bc_ox1=2", "domain1/bc_ix2=1", "domain1/bc_ox2=2"],
+                            stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, cwd=tmp, timeout=600)
+        assert pr.returncode == 0, pr.stdout[-1500:] + pr.stderr[-1500:]
+        rsts = sorted(f for f in os.listdir(os.path.join(tmp, "run")) if f.endswith(".rst"))
+        outs[exe] = read_rst(os.path.join(tmp, "run", rsts[-1]), nx, 0, False)
+        shutil.rmtree(tmp)
+    ref, gpu = outs["athena_userbc"], outs["athena_userbc_amd"]
+    assert gpu["nstep"] == ref["nstep"] == nlim
+    assert abs(gpu["time"] / ref["time"] - 1) < 1e-12 and abs(gpu["dt"] / ref["dt"] - 1) < 1e-12
+    a, b = gpu["U"][..., :5], ref["U"][..., :5]
+    scale = np.abs(b).max(axis=(0, 1, 2)); scale[scale == 0] = 1
+    assert (np.abs(a - b).max(axis=(0, 1, 2)) / scale).max() < 1e-11      # default (FMA) build, 5 steps
+    # the inflow must have mattered: x1-momentum near the inner-x1 face differs from an outflow run
+    assert np.abs(b[:, :, 0, 1]).max() > 0
