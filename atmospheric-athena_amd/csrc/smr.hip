@@ -213,7 +213,6 @@ struct aa_mesh {
   hipStream_t st = nullptr;
   double tcoarse = 0;              // ionrad_3d.c:44
   double time = 0, dt = 0; int nstep = 0;   // MeshS
-  bool started = false;
 };
 
 extern "C" {
@@ -279,8 +278,11 @@ void aa_mesh_destroy(aa_mesh *m)      // the levels stay alive and go back to th
 
 int aa_mesh_get_state(const aa_mesh *m, double *time, double *dt, int *nstep)
 { if (time) *time = m->time; if (dt) *dt = m->dt; if (nstep) *nstep = m->nstep; return 0; }
+int aa_mesh_set_state(aa_mesh *m, double time, double dt, int nstep)
+{ m->time = time; m->dt = dt; m->nstep = nstep; return 0; }
 
-// smr.c:1207.  Before the first step (main.c:401) the myFlx arrays are zero: no flux correction.
+// smr.c:1207.  Before the first step (main.c:401) the reference's myFlx arrays are all zero and the
+// flux correction adds q*(0-0); here the flux arrays are zero-initialised, to the same effect.
 int aa_mesh_restrict_correct(aa_mesh *m)
 {
   for (int l = m->nl - 2; l >= 0; l--) {       // child l+1 -> parent l, finest pair first
@@ -292,7 +294,7 @@ int aa_mesh_restrict_correct(aa_mesh *m)
     // restricts the child (Step 3 of the child's pass) before the parent applies Steps 1-2
     hipLaunchKernelGGL(k_restrict, dim3(nblk((long)L.n[0]*L.n[1]*L.n[2], 256)), dim3(256), 0, m->st,
                        C->d, P->d, L, (1u << nvar) - 1u);
-    if (m->started) for (int dim = 0; dim < 6; dim++) {
+    for (int dim = 0; dim < 6; dim++) {
       if (!L.side[dim]) continue;
       const int d = dim >> 1, d1 = (d == 0) ? 1 : 0, d2 = (d == 2) ? 1 : 2;
       hipLaunchKernelGGL(k_flux_correct, dim3(nblk((long)L.n[d1]*L.n[d2], 256)), dim3(256), 0, m->st,
@@ -410,16 +412,13 @@ int aa_mesh_ion_radtransfer(aa_mesh *m, int l, int *niter_out)
 int aa_mesh_start(aa_mesh *m)
 {
   int rc;
-  m->started = false;
   if ((rc = aa_mesh_restrict_correct(m))) return rc;
   for (int l = 0; l < m->nl; l++) {
     if ((rc = aa_bvals_mhd(m->lev[l]))) return rc;
     if ((rc = aa_bvals_ionrad(m->lev[l]))) return rc;
   }
   if ((rc = aa_mesh_prolongate(m))) return rc;
-  if ((rc = aa_mesh_new_dt(m))) return rc;
-  m->started = true;
-  return 0;
+  return aa_mesh_new_dt(m);
 }
 
 // one pass of main.c:519-669 with STATIC_MESH_REFINEMENT; niter[l] = radiation sub-cycles of level l

@@ -2,7 +2,10 @@
  * MI355X library.  Linked in place of the reference's integrators/, reconstruction/, rsolvers/,
  * ionradiation/, bvals_mhd.o and new_dt.o, it lets the reference's own driver (main.c), mesh
  * construction, parameter reader, outputs and problem files run unchanged with the per-step
- * physics on the GPU.  Single level, single Grid per process (NO_MPI / NO_SMR configuration).
+ * physics on the GPU.  One Grid per Domain and one Domain per level, all on one GPU: the single
+ * level configuration, or (compiled with -DAA_SMR against the reference's --enable-smr build) the
+ * nested levels of static mesh refinement, where it also provides SMR_init, RestrictCorrect,
+ * Prolongate and ionradRestrictCorrect (smr.c) on top of aa_mesh_*.
  *
  * Host/device coherence (the reference's problem files and outputs index pG->U on the host):
  *   AA_COHERENCE=step  (default) the host block is refreshed after Integrate() (so that
@@ -29,19 +32,25 @@ extern CoolingFun_t CoolingFunc;
 extern double par_getd(char *block, char *name);
 extern void ath_error(char *fmt, ...);
 
-static aa_grid *G = NULL;
+#define MAXLEV 8
+static int NL = 0;                          /* levels (1 without SMR) */
+static aa_grid *G[MAXLEV];
+static GridS *PG[MAXLEV];
 static MeshS *M = NULL, *M0 = NULL;
-static GridS *PG = NULL;
-static int host_newer = 1;          /* the host block holds data the device has not seen */
+#ifdef AA_SMR
+static aa_mesh *MM = NULL;
+#endif
+static int host_newer[MAXLEV];      /* the host block of this level holds data the device has not seen */
 static int learn = 0, learned = 0, sync_every = 1;
-static double *snap = NULL;         /* copy of U after Integrate (learn mode) */
-static size_t ncell = 0;
+static double *snap[MAXLEV];        /* copy of U after Integrate (learn mode) */
+static size_t ncell[MAXLEV];
+static int integrated = 0;          /* Integrate ran since the last host refresh (SMR) */
 
 #define CHK(call) do { if ((call) != 0) ath_error("[athena_amd]: %s\n", aa_last_error()); } while (0)
 
-static double *host_block(void) { return (double*)&(PG->U[0][0][0]); }   /* ath_array.c:100-117 */
+static double *host_block(int l) { return (double*)&(PG[l]->U[0][0][0]); }   /* ath_array.c:100-117 */
 #if AA_ION_RADPLANE
-static double *host_edgeflux(void) { return (double*)&(PG->EdgeFlux[0][0][0]); }
+static double *host_edgeflux(int l) { return (double*)&(PG[l]->EdgeFlux[0][0][0]); }
 #endif
 
 /* configure --with-integrator=vl  <->  -DAA_VL_INTEGRATOR at compile time, or AA_INTEGRATOR=vl */
@@ -57,88 +66,117 @@ static int use_vl(void)
 
 static void ensure_grid(MeshS *pM)
 {
-  aa_params p; DomainS *pD; int d; const char *env;
-  if (G) return;
-  if (pM->NLevels != 1 || pM->DomainsPerLevel[0] != 1)
-    ath_error("[athena_amd]: single level / single Domain only (SMR is a later round)\n");
-  if (CoolingFunc != NULL) ath_error("[athena_amd]: CoolingFunc is not supported on this path\n");
-  M = pM; pD = &pM->Domain[0][0]; PG = pD->Grid;
-  if (sizeof(ConsS) != (5 + AA_NSCALARS)*sizeof(double)) ath_error("[athena_amd]: ConsS layout\n");
-  memset(&p, 0, sizeof p);
-  for (d = 0; d < 3; d++) {
-    p.Nx[d] = PG->Nx[d]; p.rootNx[d] = pM->Nx[d];
-    p.xmin[d] = pM->RootMinX[d]; p.xmax[d] = pM->RootMaxX[d]; p.MinX[d] = PG->MinX[d];
-  }
-  p.bc[0] = pM->BCFlag_ix1; p.bc[1] = pM->BCFlag_ox1; p.bc[2] = pM->BCFlag_ix2;
-  p.bc[3] = pM->BCFlag_ox2; p.bc[4] = pM->BCFlag_ix3; p.bc[5] = pM->BCFlag_ox3;
-  for (d = 0; d < 6; d++)
-    if (p.bc[d] != 1 && p.bc[d] != 2 && p.bc[d] != 4) ath_error("[bvals_init]: bc flag = %d unknown\n", p.bc[d]);
-  p.nscal = AA_NSCALARS;
-#if AA_ION_RADPLANE
-  p.ion = (pM->radplanelist != NULL && pM->radplanelist->nradplane > 0);
+  aa_params p; DomainS *pD; int d, l, irefine; const char *env;
+  int disp[3*MAXLEV];
+  if (NL) return;
+#ifdef AA_SMR
+  if (pM->NLevels > MAXLEV) ath_error("[athena_amd]: more than %d levels\n", MAXLEV);
 #else
-  p.ion = 0;
+  if (pM->NLevels != 1) ath_error("[athena_amd]: this shim was compiled without -DAA_SMR: single level only\n");
 #endif
-  p.gamma = Gamma; p.cour_no = CourNo; p.tlim = par_getd("time", "tlim");
-  if (p.ion) {                                   /* ionrad_3d.c:742-757 */
-    p.sigma_ph = par_getd("ionradiation", "sigma_ph"); p.m_H = par_getd("ionradiation", "m_H");
-    p.mu = par_getd("ionradiation", "mu"); p.e_gamma = par_getd("ionradiation", "e_gamma");
-    p.alpha_C = par_getd("ionradiation", "alpha_C"); p.k_B = par_getd("ionradiation", "k_B");
-    p.time_unit = par_getd("ionradiation", "time_unit");
-    p.max_de_iter = par_getd("ionradiation", "max_de_iter");
-    p.max_de_therm_iter = par_getd("ionradiation", "max_de_therm_iter");
-    p.max_dx_iter = par_getd("ionradiation", "max_dx_iter");
-    p.max_de_step = par_getd("ionradiation", "max_de_step");
-    p.max_de_therm_step = par_getd("ionradiation", "max_de_therm_step");
-    p.max_dx_step = par_getd("ionradiation", "max_dx_step");
-    p.tfloor = par_getd("ionradiation", "tfloor"); p.tceil = par_getd("ionradiation", "tceil");
-    p.maxiter = (int)par_getd("ionradiation", "maxiter");
-  }
-  env = getenv("AA_DEVICE"); p.device = env ? atoi(env) : 0;
-  p.integrator = use_vl();
-  CHK(aa_create(&p, &G));
-  ncell = (size_t)(PG->Nx[0] + 2*AA_NGHOST)*(PG->Nx[1] + 2*AA_NGHOST)*(PG->Nx[2] + 2*AA_NGHOST);
-#if AA_ION_RADPLANE
-  if (p.ion) CHK(aa_add_radplane_3d(G, pM->radplanelist->dir[0], pM->radplanelist->flux_i));
-#endif
-  if (StaticGravPot != NULL) CHK(aa_set_static_grav_pot(G, StaticGravPot));
+  for (l = 0; l < pM->NLevels; l++)
+    if (pM->DomainsPerLevel[l] != 1) ath_error("[athena_amd]: one Domain per level only (level %d has %d)\n", l, pM->DomainsPerLevel[l]);
+  if (CoolingFunc != NULL) ath_error("[athena_amd]: CoolingFunc is not supported on this path\n");
+  if (sizeof(ConsS) != (5 + AA_NSCALARS)*sizeof(double)) ath_error("[athena_amd]: ConsS layout\n");
+  M = pM;
   env = getenv("AA_COHERENCE"); learn = (env && strcmp(env, "learn") == 0);
   env = getenv("AA_SYNC_EVERY"); sync_every = env ? atoi(env) : 1; if (sync_every < 1) sync_every = 1;
-  fprintf(stderr, "[athena_amd] Grid %dx%dx%d on HIP device %d, %.2f GB resident, coherence=%s\n",
-          p.Nx[0], p.Nx[1], p.Nx[2], p.device, aa_device_bytes(G)/1e9, learn ? "learn" : "step");
-}
-
-static void to_device(void)
-{
-  if (host_newer) { CHK(aa_upload_cons(G, host_block())); host_newer = 0; }
-  CHK(aa_set_mesh_state(G, M->time, M->dt, M->nstep));
-}
-
-static void to_host(void)
-{
-  CHK(aa_download_cons(G, host_block()));
+  for (l = 0, irefine = 1; l < pM->NLevels; l++, irefine *= 2) {
+    pD = &pM->Domain[l][0]; PG[l] = pD->Grid;
+    if (pD->NGrid[0]*pD->NGrid[1]*pD->NGrid[2] != 1) ath_error("[athena_amd]: one Grid per Domain only\n");
+    memset(&p, 0, sizeof p);
+    for (d = 0; d < 3; d++) {
+      p.Nx[d] = PG[l]->Nx[d]; p.rootNx[d] = pM->Nx[d];
+      p.xmin[d] = pM->RootMinX[d]; p.xmax[d] = pM->RootMaxX[d]; p.MinX[d] = PG[l]->MinX[d];
+      disp[3*l + d] = pD->Disp[d];
+    }
+    p.bc[0] = pM->BCFlag_ix1; p.bc[1] = pM->BCFlag_ox1; p.bc[2] = pM->BCFlag_ix2;
+    p.bc[3] = pM->BCFlag_ox2; p.bc[4] = pM->BCFlag_ix3; p.bc[5] = pM->BCFlag_ox3;
+    for (d = 0; d < 6; d++)
+      if (p.bc[d] != 1 && p.bc[d] != 2 && p.bc[d] != 4) ath_error("[bvals_init]: bc flag = %d unknown\n", p.bc[d]);
+    for (d = 0; d < 3; d++) {                      /* bvals_mhd.c:193-361: ProlongateLater on fine/coarse sides */
+      if (pD->Disp[d] != 0) p.bc[2*d] = 0;
+      if ((pD->Disp[d] + pD->Nx[d])/irefine != pM->Nx[d]) p.bc[2*d + 1] = 0;
+    }
+    p.level = l;
+    p.nscal = AA_NSCALARS;
 #if AA_ION_RADPLANE
-  if (M->radplanelist != NULL && M->radplanelist->nradplane > 0) CHK(aa_download_edgeflux(G, host_edgeflux()));
+    p.ion = (pM->radplanelist != NULL && pM->radplanelist->nradplane > 0);
+#else
+    p.ion = 0;
 #endif
+    p.gamma = Gamma; p.cour_no = CourNo; p.tlim = par_getd("time", "tlim");
+    if (p.ion) {                                   /* ionrad_3d.c:742-757 */
+      p.sigma_ph = par_getd("ionradiation", "sigma_ph"); p.m_H = par_getd("ionradiation", "m_H");
+      p.mu = par_getd("ionradiation", "mu"); p.e_gamma = par_getd("ionradiation", "e_gamma");
+      p.alpha_C = par_getd("ionradiation", "alpha_C"); p.k_B = par_getd("ionradiation", "k_B");
+      p.time_unit = par_getd("ionradiation", "time_unit");
+      p.max_de_iter = par_getd("ionradiation", "max_de_iter");
+      p.max_de_therm_iter = par_getd("ionradiation", "max_de_therm_iter");
+      p.max_dx_iter = par_getd("ionradiation", "max_dx_iter");
+      p.max_de_step = par_getd("ionradiation", "max_de_step");
+      p.max_de_therm_step = par_getd("ionradiation", "max_de_therm_step");
+      p.max_dx_step = par_getd("ionradiation", "max_dx_step");
+      p.tfloor = par_getd("ionradiation", "tfloor"); p.tceil = par_getd("ionradiation", "tceil");
+      p.maxiter = (int)par_getd("ionradiation", "maxiter");
+    }
+    env = getenv("AA_DEVICE"); p.device = env ? atoi(env) : 0;
+    p.integrator = use_vl();
+    CHK(aa_create(&p, &G[l]));
+    ncell[l] = (size_t)(PG[l]->Nx[0] + 2*AA_NGHOST)*(PG[l]->Nx[1] + 2*AA_NGHOST)*(PG[l]->Nx[2] + 2*AA_NGHOST);
+    host_newer[l] = 1; snap[l] = NULL;
+#if AA_ION_RADPLANE
+    if (p.ion) CHK(aa_add_radplane_3d(G[l], pM->radplanelist->dir[0], pM->radplanelist->flux_i));
+#endif
+    if (StaticGravPot != NULL) CHK(aa_set_static_grav_pot(G[l], StaticGravPot));
+    fprintf(stderr, "[athena_amd] Grid %dx%dx%d (level %d) on HIP device %d, %.2f GB resident, coherence=%s\n",
+            p.Nx[0], p.Nx[1], p.Nx[2], l, p.device, aa_device_bytes(G[l])/1e9, learn ? "learn" : "step");
+  }
+  NL = pM->NLevels;
+#ifdef AA_SMR
+  CHK(aa_mesh_create(NL, G, disp, &MM));
+#else
+  (void)disp;
+#endif
+}
+
+static void to_device(int l)
+{
+  if (host_newer[l]) { CHK(aa_upload_cons(G[l], host_block(l))); host_newer[l] = 0; }
+  CHK(aa_set_mesh_state(G[l], M->time, PG[l]->dt, M->nstep));
+}
+
+static void to_host(int l)
+{
+  CHK(aa_download_cons(G[l], host_block(l)));
+#if AA_ION_RADPLANE
+  if (M->radplanelist != NULL && M->radplanelist->nradplane > 0) CHK(aa_download_edgeflux(G[l], host_edgeflux(l)));
+#endif
+}
+
+/* after the integrator (and, with SMR, RestrictCorrect): Userwork_in_loop reads and may write pG->U */
+static void refresh_for_userwork(int l)
+{
+  if (learn && learned) { CHK(aa_apply_pinned_cells(G[l])); return; }
+  to_host(l);
+  host_newer[l] = 1;
+  if (learn) {
+    if (!snap[l]) snap[l] = (double*)malloc(ncell[l]*sizeof(ConsS));
+    memcpy(snap[l], host_block(l), ncell[l]*sizeof(ConsS));
+  }
 }
 
 /* ---- reconstruction / integrator ---------------------------------------------------------- */
 void lr_states_init(MeshS *pM) { (void)pM; }
 void lr_states_destruct(void) {}
 
-static void integrate_3d_ctu_amd(DomainS *pD)
+static void integrate_3d_amd(DomainS *pD)
 {
-  GridS *pG = pD->Grid;
-  to_device();
-  CHK(aa_set_mesh_state(G, M->time, pG->dt, M->nstep));
-  if (use_vl()) CHK(aa_integrate_3d_vl(G)); else CHK(aa_integrate_3d_ctu(G));
-  if (learn && learned) { CHK(aa_apply_pinned_cells(G)); return; }
-  to_host();                                    /* Userwork_in_loop reads and may write pG->U */
-  host_newer = 1;
-  if (learn) {
-    if (!snap) snap = (double*)malloc(ncell*sizeof(ConsS));
-    memcpy(snap, host_block(), ncell*sizeof(ConsS));
-  }
+  const int l = pD->Level;
+  to_device(l);
+  if (use_vl()) CHK(aa_integrate_3d_vl(G[l])); else CHK(aa_integrate_3d_ctu(G[l]));
+  integrated = 1;
+  if (NL == 1) refresh_for_userwork(0);         /* with SMR, RestrictCorrect (main.c:591) still follows */
 }
 
 VDFun_t integrate_init(MeshS *pM)
@@ -146,13 +184,17 @@ VDFun_t integrate_init(MeshS *pM)
   if (CourNo > 0.5)     /* integrate.c:66-68 */
     ath_error("<time>cour_no was set to %g: must be <= 0.5 with 3D integrator\n", CourNo);
   ensure_grid(pM);
-  return integrate_3d_ctu_amd;
+  return integrate_3d_amd;
 }
 
 void integrate_destruct(void)
 {
-  if (G) { aa_destroy(G); G = NULL; }
-  free(snap); snap = NULL;
+  int l;
+#ifdef AA_SMR
+  if (MM) { aa_mesh_destroy(MM); MM = NULL; }
+#endif
+  for (l = 0; l < NL; l++) { if (G[l]) { aa_destroy(G[l]); G[l] = NULL; } free(snap[l]); snap[l] = NULL; }
+  NL = 0;
 }
 
 /* ---- boundaries / time step ------------------------------------------------------------- */
@@ -175,60 +217,108 @@ void bvals_mhd_fun(DomainS *pD, enum BCDirection dir, VGFun_t prob_bc)
 }
 
 static int after_new_dt = 0, steps_since_sync = 0;
+
+/* data_output() at the top of the next cycle reads the host blocks */
+static void refresh_for_output(void)
+{
+  int l;
+  after_new_dt = 0;
+  if (!(learn && learned) || (++steps_since_sync >= sync_every)) { for (l = 0; l < NL; l++) to_host(l); steps_since_sync = 0; }
+}
+
 void bvals_mhd(DomainS *pD)
 {
-  VGFun_t usr[6]; int d, side, any = 0;
+  VGFun_t usr[6]; int d, side, any = 0; const int l = pD->Level;
   ensure_grid(M0);
-  to_device();
+  to_device(l);
   usr[0] = pD->ix1_BCFun; usr[1] = pD->ox1_BCFun; usr[2] = pD->ix2_BCFun;
   usr[3] = pD->ox2_BCFun; usr[4] = pD->ix3_BCFun; usr[5] = pD->ox3_BCFun;
   for (d = 0; d < 6; d++) any |= (usr[d] != NULL);
-  if (!any) CHK(aa_bvals_mhd(G));
+  if (!any) CHK(aa_bvals_mhd(G[l]));
   else {
     /* bvals_mhd.c:196-420: ix1, ox1, ix2, ox2, ix3, ox3 in this order; a user function sees the host
      * block with everything filled so far and its ghost zones travel back before the next side */
     for (d = 0; d < 3; d++) for (side = 0; side < 2; side++) {
-      if (usr[2*d + side] == NULL) { CHK(aa_bvals_mhd_side(G, d, side)); continue; }
-      CHK(aa_download_cons(G, host_block()));
-      (*usr[2*d + side])(PG);
-      CHK(aa_upload_cons(G, host_block()));
+      if (usr[2*d + side] == NULL) { CHK(aa_bvals_mhd_side(G[l], d, side)); continue; }
+      CHK(aa_download_cons(G[l], host_block(l)));
+      (*usr[2*d + side])(PG[l]);
+      CHK(aa_upload_cons(G[l], host_block(l)));
     }
   }
   /* main.c calls bvals_mhd after the ion step (:552; nothing on the host looks at U before
-   * Integrate) and after new_dt (:638; data_output() at the top of the next cycle reads the host
-   * block): only the latter refreshes the host view */
-  if (after_new_dt) {
-    after_new_dt = 0;
-    if (!(learn && learned) || (++steps_since_sync >= sync_every)) { to_host(); steps_since_sync = 0; }
-  }
+   * Integrate) and after new_dt (:638): only the latter refreshes the host view -- with SMR the
+   * refresh waits for Prolongate (:647), which still writes the fine ghost zones */
+  if (after_new_dt && NL == 1) refresh_for_output();
 }
 
 void new_dt(MeshS *pM)
 {
-  int nl, nd; double t, dt; int n;
+  int nl, nd, l; double t, dt; int n;
   ensure_grid(pM);
-  if (learn && !learned && snap) {              /* what did Userwork_in_loop change? */
-    const double *h = host_block(); long long cnt = 0, c; size_t i; int v;
-    const int nv = 5 + AA_NSCALARS; long long *idx; double *val;
-    for (i = 0; i < ncell; i++) if (memcmp(h + i*nv, snap + i*nv, nv*sizeof(double)) != 0) cnt++;
-    idx = (long long*)malloc((size_t)(cnt + 1)*sizeof(long long)); val = (double*)malloc((size_t)(cnt + 1)*nv*sizeof(double));
-    for (i = 0, c = 0; i < ncell; i++) if (memcmp(h + i*nv, snap + i*nv, nv*sizeof(double)) != 0) {
-      idx[c] = (long long)i; for (v = 0; v < nv; v++) val[c*nv + v] = h[i*nv + v]; c++;
+  if (learn && !learned && snap[0]) {           /* what did Userwork_in_loop change? */
+    const int nv = 5 + AA_NSCALARS;
+    for (l = 0; l < NL; l++) {
+      const double *h = host_block(l); long long cnt = 0, c; size_t i; int v; long long *idx; double *val;
+      for (i = 0; i < ncell[l]; i++) if (memcmp(h + i*nv, snap[l] + i*nv, nv*sizeof(double)) != 0) cnt++;
+      idx = (long long*)malloc((size_t)(cnt + 1)*sizeof(long long)); val = (double*)malloc((size_t)(cnt + 1)*nv*sizeof(double));
+      for (i = 0, c = 0; i < ncell[l]; i++) if (memcmp(h + i*nv, snap[l] + i*nv, nv*sizeof(double)) != 0) {
+        idx[c] = (long long)i; for (v = 0; v < nv; v++) val[c*nv + v] = h[i*nv + v]; c++;
+      }
+      CHK(aa_set_pinned_cells(G[l], cnt, idx, val));
+      free(idx); free(val); free(snap[l]); snap[l] = NULL;
+      CHK(aa_apply_pinned_cells(G[l]));          /* this step's Userwork, on the device */
+      fprintf(stderr, "[athena_amd] Userwork_in_loop pins %lld cells on level %d; re-imposed on the device from now on\n", cnt, l);
     }
-    CHK(aa_set_pinned_cells(G, cnt, idx, val));
-    free(idx); free(val); free(snap); snap = NULL; learned = 1;
-    CHK(aa_apply_pinned_cells(G));              /* this step's Userwork, on the device */
-    fprintf(stderr, "[athena_amd] Userwork_in_loop pins %lld cells; re-imposed on the device from now on\n", cnt);
+    learned = 1;
   }
-  if (learn && learned) host_newer = 0;         /* the stale host copy must not travel back */
-  to_device();
-  CHK(aa_new_dt(G));
-  CHK(aa_get_mesh_state(G, &t, &dt, &n));
+  for (l = 0; l < NL; l++) {
+    if (learn && learned) host_newer[l] = 0;    /* the stale host copy must not travel back */
+    to_device(l);
+  }
+#ifdef AA_SMR
+  CHK(aa_mesh_set_state(MM, pM->time, pM->dt, pM->nstep));
+  CHK(aa_mesh_new_dt(MM));
+  CHK(aa_mesh_get_state(MM, &t, &dt, &n));
+#else
+  CHK(aa_new_dt(G[0]));
+  CHK(aa_get_mesh_state(G[0], &t, &dt, &n));
+#endif
   pM->dt = dt;
   after_new_dt = 1;
   for (nl = 0; nl < pM->NLevels; nl++) for (nd = 0; nd < pM->DomainsPerLevel[nl]; nd++)
     if (pM->Domain[nl][nd].Grid != NULL) pM->Domain[nl][nd].Grid->dt = dt;      /* new_dt.c:189-195 */
 }
+
+#ifdef AA_SMR
+/* ---- static mesh refinement (smr.c) ------------------------------------------------------- */
+void SMR_init(MeshS *pM) { ensure_grid(pM); }          /* main.c:400, after problem() on every level */
+
+void RestrictCorrect(MeshS *pM)                        /* main.c:401, :591 */
+{
+  int l;
+  ensure_grid(pM);
+  for (l = 0; l < NL; l++) to_device(l);
+  CHK(aa_mesh_restrict_correct(MM));
+  if (integrated) { integrated = 0; for (l = 0; l < NL; l++) refresh_for_userwork(l); }
+}
+
+void Prolongate(MeshS *pM)                             /* main.c:446, :647 */
+{
+  int l;
+  ensure_grid(pM);
+  for (l = 0; l < NL; l++) to_device(l);
+  CHK(aa_mesh_prolongate(MM));
+  /* :647 ends the cycle (data_output follows at the top of the next one); :446 precedes the very
+   * first output, which must already see the restricted parent zones */
+  if (after_new_dt || pM->nstep == 0) refresh_for_output();
+}
+
+void ionradRestrictCorrect(MeshS *pM)                  /* main.c:561 */
+{
+  (void)pM;
+  CHK(aa_mesh_ionrad_restrict_correct(MM));
+}
+#endif /* AA_SMR */
 
 /* ---- ion radiation ------------------------------------------------------------------------ */
 void ion_radtransfer_init_domain(MeshS *pM) { (void)pM; }
@@ -236,11 +326,15 @@ void ion_radtransfer_init_domain(MeshS *pM) { (void)pM; }
 #if AA_ION_RADPLANE
 static void ion_radtransfer_3d_amd(DomainS *pD)
 {
-  GridS *pG = pD->Grid; MeshS *pM = pD->Mesh; int niter = 0; double t, dt; int n;
-  to_device();
-  CHK(aa_set_mesh_state(G, pM->time, pG->dt, pM->nstep));
-  CHK(aa_ion_radtransfer_3d(G, &niter));
-  CHK(aa_get_mesh_state(G, &t, &dt, &n));
+  GridS *pG = pD->Grid; MeshS *pM = pD->Mesh; int niter = 0; double t, dt; int n; const int l = pD->Level;
+  to_device(l);
+#ifdef AA_SMR
+  CHK(aa_mesh_set_state(MM, pM->time, pM->dt, pM->nstep));
+  CHK(aa_mesh_ion_radtransfer(MM, l, &niter));
+#else
+  CHK(aa_ion_radtransfer_3d(G[l], &niter));
+#endif
+  CHK(aa_get_mesh_state(G[l], &t, &dt, &n));
   pG->dt = dt; pM->dt = dt;                     /* ionrad_3d.c:1033 */
   fprintf(stderr, "Radiation done in %d iterations; new dt = %e\n", niter, dt);
 }
@@ -253,15 +347,15 @@ VDFun_t ion_radtransfer_init(MeshS *pM, int ires)
 }
 
 void bvals_ionrad_init(MeshS *pM) { (void)pM; }
-void bvals_ionrad(DomainS *pD) { ensure_grid(pD->Mesh); CHK(aa_bvals_ionrad(G)); }
+void bvals_ionrad(DomainS *pD) { ensure_grid(pD->Mesh); CHK(aa_bvals_ionrad(G[pD->Level])); }
 void set_coarse_time(void) {}
 void clear_coarse_time(void) {}
 
 void add_radplane_3d(GridS *pGrid, int dir, Real flux)   /* ionradplane_3d.c:56-66 */
 {
-  MeshS *pMesh = pGrid->Mesh;
+  MeshS *pMesh = pGrid->Mesh; int l;
   pMesh->radplanelist->dir[0] = dir;
   pMesh->radplanelist->flux_i = flux;
-  if (G) CHK(aa_add_radplane_3d(G, dir, flux));
+  for (l = 0; l < NL; l++) CHK(aa_add_radplane_3d(G[l], dir, flux));
 }
 #endif /* AA_ION_RADPLANE */

@@ -94,7 +94,7 @@ def load(strict: bool | None = None) -> C.CDLL:
         "aa_ion_update": (I, [P, D, llp, dp]),
         "aa_halo_doubles": (LL, [P]), "aa_pack_x3": (I, [P, I, P]), "aa_unpack_x3": (I, [P, I, P]),
         "aa_mesh_create": (I, [I, C.POINTER(P), ip, C.POINTER(P)]), "aa_mesh_destroy": (None, [P]),
-        "aa_mesh_get_state": (I, [P, dp, dp, ip]),
+        "aa_mesh_get_state": (I, [P, dp, dp, ip]), "aa_mesh_set_state": (I, [P, D, D, I]),
         "aa_mesh_restrict_correct": (I, [P]), "aa_mesh_ionrad_restrict_correct": (I, [P]),
         "aa_mesh_prolongate": (I, [P]), "aa_mesh_new_dt": (I, [P]), "aa_mesh_ion_radtransfer": (I, [P, I, ip]),
         "aa_mesh_start": (I, [P]), "aa_mesh_step": (I, [P, ip]),

@@ -115,6 +115,7 @@ int  aa_mesh_create(int nlevels, aa_grid **levels, const int *disp, aa_mesh **ou
                                                           tables (:150-560) + SMR_init (smr.c:2931)  */
 void aa_mesh_destroy(aa_mesh *m);
 int  aa_mesh_get_state(const aa_mesh *m, double *time, double *dt, int *nstep);     /* MeshS          */
+int  aa_mesh_set_state(aa_mesh *m, double time, double dt, int nstep);
 int  aa_mesh_restrict_correct(aa_mesh *m);        /* smr.c:1207 RestrictCorrect                      */
 int  aa_mesh_ionrad_restrict_correct(aa_mesh *m); /* smr.c:85 ionradRestrictCorrect                  */
 int  aa_mesh_prolongate(aa_mesh *m);              /* smr.c:2359 Prolongate                           */

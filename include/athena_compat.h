@@ -1,7 +1,8 @@
 /* include/athena_compat.h -- the reference's host-side data structures, restated for the one
  * configuration this package accelerates:
  *   HYDRO, ADIABATIC, CARTESIAN, NSCALARS = AA_NSCALARS (default 1), ION_RADIATION + ION_RADPLANE,
- *   NO_MPI_PARALLEL, NO_MESH_REFINEMENT, no particles / self-gravity / shearing box.
+ *   NO_MPI_PARALLEL, NO_MESH_REFINEMENT (or STATIC_MESH_REFINEMENT with -DAA_SMR), no particles /
+ *   self-gravity / shearing box.
  * A driver or problem file compiled against the reference's athena.h with those macros and one
  * compiled against this header agree on every offset, so the reference's own main.o, init_mesh.o,
  * problem.o ... can be linked against host/athena_shim.c unchanged.  Field order
@@ -24,6 +25,9 @@ struct Mesh_s;
 typedef struct GridsData_s {               /* athena.h:66-72 */
   int Nx[3], Disp[3];
   int ID_Comm_world, ID_Comm_Domain;
+#ifdef AA_SMR
+  int ID_Comm_Children, ID_Comm_Parent;    /* athena.h:70-73 */
+#endif
 } GridsDataS;
 
 typedef struct Cons_s {                    /* athena.h:81-100 */
@@ -39,6 +43,18 @@ typedef struct Radplane_s {                /* athena.h:134-142 */
   Real flux_i;
 } Radplane;
 
+#ifdef AA_SMR
+typedef struct GridOvrlp_s {               /* athena.h:257-276 */
+  int ijks[3], ijke[3];
+  int ID, DomN;
+  int nWordsRC, nWordsP;
+  ConsS **myFlx[6];
+#if AA_ION_RADPLANE
+  Real *ionFlx[6];
+#endif
+} GridOvrlpS;
+#endif
+
 typedef struct Grid_s {                    /* athena.h:289-321 */
   ConsS ***U;
   Real MinX[3], MaxX[3];
@@ -50,6 +66,10 @@ typedef struct Grid_s {                    /* athena.h:289-321 */
 #if AA_ION_RADPLANE
   Real ***EdgeFlux;                        /* athena.h:316-319 */
   struct Mesh_s *Mesh;
+#endif
+#ifdef AA_SMR
+  int NCGrid, NPGrid, NmyCGrid, NmyPGrid;  /* athena.h:332-342 */
+  GridOvrlpS *CGrid, *PGrid;
 #endif
 } GridS;
 
@@ -105,5 +125,11 @@ void    bvals_mhd(DomainS *pD);                    /* :76 */
 enum BCDirection {left_x1, right_x1, left_x2, right_x2, left_x3, right_x3};   /* athena.h:543 */
 void    bvals_mhd_fun(DomainS *pD, enum BCDirection dir, VGFun_t prob_bc);    /* :77 */
 void    new_dt(MeshS *pM);                         /* :147 */
+#ifdef AA_SMR                                      /* prototypes.h:163-168 (smr.c) */
+void    SMR_init(MeshS *pM);
+void    RestrictCorrect(MeshS *pM);
+void    Prolongate(MeshS *pM);
+void    ionradRestrictCorrect(MeshS *pM);
+#endif
 
 #endif

@@ -99,3 +99,54 @@ def test_user_boundary_functions_enrolled_by_problem():
     assert (np.abs(a - b).max(axis=(0, 1, 2)) / scale).max() < 1e-11      # default (FMA) build, 5 steps
     # the inflow must have mattered: x1-momentum near the inner-x1 face differs from an outflow run
     assert np.abs(b[:, :, 0, 1]).max() > 0
+
+
+@pytest.mark.parametrize("fixture,cfg,env", [
+    ("smr_blast_3lev_s6", "blast_smr", {}),
+    ("smr_blast_3lev_edge_s8", "blast_smr", {}),
+    ("smr_ioniz_sphere_2lev_s4", "ioniz_sphere_smr", {}),
+    ("smr_ioniz_sphere_2lev_s4", "ioniz_sphere_smr", {"AA_COHERENCE": "learn"}),
+])
+def test_reference_smr_driver_on_gpu_library(fixture, cfg, env):
+    """The reference's --enable-smr driver (main.o, init_mesh.o, init_grid.o with its overlap tables,
+    restart writer, unmodified problem file) linked against the shim compiled with -DAA_SMR: SMR_init,
+    RestrictCorrect, Prolongate and ionradRestrictCorrect come from the HIP library.  Every level of
+    the restart dump is compared with the all-CPU reference executable's."""
+    if not os.path.exists(os.path.join(REFBIN, f"athena_{cfg}_amd")):
+        pytest.skip("oracle/_ref SMR drop-in executables not built (make -C oracle ref)")
+    from make_golden import read_rst_levels
+    g = np.load(os.path.join(HERE, "golden", fixture + ".npz"))
+    over = [str(o) for o in g["overrides"]]
+    nlim = int(g["nstep"])
+    problem = "blast" if "blast" in cfg else "ioniz_sphere"
+    ion = problem != "blast"
+    nlev = int(g["nlevels"])
+    nxs = [tuple(int(next(o for o in over if o.startswith(f"domain{n}/Nx{d}=")).split("=")[1]) for d in (1, 2, 3))
+           for n in range(1, nlev + 1)]
+    outs = {}
+    for exe, e in ((f"athena_{cfg}", {}), (f"athena_{cfg}_amd", env)):
+        tmp = tempfile.mkdtemp(prefix="dropin_smr_")
+        deck = os.path.join(tmp, "athinput")
+        text = open(os.path.join(ROOT, "atmospheric-athena_amd", "decks", "athinput." + problem)).read()
+        text = text.replace("maxout      = 0", "maxout      = 1") + "\n<output1>\nout_fmt = rst\ndt = 1e300\n"
+        open(deck, "w").write(text)
+        envp = dict(os.environ); envp.update(e)
+        pr = subprocess.run([os.path.join(REFBIN, exe), "-i", deck, "-d", os.path.join(tmp, "run"), f"time/nlim={nlim}"] + over,
+                            stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, cwd=tmp, env=envp, timeout=600)
+        assert pr.returncode == 0, pr.stdout[-1500:] + pr.stderr[-1500:]
+        rsts = sorted(f for f in os.listdir(os.path.join(tmp, "run")) if f.endswith(".rst"))
+        outs[exe] = (read_rst_levels(os.path.join(tmp, "run", rsts[0]), nxs, 1 if ion else 0, ion),
+                     read_rst_levels(os.path.join(tmp, "run", rsts[-1]), nxs, 1 if ion else 0, ion), pr.stderr)
+        shutil.rmtree(tmp)
+    (ref0, ref, _), (gpu0, gpu, err) = outs[f"athena_{cfg}"], outs[f"athena_{cfg}_amd"]
+    assert "(level 1) on HIP device" in err
+    assert gpu["nstep"] == ref["nstep"] == nlim
+    assert abs(gpu["time"] / ref["time"] - 1) < 1e-9 and abs(gpu["dt"] / ref["dt"] - 1) < 1e-9
+    nv = 6 if ion else 5
+    for l in range(nlev):
+        # the dump written before the first cycle already holds the restricted parent zones
+        assert np.array_equal(gpu0["levels"][l][0][..., :nv], ref0["levels"][l][0][..., :nv]), f"initial dump, level {l}"
+        a, b = gpu["levels"][l][0][..., :nv], ref["levels"][l][0][..., :nv]
+        scale = np.abs(b).max(axis=(0, 1, 2)); scale[scale == 0] = 1
+        e = (np.abs(a - b).max(axis=(0, 1, 2)) / scale).max()
+        assert e < 1e-8, (l, e)                  # north_star bar: 1e-6
