@@ -115,3 +115,22 @@ def test_restart_round_trip(aa, tmp_path):
     assert np.array_equal(r["U"], U[..., :5]) and r["edgeflux"] is None
     with pytest.raises(ValueError):
         R.read_rst(p, nx, 1, True)
+
+
+def test_restart_levels_round_trip(aa, tmp_path):
+    """Multi-level dumps (static mesh refinement): the Domains' blocks follow each other under one header."""
+    R = aa.restart
+    rng = np.random.default_rng(5)
+    nxs = [(6, 4, 8), (4, 4, 2)]
+    levels = [(rng.normal(size=(nx[2], nx[1], nx[0], 6)), rng.normal(size=(nx[2] + 1, nx[1] + 1, nx[0] + 1))) for nx in nxs]
+    par = aa.athinput.ParTable.from_text("<job>\nproblem_id = x\nnum_domains = 2\n")
+    p = str(tmp_path / "l.rst")
+    R.write_rst_levels(p, R.par_dump(par), 9, 2.5, 0.125, levels)
+    r = R.read_rst_levels(p, nxs, 1, True)
+    assert (r["nstep"], r["time"], r["dt"]) == (9, 2.5, 0.125) and r["par"].geti("job", "num_domains") == 2
+    for (U, ef), (U2, ef2) in zip(levels, r["levels"]):
+        assert np.array_equal(U, U2) and np.array_equal(ef, ef2)
+    # a single-level file is the one-level case of the same layout
+    R.write_rst(p, R.par_dump(par), 9, 2.5, 0.125, levels[0][0], levels[0][1])
+    r1 = R.read_rst_levels(p, nxs[:1], 1, True)
+    assert np.array_equal(r1["levels"][0][0], levels[0][0])
