@@ -15,7 +15,7 @@ x3 slabs are produced.
 from __future__ import annotations
 
 from dataclasses import dataclass, field, replace
-from typing import Dict, List, Optional, Tuple
+from typing import Dict, List, Optional, Sequence, Tuple
 
 from .athinput import ParTable, ParError
 
@@ -194,3 +194,148 @@ def levels(par: ParTable, run: RunConfig) -> List[GridConfig]:
         out.append(GridConfig(run=run, rank=0, nranks=1, Nx=Nx, disp=disp, MinX=MinX, bc=tuple(bc),
                               lx3=-1, rx3=-1, level=lev))
     return out
+
+
+# ---- static mesh refinement across several GPUs ---------------------------------------------------
+# Every level is cut at the SAME planes as the root (x3 slabs, SURVEY.md 8e "co-partitioned"): rank r
+# owns root planes [K_r, K_r+1) and, of level l, the zones lying over them.  Restriction, the
+# radiation hand-off and prolongation then stay inside a rank (prolongation reads the parent's
+# ghost planes where a level starts exactly at a cut); what crosses ranks is the x3 halo of every
+# level and the flux correction of the one parent plane that lies across a cut from the child.
+
+@dataclass
+class LinkConfig:
+    """Level l+1 (this rank's slab of it) seen from this rank's slab of level l."""
+    cs: Tuple[int, int, int]          # first parent zone under the child slab, local parent index incl. ghosts
+    n: Tuple[int, int, int]           # overlap, parent zones
+    prol: Tuple[int, ...]             # [6] the child's ghost zones on this side are prolonged from the parent
+    corr: Tuple[int, ...]             # [6] the parent zone outside this side is on this rank: flux-correct it here
+    corr_to: Tuple[int, int]          # x3 sides: rank owning the parent plane outside (-1 if local or no boundary)
+    cdisp: Tuple[int, int, int]       # child slab origin minus 2 x parent slab origin (zones of the child level)
+
+
+@dataclass
+class MeshSlabConfig:
+    rank: int
+    nranks: int
+    cuts: Tuple[int, ...]             # root planes K_0=0 < ... < K_N
+    table: List[List[Optional[Tuple[int, int]]]]   # table[r][l] = (k0, k1) of level l on rank r (level units) or None
+    levels: List[GridConfig]          # the levels present on this rank, root first
+    links: List[LinkConfig]           # links[l]: levels[l+1] on levels[l]
+    # flux corrections arriving from a neighbour's child slab: (level of the parent, side of the child
+    # boundary 0 lower / 1 upper, source rank, i0, j0, n1, n2) with i0, j0 local parent indices incl. ghosts
+    corr_in: List[Tuple[int, int, int, int, int, int, int]]
+
+
+def balanced_cuts(levs: List[GridConfig], nranks: int) -> Tuple[int, ...]:
+    """Root planes K_r such that every rank gets about the same number of zones summed over levels
+    (a root plane under level l carries 2^l planes of that level)."""
+    root = levs[0]
+    n3 = root.Nx[2]
+    w = [float(root.Nx[0] * root.Nx[1])] * n3
+    for g in levs[1:]:
+        f = 2 ** g.level
+        for k in range(g.disp[2] // f, (g.disp[2] + g.Nx[2]) // f):
+            w[k] += float(g.Nx[0] * g.Nx[1]) * f
+    tot = sum(w)
+    cuts, acc, k = [0], 0.0, 0
+    for r in range(1, nranks):
+        while k < n3 and acc + 0.5 * w[k] < tot * r / nranks:
+            acc += w[k]; k += 1
+        k = max(k, cuts[-1] + NGHOST)
+        cuts.append(k)
+    cuts.append(n3)
+    return tuple(cuts)
+
+
+def mesh_slabs(par: ParTable, run: RunConfig, rank: int, nranks: int,
+               cuts: Optional[Sequence[int]] = None) -> MeshSlabConfig:
+    levs = levels(par, run)
+    n3 = run.rootNx[2]
+    cuts = tuple(cuts) if cuts is not None else balanced_cuts(levs, nranks)
+    if len(cuts) != nranks + 1 or cuts[0] != 0 or cuts[-1] != n3 or any(b - a < NGHOST for a, b in zip(cuts, cuts[1:])):
+        raise ParError(f"[config]: bad x3 cuts {cuts} for {nranks} ranks (slabs need >= {NGHOST} root planes)")
+    table: List[List[Optional[Tuple[int, int]]]] = []
+    for r in range(nranks):
+        row: List[Optional[Tuple[int, int]]] = []
+        for g in levs:
+            f = 2 ** g.level
+            d3 = g.disp[2] if g.level else 0
+            k0, k1 = max(d3, f * cuts[r]), min(d3 + g.Nx[2], f * cuts[r + 1])
+            if k1 <= k0 or (row and row[-1] is None):
+                row.append(None)
+            else:
+                if k1 - k0 < NGHOST:
+                    raise ParError(f"[config]: level {g.level} slab of rank {r} is thinner than nghost; choose other cuts")
+                row.append((k0, k1))
+        table.append(row)
+
+    def has(r, l):
+        return 0 <= r < nranks and table[r][l] is not None
+
+    periodic3 = (run.bc[4] == 4 and run.bc[5] == 4)
+    mine: List[GridConfig] = []
+    for g in levs:
+        span = table[rank][g.level]
+        if span is None:
+            break
+        k0, k1 = span
+        f = 2 ** g.level
+        d3 = g.disp[2] if g.level else 0
+        dx3 = run.dx[2] / float(f)
+        bc = list(g.bc)
+        lo_nb = hi_nb = -1
+        if k0 > d3:                                  # the cut is interior to this level: neighbour slab below
+            lo_nb = rank - 1; bc[4] = 0
+        elif g.level == 0 and periodic3 and nranks > 1:
+            lo_nb = nranks - 1; bc[4] = 0
+        if k1 < d3 + g.Nx[2]:
+            hi_nb = rank + 1; bc[5] = 0
+        elif g.level == 0 and periodic3 and nranks > 1:
+            hi_nb = 0; bc[5] = 0
+        minx3 = run.xmin[2] if k0 == 0 else run.xmin[2] + float(k0) * dx3        # init_mesh.c:281-286 form
+        mine.append(GridConfig(run=run, rank=rank, nranks=nranks, Nx=(g.Nx[0], g.Nx[1], k1 - k0),
+                               disp=(g.disp[0] if g.level else 0, g.disp[1] if g.level else 0, k0),
+                               MinX=(g.MinX[0], g.MinX[1], minx3), bc=tuple(bc), lx3=lo_nb, rx3=hi_nb, level=g.level))
+    links: List[LinkConfig] = []
+    for l in range(len(mine) - 1):
+        P, C, Cg = mine[l], mine[l + 1], levs[l + 1]
+        irefine = 2 ** (l + 1)
+        cs, n, prol, corr = [], [], [0] * 6, [0] * 6
+        corr_to = [-1, -1]
+        for d in range(3):
+            a = C.disp[d] // 2 - P.disp[d]
+            b = (C.disp[d] + C.Nx[d]) // 2 - P.disp[d]
+            cs.append(a + NGHOST); n.append(b - a)
+            glo, ghi = Cg.disp[d], Cg.disp[d] + Cg.Nx[d]           # the level's global extent
+            at_lo = (C.disp[d] == glo) and glo != 0                # a fine/coarse boundary of the LEVEL
+            at_hi = (C.disp[d] + C.Nx[d] == ghi) and (ghi // irefine != run.rootNx[d])
+            prol[2 * d], prol[2 * d + 1] = int(at_lo), int(at_hi)
+            if at_lo:
+                if a > 0 or d < 2:
+                    corr[2 * d] = 1
+                else:
+                    corr_to[0] = rank - 1
+            if at_hi:
+                if b < P.Nx[d] or d < 2:
+                    corr[2 * d + 1] = 1
+                else:
+                    corr_to[1] = rank + 1
+        links.append(LinkConfig(cs=tuple(cs), n=tuple(n), prol=tuple(prol), corr=tuple(corr), corr_to=tuple(corr_to),
+                                cdisp=tuple(C.disp[d] - 2 * P.disp[d] for d in range(3))))
+    corr_in = []
+    for l in range(len(mine)):
+        if l + 1 >= len(levs):
+            break
+        P, Cg = mine[l], levs[l + 1]
+        irefine = 2 ** (l + 1)
+        k0, k1 = table[rank][l]
+        i0 = Cg.disp[0] // 2 - P.disp[0] + NGHOST; j0 = Cg.disp[1] // 2 - P.disp[1] + NGHOST
+        n1, n2 = Cg.Nx[0] // 2, Cg.Nx[1] // 2
+        # the child level starts exactly at my upper cut: my top plane lies outside its lower boundary
+        if Cg.disp[2] == 2 * k1 and Cg.disp[2] != 0 and has(rank + 1, l + 1):
+            corr_in.append((l, 0, rank + 1, i0, j0, n1, n2))
+        ghi = Cg.disp[2] + Cg.Nx[2]
+        if ghi == 2 * k0 and ghi // irefine != run.rootNx[2] and has(rank - 1, l + 1):
+            corr_in.append((l, 1, rank - 1, i0, j0, n1, n2))
+    return MeshSlabConfig(rank=rank, nranks=nranks, cuts=cuts, table=table, levels=mine, links=links, corr_in=corr_in)

@@ -291,6 +291,16 @@ int aa_new_dt_local(aa_grid *g, double *dt_cfl)
   return 0;
 }
 
+int aa_cfl_max_v(aa_grid *g, double *v)      // new_dt.c:72-140 of this Grid: max(|v_d| + a) per direction
+{
+  { Scope s(g, "new_dt");
+    HIPCHK(hipMemsetAsync(g->sc->max_v, 0, 3*sizeof(unsigned long long), g->st));
+    launch_cfl(g->d, g->sc, g->st); }
+  int rc = fetch_scalars(g); if (rc) return rc;
+  for (int d = 0; d < 3; d++) v[d] = bits_to_double(g->sc_host->max_v[d]);
+  return 0;
+}
+
 int aa_new_dt(aa_grid *g)
 {
   double dtc; int rc = aa_new_dt_local(g, &dtc); if (rc) return rc;

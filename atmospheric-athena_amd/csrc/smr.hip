@@ -31,8 +31,9 @@ namespace {
 struct Link {                 // level l+1 seen from level l (init_grid.c: CGrid.ijks/ijke, myFlx != NULL)
   int cs[3], ce[3];           // overlap on the parent, parent indices incl. ghost offset
   int n[3];                   // overlap size in parent zones
-  int side[6];                // the child has a fine/coarse boundary on this side
-  int cdisp[3];               // child's Disp (zones of the child's level)
+  int prol[6];                // the child has a fine/coarse boundary on this side: ghost zones prolonged
+  int corr[6];                // ... and the parent zone outside is on this Grid: flux-corrected here
+  int cdisp[3];               // child origin minus 2 x parent origin, zones of the child's level
 };
 
 __device__ __forceinline__ Real *fld(const DevGrid &g, Real *base, int v) { return base + (long)v*g.nc; }
@@ -200,6 +201,38 @@ k_ionflux_prolong(DevGrid f, DevGrid c, Link L)
 #undef EF
 }
 
+// ---- flux correction across slabs: the child's restricted x3 boundary flux as a message
+// ([b][a][6]), and its application on the neighbouring slab of the parent (smr.c:1322-1340) ----
+__global__ void __launch_bounds__(256)
+k_flux_x3_export(DevGrid f, int side, Real *buf)
+{
+  const int n1 = f.Nx1/2, n2 = f.Nx2/2;
+  const int lin = blockIdx.x*blockDim.x + threadIdx.x;
+  if (lin >= n1*n2) return;
+  const int a = lin % n1, b = lin / n1;
+  const long m = (long)(side ? f.ke + 1 : f.ks)*f.sK + (long)(f.js + 2*b)*f.sJ + (f.is + 2*a);
+  for (int v = 0; v < 6; v++) {
+    const Real *q = fld(f, f.F, 2*6 + v) + m;
+    Real s = q[0] + q[1];
+    s += q[f.sJ] + q[f.sJ + 1];
+    s *= 0.25;
+    buf[(long)lin*6 + v] = s;
+  }
+}
+
+__global__ void __launch_bounds__(256)
+k_flux_x3_apply(DevGrid c, int side, int i0, int j0, int n1, int n2, int nvar, Real dt, const Real *buf)
+{
+  const int lin = blockIdx.x*blockDim.x + threadIdx.x;
+  if (lin >= n1*n2) return;
+  const int a = lin % n1, b = lin / n1;
+  const int kc = side ? c.ks : c.ke, kf = side ? c.ks : c.ke + 1;
+  const Real q = side ? (dt/c.dx[2]) : -(dt/c.dx[2]);
+  const long mc = (long)kc*c.sK + (long)(j0 + b)*c.sJ + (i0 + a), mf = (long)kf*c.sK + (long)(j0 + b)*c.sJ + (i0 + a);
+  for (int v = 0; v < nvar; v++)
+    fld(c, c.U, v)[mc] -= q*(fld(c, c.F, 2*6 + v)[mf] - buf[(long)lin*6 + v]);
+}
+
 inline unsigned nblk(long n, int b) { return (unsigned)((n + b - 1)/b); }
 
 }  // namespace
@@ -210,55 +243,20 @@ struct aa_mesh {
   int disp[AA_MAXLEV][3];
   Link link[AA_MAXLEV];            // link[l]: level l+1 on level l
   Real *box[AA_MAXLEV];            // prolongation snapshot of level l around level l+1
-  hipStream_t st = nullptr;
+  hipStream_t st = nullptr; bool own_stream = true;
   double tcoarse = 0;              // ionrad_3d.c:44
   double time = 0, dt = 0; int nstep = 0;   // MeshS
 };
 
 extern "C" {
 
-// init_grid.c (overlap tables) + SMR_init (smr.c:2931).  Takes over the levels' streams: all
-// levels run on one stream so that inter-level kernels are ordered without events.
-int aa_mesh_create(int nlevels, aa_grid **levels, const int *disp, aa_mesh **out)
+static int mesh_finish(aa_mesh *m, aa_grid **levels, aa_mesh **out)
 {
-  if (!levels || !disp || !out || nlevels < 1 || nlevels > AA_MAXLEV) return aa_fail(-1, "[aa_mesh_create]: bad arguments");
-  aa_mesh *m = new aa_mesh();
-  m->nl = nlevels;
-  for (int l = 0; l < nlevels; l++) {
-    aa_grid *g = levels[l];
-    if (!g || g->level != l) { delete m; return aa_fail(-1, "[aa_mesh_create]: levels[%d] was not created with level=%d", l, l); }
-    if (g->p.device != levels[0]->p.device) { delete m; return aa_fail(-1, "[aa_mesh_create]: all levels must live on one device"); }
-    m->lev[l] = g; m->box[l] = nullptr;
-    for (int d = 0; d < 3; d++) m->disp[l][d] = disp[3*l + d];
-  }
-  for (int l = 0; l + 1 < nlevels; l++) {
-    const aa_grid *P = m->lev[l], *C = m->lev[l + 1];
-    Link &L = m->link[l];
-    const int lo[3] = {P->d.is, P->d.js, P->d.ks};
-    const int irefine = 1 << (l + 1);
-    for (int d = 0; d < 3; d++) {
-      const int a = m->disp[l + 1][d]/2 - m->disp[l][d], b = (m->disp[l + 1][d] + C->p.Nx[d])/2 - m->disp[l][d];
-      if ((m->disp[l + 1][d] & 1) || (C->p.Nx[d] & 1) || a < 0 || b > P->p.Nx[d]) {
-        delete m; return aa_fail(-1, "[aa_mesh_create]: level %d is not nested in level %d along x%d", l + 1, l, d + 1);
-      }
-      L.cs[d] = a + lo[d]; L.ce[d] = b + lo[d] - 1; L.n[d] = b - a; L.cdisp[d] = m->disp[l + 1][d];
-      L.side[2*d]     = (m->disp[l + 1][d] != 0);
-      L.side[2*d + 1] = ((m->disp[l + 1][d] + C->p.Nx[d])/irefine != C->p.rootNx[d]);
-      // init_mesh.c:320-360: a child may touch its parent's edge only on the root boundary
-      if ((a == 0 && L.side[2*d]) || (b == P->p.Nx[d] && L.side[2*d + 1])) {
-        delete m; return aa_fail(-1, "[init_mesh] child Domain of level %d touches its parent in x%d", l + 1, d + 1);
-      }
-    }
-    // ionrad_smr.c:97-98 mixes a parent-local index with the child's root-relative Disp
-    if (P->p.ion && (m->disp[l][1] || m->disp[l][2])) {
-      delete m; return aa_fail(-1, "[aa_mesh_create]: radiation across a displaced parent (level %d) is undefined in the reference", l);
-    }
-  }
   hipError_t e = hipSetDevice(levels[0]->p.device);
   if (e == hipSuccess) e = hipStreamCreate(&m->st);
   if (e != hipSuccess) { delete m; return aa_fail(-2, "[aa_mesh_create]: %s", hipGetErrorString(e)); }
-  for (int l = 0; l < nlevels; l++) aa_set_stream(m->lev[l], (void*)m->st);
-  for (int l = 0; l + 1 < nlevels; l++) {
+  for (int l = 0; l < m->nl; l++) aa_set_stream(m->lev[l], (void*)m->st);
+  for (int l = 0; l + 1 < m->nl; l++) {
     const Link &L = m->link[l];
     const size_t nb = (size_t)(L.n[0] + 6)*(L.n[1] + 6)*(L.n[2] + 6)*6;
     if (hipMalloc(&m->box[l], nb*sizeof(Real)) != hipSuccess) return aa_fail(-2, "[aa_mesh_create]: hipMalloc box");
@@ -267,13 +265,95 @@ int aa_mesh_create(int nlevels, aa_grid **levels, const int *disp, aa_mesh **out
   return 0;
 }
 
+static aa_mesh *mesh_alloc(int nlevels, aa_grid **levels)
+{
+  if (!levels || nlevels < 1 || nlevels > AA_MAXLEV) { aa_fail(-1, "[aa_mesh_create]: bad arguments"); return nullptr; }
+  aa_mesh *m = new aa_mesh();
+  m->nl = nlevels;
+  for (int l = 0; l < nlevels; l++) {
+    aa_grid *g = levels[l];
+    if (!g || g->level != l) { delete m; aa_fail(-1, "[aa_mesh_create]: levels[%d] was not created with level=%d", l, l); return nullptr; }
+    if (g->p.device != levels[0]->p.device) { delete m; aa_fail(-1, "[aa_mesh_create]: all levels must live on one device"); return nullptr; }
+    m->lev[l] = g; m->box[l] = nullptr;
+  }
+  return m;
+}
+
+// init_grid.c (overlap tables) + SMR_init (smr.c:2931).  Takes over the levels' streams: all
+// levels run on one stream so that inter-level kernels are ordered without events.
+int aa_mesh_create(int nlevels, aa_grid **levels, const int *disp, aa_mesh **out)
+{
+  if (!disp || !out) return aa_fail(-1, "[aa_mesh_create]: bad arguments");
+  aa_mesh *m = mesh_alloc(nlevels, levels);
+  if (!m) return -1;
+  for (int l = 0; l + 1 < nlevels; l++) {
+    const aa_grid *P = m->lev[l], *C = m->lev[l + 1];
+    Link &L = m->link[l];
+    const int lo[3] = {P->d.is, P->d.js, P->d.ks};
+    const int irefine = 1 << (l + 1);
+    const int *dp = disp + 3*l, *dc = disp + 3*(l + 1);
+    for (int d = 0; d < 3; d++) {
+      const int a = dc[d]/2 - dp[d], b = (dc[d] + C->p.Nx[d])/2 - dp[d];
+      if ((dc[d] & 1) || (C->p.Nx[d] & 1) || a < 0 || b > P->p.Nx[d]) {
+        delete m; return aa_fail(-1, "[aa_mesh_create]: level %d is not nested in level %d along x%d", l + 1, l, d + 1);
+      }
+      L.cs[d] = a + lo[d]; L.ce[d] = b + lo[d] - 1; L.n[d] = b - a; L.cdisp[d] = dc[d];
+      L.prol[2*d]     = L.corr[2*d]     = (dc[d] != 0);
+      L.prol[2*d + 1] = L.corr[2*d + 1] = ((dc[d] + C->p.Nx[d])/irefine != C->p.rootNx[d]);
+      // init_mesh.c:320-360: a child may touch its parent's edge only on the root boundary
+      if ((a == 0 && L.prol[2*d]) || (b == P->p.Nx[d] && L.prol[2*d + 1])) {
+        delete m; return aa_fail(-1, "[init_mesh] child Domain of level %d touches its parent in x%d", l + 1, d + 1);
+      }
+    }
+    // ionrad_smr.c:97-98 mixes a parent-local index with the child's root-relative Disp
+    if (P->p.ion && (dp[1] || dp[2])) {
+      delete m; return aa_fail(-1, "[aa_mesh_create]: radiation across a displaced parent (level %d) is undefined in the reference", l);
+    }
+  }
+  return mesh_finish(m, levels, out);
+}
+
+// One rank's stack of x3 slabs of a Mesh whose levels are all cut at the same planes (multi-GPU
+// SMR).  links[21*l..]: cs[3] (local parent index incl. ghosts), n[3], prol[6], corr[6], cdisp[3]
+// of level l+1 on level l.  A child slab may reach the edge of its parent slab; where the level
+// itself ends at that edge (prol=1, corr=0) the parent plane outside is corrected on the
+// neighbouring slab with aa_flux_x3_export / aa_flux_x3_apply.
+int aa_mesh_create_local(int nlevels, aa_grid **levels, const int *links, aa_mesh **out)
+{
+  if ((nlevels > 1 && !links) || !out) return aa_fail(-1, "[aa_mesh_create_local]: bad arguments");
+  aa_mesh *m = mesh_alloc(nlevels, levels);
+  if (!m) return -1;
+  for (int l = 0; l + 1 < nlevels; l++) {
+    const int *q = links + 21*l;
+    const aa_grid *P = m->lev[l], *C = m->lev[l + 1];
+    Link &L = m->link[l];
+    for (int d = 0; d < 3; d++) {
+      L.cs[d] = q[d]; L.n[d] = q[3 + d]; L.ce[d] = q[d] + q[3 + d] - 1; L.cdisp[d] = q[18 + d];
+      if (L.n[d]*2 != C->p.Nx[d] || L.cs[d] < AA_NGHOST || L.ce[d] >= AA_NGHOST + P->p.Nx[d]) {
+        delete m; return aa_fail(-1, "[aa_mesh_create_local]: link %d does not match the slabs along x%d", l, d + 1);
+      }
+    }
+    for (int d = 0; d < 6; d++) { L.prol[d] = q[6 + d]; L.corr[d] = q[12 + d]; }
+  }
+  return mesh_finish(m, levels, out);
+}
+
 void aa_mesh_destroy(aa_mesh *m)      // the levels stay alive and go back to the default stream
 {
   if (!m) return;
   hipStreamSynchronize(m->st);
   for (int l = 0; l < m->nl; l++) { m->lev[l]->st = nullptr; m->lev[l]->own_stream = false; if (m->box[l]) hipFree(m->box[l]); }
-  hipStreamDestroy(m->st);
+  if (m->own_stream) hipStreamDestroy(m->st);
   delete m;
+}
+
+int aa_mesh_set_stream(aa_mesh *m, void *hip_stream)   // run every level on a caller-owned stream
+{
+  hipStreamSynchronize(m->st);
+  if (m->own_stream) { hipStreamDestroy(m->st); m->own_stream = false; }
+  m->st = (hipStream_t)hip_stream;
+  for (int l = 0; l < m->nl; l++) { m->lev[l]->st = m->st; m->lev[l]->own_stream = false; }
+  return 0;
 }
 
 int aa_mesh_get_state(const aa_mesh *m, double *time, double *dt, int *nstep)
@@ -283,25 +363,30 @@ int aa_mesh_set_state(aa_mesh *m, double time, double dt, int nstep)
 
 // smr.c:1207.  Before the first step (main.c:401) the reference's myFlx arrays are all zero and the
 // flux correction adds q*(0-0); here the flux arrays are zero-initialised, to the same effect.
-int aa_mesh_restrict_correct(aa_mesh *m)
+int aa_mesh_restrict_correct_pair(aa_mesh *m, int l)      // level l+1 -> level l
 {
-  for (int l = m->nl - 2; l >= 0; l--) {       // child l+1 -> parent l, finest pair first
-    aa_grid *P = m->lev[l], *C = m->lev[l + 1];
-    const Link &L = m->link[l];
-    const int nvar = 5 + P->p.nscal;
-    Scope s(P, "smr_restrict_correct");
-    // flux correction needs the child's (already corrected) fluxes and solution; the reference
-    // restricts the child (Step 3 of the child's pass) before the parent applies Steps 1-2
-    hipLaunchKernelGGL(k_restrict, dim3(nblk((long)L.n[0]*L.n[1]*L.n[2], 256)), dim3(256), 0, m->st,
-                       C->d, P->d, L, (1u << nvar) - 1u);
-    for (int dim = 0; dim < 6; dim++) {
-      if (!L.side[dim]) continue;
-      const int d = dim >> 1, d1 = (d == 0) ? 1 : 0, d2 = (d == 2) ? 1 : 2;
-      hipLaunchKernelGGL(k_flux_correct, dim3(nblk((long)L.n[d1]*L.n[d2], 256)), dim3(256), 0, m->st,
-                         C->d, P->d, L, dim, nvar, (Real)P->dt);
-    }
+  if (l < 0 || l + 1 >= m->nl) return aa_fail(-1, "[aa_mesh_restrict_correct_pair]: pair %d", l);
+  aa_grid *P = m->lev[l], *C = m->lev[l + 1];
+  const Link &L = m->link[l];
+  const int nvar = 5 + P->p.nscal;
+  Scope s(P, "smr_restrict_correct");
+  hipLaunchKernelGGL(k_restrict, dim3(nblk((long)L.n[0]*L.n[1]*L.n[2], 256)), dim3(256), 0, m->st,
+                     C->d, P->d, L, (1u << nvar) - 1u);
+  for (int dim = 0; dim < 6; dim++) {
+    if (!L.corr[dim]) continue;
+    const int d = dim >> 1, d1 = (d == 0) ? 1 : 0, d2 = (d == 2) ? 1 : 2;
+    hipLaunchKernelGGL(k_flux_correct, dim3(nblk((long)L.n[d1]*L.n[d2], 256)), dim3(256), 0, m->st,
+                       C->d, P->d, L, dim, nvar, (Real)P->dt);
   }
   HIPCHK(hipGetLastError());
+  return 0;
+}
+
+int aa_mesh_restrict_correct(aa_mesh *m)
+{
+  // finest pair first: a level is restricted for its parent after it received its own child's
+  // solution and flux correction (the order of the loop over levels at smr.c:1224)
+  for (int l = m->nl - 2; l >= 0; l--) { int rc = aa_mesh_restrict_correct_pair(m, l); if (rc) return rc; }
   return 0;
 }
 
@@ -334,7 +419,7 @@ int aa_mesh_prolongate(aa_mesh *m)
       const int nvar = 5 + C->p.nscal;
       Scope s(C, "smr_prolongate");
       for (int dim = 0; dim < 6; dim++) {
-        if (!L.side[dim]) continue;
+        if (!L.prol[dim]) continue;
         long cnt = 1;
         for (int d = 0; d < 3; d++) cnt *= (d == (dim >> 1)) ? NG/2 : (C->p.Nx[d] + 2*NG)/2;
         hipLaunchKernelGGL(k_prolong, dim3(nblk(cnt, 128)), dim3(128), 0, m->st, C->d, L, m->box[l - 1], dim, nvar);
@@ -369,6 +454,37 @@ int aa_mesh_new_dt(aa_mesh *m)
   return 0;
 }
 
+// ionrad_smr.c:345 + :34: the flux level l-1 left at the upstream face of level l, onto level l's rays
+int aa_mesh_ionflux_prolong(aa_mesh *m, int l)
+{
+  if (l < 1 || l >= m->nl) return aa_fail(-1, "[aa_mesh_ionflux_prolong]: level %d", l);
+  const Link &L = m->link[l - 1];
+  if (L.prol[0])
+    hipLaunchKernelGGL(k_ionflux_prolong, dim3(nblk((long)(L.n[1] + 1)*(L.n[2] + 1), 256)), dim3(256), 0, m->st,
+                       m->lev[l]->d, m->lev[l - 1]->d, L);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+// multi-GPU SMR: the child's restricted boundary flux (DEVICE buffer of (Nx1/2)(Nx2/2)*6 doubles) ...
+int aa_flux_x3_export(aa_grid *child, int side, double *dev_buf)
+{
+  const long n = (long)(child->p.Nx[0]/2)*(child->p.Nx[1]/2);
+  hipLaunchKernelGGL(k_flux_x3_export, dim3(nblk(n, 256)), dim3(256), 0, child->st, child->d, side, dev_buf);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+// ... and its application to the plane of the parent slab across the cut (Grid dt as in RestrictCorrect)
+int aa_flux_x3_apply(aa_grid *parent, int side, int i0, int j0, int n1, int n2, const double *dev_buf)
+{
+  if (i0 < AA_NGHOST || j0 < AA_NGHOST || i0 + n1 > AA_NGHOST + parent->p.Nx[0] || j0 + n2 > AA_NGHOST + parent->p.Nx[1])
+    return aa_fail(-1, "[aa_flux_x3_apply]: region outside the Grid");
+  hipLaunchKernelGGL(k_flux_x3_apply, dim3(nblk((long)n1*n2, 256)), dim3(256), 0, parent->st, parent->d, side, i0, j0, n1, n2,
+                     5 + parent->p.nscal, (Real)parent->dt, dev_buf);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
 // ionrad_3d.c:862 with STATIC_MESH_REFINEMENT: the root sub-cycles to its own stopping criteria and
 // publishes the time it covered; a refined level sub-cycles until it has covered exactly that
 int aa_mesh_ion_radtransfer(aa_mesh *m, int l, int *niter_out)
@@ -378,12 +494,8 @@ int aa_mesh_ion_radtransfer(aa_mesh *m, int l, int *niter_out)
   double dt_chem, dt_therm, dt_hydro = 0, dt, dt_done = 0.0;
   long long cellcount;
   int niter = 0, hydro_done = 0, coarsetime_done = 0, rc;
-  if (finegrid) {
-    const Link &L = m->link[l - 1];
-    if (L.side[0])
-      hipLaunchKernelGGL(k_ionflux_prolong, dim3(nblk((long)(L.n[1] + 1)*(L.n[2] + 1), 256)), dim3(256), 0, m->st,
-                         g->d, m->lev[l - 1]->d, L);
-  } else m->tcoarse = 0;
+  if (finegrid) { if ((rc = aa_mesh_ionflux_prolong(m, l))) return rc; }
+  else m->tcoarse = 0;
   if ((rc = aa_ion_begin(g))) return rc;
   while (finegrid || !hydro_done) {
     if ((rc = aa_ion_rates(g, &dt_chem, &dt_therm))) return rc;

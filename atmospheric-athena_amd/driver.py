@@ -248,3 +248,286 @@ class Driver:
         self.bvals_mhd()
         self.niter_trace.append(niter)
         return niter
+
+
+# ==================================================================================================
+# Static mesh refinement over several GPUs
+# ==================================================================================================
+class HipMeshEngine:
+    """One rank's stack of x3 slabs (one per level present on the rank) on one MI355X."""
+
+    def __init__(self, cfg, device: int = 0, strict: Optional[bool] = None, use_torch_stream: bool = True):
+        import torch
+        from . import lib
+        self.torch = torch
+        self.cfg = cfg
+        torch.cuda.set_device(device)
+        self.mesh = lib.Mesh(cfg.levels, device, strict, links=cfg.links)
+        if use_torch_stream:
+            self.mesh.set_stream(torch.cuda.current_stream().cuda_stream)
+        self.lev = self.mesh.lev
+        dev = torch.device("cuda", device)
+        self.scalar_device = dev
+        self.send = [[torch.empty(g.halo_doubles(), dtype=torch.float64, device=dev) for _ in range(2)] for g in self.lev]
+        self.recv = [[torch.empty(g.halo_doubles(), dtype=torch.float64, device=dev) for _ in range(2)] for g in self.lev]
+        self._fbuf = {}
+
+    nlev = property(lambda s: len(s.lev))
+
+    # per-level slab arithmetic
+    def bvals_local(self, l): self.lev[l].bvals_mhd()
+    def bvals_ionrad(self, l): self.lev[l].bvals_ionrad()
+    def integrate(self, l): self.lev[l].integrate()
+    def userwork(self, l): self.lev[l].apply_pinned_cells()
+    def ion_begin(self, l): self.lev[l].ion_begin()
+    def ion_rates(self, l): return self.lev[l].ion_rates()
+    def ion_update(self, l, dt): return self.lev[l].ion_update(dt)
+    def set_level_state(self, l, time, dt, nstep): self.lev[l].set_mesh_state(time, dt, nstep)
+    def cfl_max_v(self, l): return self.lev[l].cfl_max_v()
+    def has_radiation(self) -> bool: return bool(self.cfg.levels[0].run.ion)
+
+    # x3 halo of level l
+    def pack_x3(self, l, side):
+        self.lev[l].pack_x3(side, self.send[l][side].data_ptr()); return self.send[l][side]
+
+    def recv_buffer(self, l, side): return self.recv[l][side]
+    def unpack_x3(self, l, side): self.lev[l].unpack_x3(side, self.recv[l][side].data_ptr())
+
+    # level coupling inside the rank
+    def restrict_correct_pair(self, l): self.mesh.restrict_correct_pair(l)
+    def ion_restrict_correct(self): self.mesh.ionradRestrictCorrect()
+    def prolongate(self): self.mesh.Prolongate()
+    def ionflux_prolong(self, l): self.mesh.ionflux_prolong(l)
+
+    # flux correction across a cut
+    def flux_buffer(self, n1, n2):
+        key = (n1, n2)
+        if key not in self._fbuf:
+            self._fbuf[key] = self.torch.empty(n1 * n2 * 6, dtype=self.torch.float64, device=self.scalar_device)
+        return self._fbuf[key]
+
+    def flux_x3_export(self, l, side):
+        g = self.lev[l]; nx = self.cfg.levels[l].Nx
+        t = self.torch.empty((nx[0] // 2) * (nx[1] // 2) * 6, dtype=self.torch.float64, device=self.scalar_device)
+        g.flux_x3_export(side, t.data_ptr()); return t
+
+    def flux_x3_apply(self, l, side, i0, j0, n1, n2, t): self.lev[l].flux_x3_apply(side, i0, j0, n1, n2, t.data_ptr())
+
+    def download(self, l) -> np.ndarray: return self.lev[l].download()
+    def sync(self): self.lev[0].sync()
+    def close(self): self.mesh.close()
+
+
+class MeshDriver:
+    """main() of the reference built with STATIC_MESH_REFINEMENT (main.c:395-447, :519-669) for one
+    process of an N-process run in which every level is cut into x3 slabs at the same root planes
+    (config.mesh_slabs).  Inside a rank the level coupling is the local aa_mesh; across ranks go the
+    x3 halo of every level, the flux correction of a parent plane that lies across a cut from the
+    child's boundary, and the scalar reductions (the MPI calls of smr.c, bvals_mhd.c, new_dt.c and
+    ionrad_3d.c in the reference)."""
+
+    def __init__(self, par, run: RunConfig, engine_factory=None, rank: int = 0, nranks: int = 1, device: int = 0,
+                 strict: Optional[bool] = None, cuts=None):
+        from .config import mesh_slabs
+        import torch
+        import torch.distributed as dist
+        self.torch, self.dist = torch, dist
+        self.run, self.rank, self.nranks = run, rank, nranks
+        self.cfg = mesh_slabs(par, run, rank, nranks, cuts)
+        self.eng = engine_factory(self.cfg) if engine_factory else HipMeshEngine(self.cfg, device, strict)
+        self.NL = len(self.cfg.table[0])                  # levels of the Mesh
+        self.nl = len(self.cfg.levels)                    # levels present on this rank
+        self.time, self.dt, self.nstep = 0.0, 0.0, 0
+        self.dtl = [0.0] * self.NL                        # pGrid->dt of every level
+        self.tcoarse = 0.0
+        self.distributed = nranks > 1
+        if self.distributed:
+            assert dist.is_initialized() and dist.get_world_size() == nranks and dist.get_rank() == rank
+        self._sdev = getattr(self.eng, "scalar_device", torch.device("cpu"))
+        self.niter_trace: List[List[int]] = []
+
+    def has(self, l: int) -> bool: return l < self.nl
+
+    def _allreduce(self, vals, op):
+        if not self.distributed:
+            return list(vals)
+        t = self.torch.tensor(list(vals), dtype=self.torch.float64, device=self._sdev)
+        self.dist.all_reduce(t, op=op)
+        return t.tolist()
+
+    def _p2p(self, sends, recvs):
+        """sends: [(tensor, peer)], recvs: [(tensor, peer)]; gloo moves host tensors only."""
+        dist = self.dist
+        host_stage = (dist.get_backend() == "gloo")
+        ops, staged = [], []
+        for t, peer in sends:
+            ops.append(dist.P2POp(dist.isend, t.cpu() if (host_stage and t.is_cuda) else t, peer))
+        for t, peer in recvs:
+            if host_stage and t.is_cuda:
+                h = self.torch.empty(t.shape, dtype=t.dtype); staged.append((t, h)); t = h
+            ops.append(dist.P2POp(dist.irecv, t, peer))
+        if ops:
+            for w in dist.batch_isend_irecv(ops):
+                w.wait()
+        for t, h in staged:
+            t.copy_(h)
+
+    # ---- ghost zones ---------------------------------------------------------------------------
+    def exchange_x3(self, l: int):
+        if not self.distributed or not self.has(l):
+            return
+        g, e = self.cfg.levels[l], self.eng
+        if g.lx3 < 0 and g.rx3 < 0:
+            return
+        sends, recvs, sides = [], [], []
+        if g.lx3 == g.rx3 and g.lx3 >= 0:
+            # two slabs with periodic wrap: post so that the peer's inner planes land in my OUTER ghosts
+            sends = [(e.pack_x3(l, 0), g.lx3), (e.pack_x3(l, 1), g.rx3)]
+            recvs = [(e.recv_buffer(l, 1), g.rx3), (e.recv_buffer(l, 0), g.lx3)]
+            sides = [0, 1]
+        else:
+            if g.lx3 >= 0:
+                sends.append((e.pack_x3(l, 0), g.lx3)); recvs.append((e.recv_buffer(l, 0), g.lx3)); sides.append(0)
+            if g.rx3 >= 0:
+                sends.append((e.pack_x3(l, 1), g.rx3)); recvs.append((e.recv_buffer(l, 1), g.rx3)); sides.append(1)
+        self._p2p(sends, recvs)
+        for side in sides:
+            e.unpack_x3(l, side)
+
+    def bvals_mhd(self, l: int):
+        if self.has(l):
+            self.eng.bvals_local(l)
+        self.exchange_x3(l)
+
+    # ---- level coupling ------------------------------------------------------------------------
+    def restrict_correct(self):
+        """smr.c:1207: finest pair first; a parent plane that lies across a cut from the child's
+        boundary is corrected by the rank that owns it, with the child's restricted flux as message."""
+        for l in range(self.NL - 2, -1, -1):
+            if self.has(l + 1):
+                self.eng.restrict_correct_pair(l)
+            if not self.distributed:
+                continue
+            sends, recvs, todo = [], [], []
+            if self.has(l + 1):
+                for side, peer in enumerate(self.cfg.links[l].corr_to):
+                    if peer >= 0:
+                        sends.append((self.eng.flux_x3_export(l + 1, side), peer))
+            for (lp, side, src, i0, j0, n1, n2) in self.cfg.corr_in:
+                if lp == l:
+                    buf = self.eng.flux_buffer(n1, n2)
+                    recvs.append((buf, src)); todo.append((side, i0, j0, n1, n2, buf))
+            self._p2p(sends, recvs)
+            for side, i0, j0, n1, n2, buf in todo:
+                self.eng.flux_x3_apply(l, side, i0, j0, n1, n2, buf)
+
+    # ---- time step -------------------------------------------------------------------------------
+    def new_dt(self):
+        """new_dt.c:32 over all levels: max(|v|+a) per level (MAX over its slabs), carried from level to
+        level (:33), one dt for the Mesh."""
+        v = []
+        for l in range(self.NL):
+            v += self.eng.cfl_max_v(l) if self.has(l) else [0.0, 0.0, 0.0]
+        if self.distributed:
+            v = self._allreduce(v, self.dist.ReduceOp.MAX)
+        cum, max_dti = [0.0, 0.0, 0.0], 0.0
+        for l in range(self.NL):
+            for d in range(3):
+                cum[d] = cum[d] if cum[d] > v[3 * l + d] else v[3 * l + d]
+            for d in range(3):
+                q = cum[d] / (self.run.dx[d] / float(1 << l))
+                max_dti = max_dti if max_dti > q else q
+        dtc = self.run.cour_no / max_dti
+        self.dt = dtc if self.nstep == 0 else min(2.0 * self.dt, dtc)
+        if self.time < self.run.tlim and (self.run.tlim - self.time) < self.dt:
+            self.dt = self.run.tlim - self.time
+        for l in range(self.NL):
+            self.dtl[l] = self.dt
+            if self.has(l):
+                self.eng.set_level_state(l, self.time, self.dt, self.nstep)
+
+    # ---- radiation ---------------------------------------------------------------------------------
+    def ion_radtransfer(self, l: int) -> int:
+        """ionrad_3d.c:862 on level l (all ranks take part in the reductions, with neutral values where
+        the level is absent)."""
+        e, has = self.eng, self.has(l)
+        fine = l != 0
+        INF = float("inf")
+        if fine:
+            if has:
+                e.ionflux_prolong(l)
+        else:
+            self.tcoarse = 0.0
+        if has:
+            e.set_level_state(l, self.time, self.dtl[l], self.nstep)
+            e.ion_begin(l)
+        dt_done, niter, hydro_done, coarse_done = 0.0, 0, False, False
+        while fine or not hydro_done:
+            dt_chem, dt_therm = e.ion_rates(l) if has else (INF, INF)
+            if self.distributed:
+                dt_chem, dt_therm = self._allreduce((dt_chem, dt_therm), self.dist.ReduceOp.MIN)
+            dt = min(dt_therm, dt_chem)
+            if not fine:
+                if dt_done + dt > self.dtl[0]:
+                    dt = self.dtl[0] - dt_done; hydro_done = True
+            elif dt_done + dt > self.tcoarse:
+                dt = self.tcoarse - dt_done; coarse_done = True
+            cellcount, dt_hydro = e.ion_update(l, dt) if has else (0, INF)
+            if self.distributed and not fine:
+                t = self._allreduce((float(cellcount),), self.dist.ReduceOp.SUM)
+                h = self._allreduce((dt_hydro,), self.dist.ReduceOp.MIN)
+                cellcount, dt_hydro = int(t[0]), h[0]
+            dt_done += dt
+            niter += 1
+            if not fine:
+                if cellcount > MAXCELLCOUNT:
+                    self.dtl[0] = dt_done; break
+                if hydro_done:
+                    break
+                if dt_hydro < dt_done:
+                    self.dtl[0] = dt_done; break
+            elif coarse_done:
+                self.dtl[l] = dt_done; break
+        if not fine:
+            if niter == self.run.maxiter:
+                self.dtl[0] = dt_done
+            self.tcoarse = dt_done
+        self.dt = self.dtl[l]                                   # ionrad_3d.c:1030 pMesh->dt = pGrid->dt
+        if has:
+            e.set_level_state(l, self.time, self.dtl[l], self.nstep)
+        return niter
+
+    # ---- main.c ----------------------------------------------------------------------------------------
+    def start(self):
+        for l in range(self.nl):
+            self.eng.set_level_state(l, self.time, 0.0, self.nstep)
+        self.restrict_correct()
+        for l in range(self.NL):
+            self.bvals_mhd(l)
+            if self.has(l):
+                self.eng.bvals_ionrad(l)
+        self.eng.prolongate()
+        self.new_dt()
+        return self
+
+    def step(self) -> List[int]:
+        niter = [0] * self.NL
+        if self.eng.has_radiation():                              # main.c:546-562
+            for l in range(self.NL):
+                niter[l] = self.ion_radtransfer(l)
+                self.bvals_mhd(l)
+            self.eng.ion_restrict_correct()
+        for l in range(self.nl):                                  # :572-585
+            self.eng.set_level_state(l, self.time, self.dtl[l], self.nstep)
+            self.eng.integrate(l)
+        self.restrict_correct()                                   # :591
+        for l in range(self.nl):                                  # :597
+            self.eng.userwork(l)
+        self.nstep += 1
+        self.time += self.dt                                      # :618-626
+        self.new_dt()                                             # :629
+        for l in range(self.NL):                                  # :635-644
+            self.bvals_mhd(l)
+        self.eng.prolongate()                                     # :647
+        self.niter_trace.append(niter)
+        return niter

@@ -95,9 +95,12 @@ def load(strict: bool | None = None) -> C.CDLL:
         "aa_halo_doubles": (LL, [P]), "aa_pack_x3": (I, [P, I, P]), "aa_unpack_x3": (I, [P, I, P]),
         "aa_mesh_create": (I, [I, C.POINTER(P), ip, C.POINTER(P)]), "aa_mesh_destroy": (None, [P]),
         "aa_mesh_get_state": (I, [P, dp, dp, ip]), "aa_mesh_set_state": (I, [P, D, D, I]),
+        "aa_mesh_set_stream": (I, [P, P]), "aa_mesh_restrict_correct_pair": (I, [P, I]),
         "aa_mesh_restrict_correct": (I, [P]), "aa_mesh_ionrad_restrict_correct": (I, [P]),
         "aa_mesh_prolongate": (I, [P]), "aa_mesh_new_dt": (I, [P]), "aa_mesh_ion_radtransfer": (I, [P, I, ip]),
         "aa_mesh_start": (I, [P]), "aa_mesh_step": (I, [P, ip]),
+        "aa_mesh_ionflux_prolong": (I, [P, I]), "aa_mesh_create_local": (I, [I, C.POINTER(P), ip, C.POINTER(P)]),
+        "aa_flux_x3_export": (I, [P, I, P]), "aa_flux_x3_apply": (I, [P, I, I, I, I, I, P]), "aa_cfl_max_v": (I, [P, dp]),
         "aa_test_fluxes": (I, [I, D, I, dp, dp, dp, dp]),
         "aa_test_lr_states": (I, [I, D, I, dp, D, D, I, I, dp, dp]),
         "aa_history": (I, [P, dp]),
@@ -269,6 +272,14 @@ class Grid:
         c = C.c_longlong(); h = C.c_double()
         self._chk(self.L.aa_ion_update(self._h, dt, C.byref(c), C.byref(h))); return c.value, h.value
 
+    def cfl_max_v(self):
+        v = (C.c_double * 3)(); self._chk(self.L.aa_cfl_max_v(self._h, v)); return list(v)
+
+    def flux_x3_export(self, side: int, dev_ptr: int): self._chk(self.L.aa_flux_x3_export(self._h, side, C.c_void_p(dev_ptr)))
+
+    def flux_x3_apply(self, side: int, i0: int, j0: int, n1: int, n2: int, dev_ptr: int):
+        self._chk(self.L.aa_flux_x3_apply(self._h, side, i0, j0, n1, n2, C.c_void_p(dev_ptr)))
+
     def halo_doubles(self) -> int: return int(self.L.aa_halo_doubles(self._h))
     def pack_x3(self, side: int, dev_ptr: int): self._chk(self.L.aa_pack_x3(self._h, side, C.c_void_p(dev_ptr)))
     def unpack_x3(self, side: int, dev_ptr: int): self._chk(self.L.aa_unpack_x3(self._h, side, C.c_void_p(dev_ptr)))
@@ -330,15 +341,21 @@ class Mesh:
     names follow the reference: RestrictCorrect, Prolongate (smr.c), new_dt, and the per-level
     ion_radtransfer_3d with its coarse -> fine EdgeFlux hand-off (ionrad_smr.c)."""
 
-    def __init__(self, grids, device: int = 0, strict: bool | None = None):
+    def __init__(self, grids, device: int = 0, strict: bool | None = None, links=None):
+        """links: config.LinkConfig list for one rank's stack of slabs (multi-GPU SMR); None = the whole Mesh."""
         self.lev = [setup_problem(g, device, strict) for g in grids]
         self.L = self.lev[0].L
         n = len(grids)
         hs = (C.c_void_p * n)(*[g._h for g in self.lev])
-        disp = (C.c_int * (3 * n))(*[g.disp[d] if g.level else 0 for g in grids for d in range(3)])
         h = C.c_void_p()
         self._h = None
-        self._chk(self.L.aa_mesh_create(n, hs, disp, C.byref(h)))
+        if links is None:
+            disp = (C.c_int * (3 * n))(*[g.disp[d] if g.level else 0 for g in grids for d in range(3)])
+            self._chk(self.L.aa_mesh_create(n, hs, disp, C.byref(h)))
+        else:
+            flat = [v for L_ in links for v in (*L_.cs, *L_.n, *L_.prol, *L_.corr, *L_.cdisp)]
+            arr = (C.c_int * max(1, len(flat)))(*flat)
+            self._chk(self.L.aa_mesh_create_local(n, hs, arr, C.byref(h)))
         self._h = h
 
     def _chk(self, rc: int):
@@ -366,13 +383,17 @@ class Mesh:
     dt = property(lambda s: s.state()[1])
     nstep = property(lambda s: s.state()[2])
 
+    def set_stream(self, stream_ptr: int): self._chk(self.L.aa_mesh_set_stream(self._h, C.c_void_p(stream_ptr)))
     def RestrictCorrect(self): self._chk(self.L.aa_mesh_restrict_correct(self._h))
+    def restrict_correct_pair(self, l: int): self._chk(self.L.aa_mesh_restrict_correct_pair(self._h, l))
     def ionradRestrictCorrect(self): self._chk(self.L.aa_mesh_ionrad_restrict_correct(self._h))
     def Prolongate(self): self._chk(self.L.aa_mesh_prolongate(self._h))
     def new_dt(self): self._chk(self.L.aa_mesh_new_dt(self._h))
 
     def ion_radtransfer_3d(self, level: int) -> int:
         n = C.c_int(); self._chk(self.L.aa_mesh_ion_radtransfer(self._h, level, C.byref(n))); return n.value
+
+    def ionflux_prolong(self, level: int): self._chk(self.L.aa_mesh_ionflux_prolong(self._h, level))
 
     def start(self):
         self._chk(self.L.aa_mesh_start(self._h)); return self

@@ -116,14 +116,31 @@ int  aa_mesh_create(int nlevels, aa_grid **levels, const int *disp, aa_mesh **ou
 void aa_mesh_destroy(aa_mesh *m);
 int  aa_mesh_get_state(const aa_mesh *m, double *time, double *dt, int *nstep);     /* MeshS          */
 int  aa_mesh_set_state(aa_mesh *m, double time, double dt, int nstep);
+int  aa_mesh_set_stream(aa_mesh *m, void *hip_stream);
 int  aa_mesh_restrict_correct(aa_mesh *m);        /* smr.c:1207 RestrictCorrect                      */
+int  aa_mesh_restrict_correct_pair(aa_mesh *m, int l); /* its step for one pair: level l+1 -> level l  */
 int  aa_mesh_ionrad_restrict_correct(aa_mesh *m); /* smr.c:85 ionradRestrictCorrect                  */
 int  aa_mesh_prolongate(aa_mesh *m);              /* smr.c:2359 Prolongate                           */
 int  aa_mesh_new_dt(aa_mesh *m);                  /* new_dt.c:32 over all levels                     */
 int  aa_mesh_ion_radtransfer(aa_mesh *m, int level, int *niter); /* ionrad_3d.c:862 on Domain[level],
                                                      incl. ionrad_prolong_rcv/_snd (ionrad_smr.c)   */
+int  aa_mesh_ionflux_prolong(aa_mesh *m, int level); /* ionrad_prolong_snd(level-1) + _rcv(level) alone    */
 int  aa_mesh_start(aa_mesh *m);                   /* main.c:395-447                                  */
 int  aa_mesh_step(aa_mesh *m, int *niter);        /* one pass of main.c:519-669; niter[nlevels]      */
+
+/* Multi-GPU SMR: every level is cut into x3 slabs at the SAME root planes, so that restriction, the
+ * radiation hand-off and prolongation stay inside a rank.  aa_mesh_create_local builds one rank's stack
+ * of slabs from explicit links (21 ints per link l: cs[3] = first parent zone under the child slab as a
+ * local index incl. ghosts, n[3] parent zones, prol[6] = that side of the child slab is a fine/coarse
+ * boundary of the LEVEL, corr[6] = the parent zone outside that side is on this rank, cdisp[3] = child
+ * origin - 2 x parent origin).  Where a level ends exactly at a cut (prol=1, corr=0 on an x3 side) the
+ * parent plane outside belongs to the neighbouring rank: the child's restricted boundary flux travels
+ * as a message of (Nx1/2)(Nx2/2) x 6 doubles (smr.c:1592-1640 is the same message under MPI).        */
+int  aa_mesh_create_local(int nlevels, aa_grid **levels, const int *links, aa_mesh **out);
+int  aa_flux_x3_export(aa_grid *child, int side, double *dev_buf);   /* side 0 lower / 1 upper boundary */
+int  aa_flux_x3_apply(aa_grid *parent, int side, int i0, int j0, int n1, int n2, const double *dev_buf);
+int  aa_cfl_max_v(aa_grid *g, double v[3]);       /* new_dt.c:72-140 of one Grid (the MAX over the slabs of
+                                                     a level and the carry from level to level are the driver's) */
 
 /* ---- function-level kernels on device arrays' host mirrors (parity tests): n states of
  *      nvar = 5+nscal doubles each, same conventions as fluxes()/lr_states()              */

@@ -1084,10 +1084,14 @@ int orc_step(OrcSim *s)
 struct OrcMesh {
   int nl;
   OrcSim *lev[ORC_MAXLEV];
-  int disp[ORC_MAXLEV][3];   /* DomainS.Disp, in zones of its own level (init_mesh.c:252-267)   */
   /* overlap of level l+1 on level l in level-l indices (init_grid.c: CGrid.ijks/ijke) */
   int cs[ORC_MAXLEV][3], ce[ORC_MAXLEV][3];
-  int side[ORC_MAXLEV][6];   /* level l+1 has a fine/coarse boundary on this side (myFlx != NULL) */
+  int prol[ORC_MAXLEV][6];   /* level l+1 has a fine/coarse boundary on this side (myFlx != NULL): its ghost
+                                zones there are prolonged ...                                          */
+  int corr[ORC_MAXLEV][6];   /* ... and the parent zone outside is flux-corrected here (0 when that zone
+                                belongs to another slab of the parent: orc_flux_x3_export/_apply)       */
+  int cdisp[ORC_MAXLEV][3];  /* origin of level l+1 minus twice the origin of level l, in zones of level
+                                l+1 (= DomainS.Disp of the child when the parent is not displaced)       */
   Real *ionflx[ORC_MAXLEV];  /* CGrid.ionFlx[0] of level l: (n3+1) x (n2+1)                     */
   Cons *box[ORC_MAXLEV];     /* Prolongate: level-l zones around child l+1, taken at "send" time */
   Cons *rU[ORC_MAXLEV];      /* RestrictCorrect: restricted solution of level l+1 (send_bufRC)   */
@@ -1098,7 +1102,8 @@ struct OrcMesh {
 
 static Cons *cz(size_t n) { return (Cons*)calloc(n ? n : 1, sizeof(Cons)); }
 
-OrcMesh *orc_mesh_create(int nlevels, const OrcParams *p, const int *disp)
+/* links[21*l ..]: cs[3] (local parent index incl. ghosts), n[3], prol[6], corr[6], cdisp[3] of level l+1 on level l */
+OrcMesh *orc_mesh_create_local(int nlevels, const OrcParams *p, const int *links)
 {
   OrcMesh *m; int l, d;
   if (nlevels < 1 || nlevels > ORC_MAXLEV) return NULL;
@@ -1107,34 +1112,13 @@ OrcMesh *orc_mesh_create(int nlevels, const OrcParams *p, const int *disp)
   for (l = 0; l < nlevels; l++) {
     OrcSim *s = orc_create(&p[l]);
     s->level = l;
-    for (d = 0; d < 3; d++) {
-      s->dx[d] = s->rootdx[d]/(Real)(1 << l);                       /* init_mesh.c:245 */
-      m->disp[l][d] = disp[3*l + d];
-    }
+    for (d = 0; d < 3; d++) s->dx[d] = s->rootdx[d]/(Real)(1 << l);                       /* init_mesh.c:245 */
     m->lev[l] = s;
   }
   for (l = 0; l + 1 < nlevels; l++) {
-    const OrcSim *P = m->lev[l], *Cc = m->lev[l+1];
-    const int lo[3] = {P->is, P->js, P->ks};
-    int n[3], irefine = 1 << (l+1);
-    for (d = 0; d < 3; d++) {
-      /* init_grid.c: G3 = child extent/2 clipped to this Grid; the child must be nested */
-      int a = m->disp[l+1][d]/2 - m->disp[l][d], b = (m->disp[l+1][d] + Cc->p.Nx[d])/2 - m->disp[l][d];
-      if ((m->disp[l+1][d] & 1) || (Cc->p.Nx[d] & 1) || a < 0 || b > P->p.Nx[d]) {
-        fprintf(stderr, "[orc_mesh_create]: level %d is not nested in level %d along x%d\n", l+1, l, d+1);
-        return NULL;
-      }
-      m->cs[l][d] = a + lo[d]; m->ce[l][d] = b + lo[d] - 1;
-      n[d] = b - a;
-      m->side[l][2*d]   = (m->disp[l+1][d] != 0);
-      m->side[l][2*d+1] = ((m->disp[l+1][d] + Cc->p.Nx[d])/irefine != Cc->p.rootNx[d]);
-    }
-    /* ionrad_smr.c:97-98 mixes an index local to the parent Grid with the child's root-relative Disp:
-     * only meaningful while the parent is not displaced across the rays */
-    if (p[0].ion && (m->disp[l][1] || m->disp[l][2])) {
-      fprintf(stderr, "[orc_mesh_create]: radiation across a displaced parent (level %d) is undefined in the reference\n", l);
-      return NULL;
-    }
+    const int *L = links + 21*l; int n[3];
+    for (d = 0; d < 3; d++) { m->cs[l][d] = L[d]; n[d] = L[3+d]; m->ce[l][d] = L[d] + n[d] - 1; m->cdisp[l][d] = L[18+d]; }
+    for (d = 0; d < 6; d++) { m->prol[l][d] = L[6+d]; m->corr[l][d] = L[12+d]; }
     m->ionflx[l] = (Real*)calloc((size_t)(n[2]+1)*(n[1]+1), sizeof(Real));
     m->box[l] = cz((size_t)(n[0]+6)*(n[1]+6)*(n[2]+6));
     m->rU[l] = cz((size_t)n[0]*n[1]*n[2]);
@@ -1144,6 +1128,34 @@ OrcMesh *orc_mesh_create(int nlevels, const OrcParams *p, const int *disp)
     }
   }
   return m;
+}
+
+OrcMesh *orc_mesh_create(int nlevels, const OrcParams *p, const int *disp)
+{
+  int links[21*ORC_MAXLEV], l, d;
+  if (nlevels < 1 || nlevels > ORC_MAXLEV) return NULL;
+  for (l = 0; l + 1 < nlevels; l++) {
+    int *L = links + 21*l, irefine = 1 << (l+1);
+    const int *dp = disp + 3*l, *dc = disp + 3*(l+1);
+    for (d = 0; d < 3; d++) {
+      /* init_grid.c: G3 = child extent/2 clipped to this Grid; the child must be nested */
+      int a = dc[d]/2 - dp[d], b = (dc[d] + p[l+1].Nx[d])/2 - dp[d];
+      if ((dc[d] & 1) || (p[l+1].Nx[d] & 1) || a < 0 || b > p[l].Nx[d]) {
+        fprintf(stderr, "[orc_mesh_create]: level %d is not nested in level %d along x%d\n", l+1, l, d+1);
+        return NULL;
+      }
+      L[d] = a + NGHOST; L[3+d] = b - a; L[18+d] = dc[d];
+      L[6+2*d]   = L[12+2*d]   = (dc[d] != 0);
+      L[6+2*d+1] = L[12+2*d+1] = ((dc[d] + p[l+1].Nx[d])/irefine != p[l+1].rootNx[d]);
+    }
+    /* ionrad_smr.c:97-98 mixes an index local to the parent Grid with the child's root-relative Disp:
+     * only meaningful while the parent is not displaced across the rays */
+    if (p[0].ion && (dp[1] || dp[2])) {
+      fprintf(stderr, "[orc_mesh_create]: radiation across a displaced parent (level %d) is undefined in the reference\n", l);
+      return NULL;
+    }
+  }
+  return orc_mesh_create_local(nlevels, p, links);
 }
 
 void orc_mesh_destroy(OrcMesh *m)
@@ -1200,61 +1212,64 @@ static Cons restrict_flux(const OrcSim *F, int dir, int nidx, int slow, int fast
   return r;
 }
 
-/* smr.c:1207 RestrictCorrect.  first != 0: the call before the first step (main.c:401), when all
- * myFlx arrays are still zero and the flux correction vanishes. */
-static void restrict_correct(OrcMesh *m, int first)
+/* One level pair of smr.c:1207 RestrictCorrect: Step 3 of level l+1 (restrict its solution and its
+ * boundary fluxes, :1391-1640) followed by Steps 1-2 of level l (inject, :1256-1269; flux-correct the
+ * zones just outside, :1277-1340).  RestrictCorrect is this for l = nl-2 ... 0. */
+static void restrict_correct_pair(OrcMesh *m, int l)
 {
-  int l, i, j, k, n, dim;
-  for (l = m->nl - 1; l >= 0; l--) {
-    OrcSim *G = m->lev[l];
-    const size_t str[3] = {1, (size_t)G->N[0], (size_t)G->N[0]*G->N[1]};
-    /* Steps 1-2: this level takes the restricted solution and fluxes of its child */
-    if (l + 1 < m->nl) {
-      const int *cs = m->cs[l], *ce = m->ce[l];
-      const int nn[3] = {ce[0]-cs[0]+1, ce[1]-cs[1]+1, ce[2]-cs[2]+1};
-      const Cons *r = m->rU[l];
-      for (k = cs[2]; k <= ce[2]; k++) for (j = cs[1]; j <= ce[1]; j++) for (i = cs[0]; i <= ce[0]; i++)
-        G->U[IDX(G,k,j,i)] = *r++;                                              /* Step 1b :1256-1269 */
-      if (!first) for (dim = 0; dim < 6; dim++) {                                /* Step 2a :1277-1340 */
-        const int d = dim/2, d1 = (d == 0) ? 1 : 0, d2 = (d == 2) ? 1 : 2;       /* fast, slow */
-        Real q; int a, b, idx[3];
-        if (!m->side[l][dim]) continue;
-        if (dim & 1) { idx[d] = ce[d]+1; q =  (G->dt/G->dx[d]); }
-        else         { idx[d] = cs[d]-1; q = -(G->dt/G->dx[d]); }
-        for (b = 0; b < nn[d2]; b++) for (a = 0; a < nn[d1]; a++) {
-          size_t mc, mf; Real *u; const Real *mine, *fine;
-          idx[d1] = cs[d1] + a; idx[d2] = cs[d2] + b;
-          mc = IDX(G, idx[2], idx[1], idx[0]);
-          /* this level's own flux through the shared face (Step 12e of the integrator, :3072) */
-          idx[d] = (dim & 1) ? ce[d]+1 : cs[d];
-          mf = IDX(G, idx[2], idx[1], idx[0]);
-          idx[d] = (dim & 1) ? ce[d]+1 : cs[d]-1;
-          u = (Real*)&G->U[mc]; mine = (const Real*)&G->F[d][mf];
-          fine = (const Real*)&m->rF[l][dim][(size_t)b*nn[d1] + a];
-          for (n = 0; n < 6; n++) u[n] -= q*(mine[n] - fine[n]);
-        }
-      }
-      (void)str;
+  OrcSim *G = m->lev[l]; const OrcSim *F = m->lev[l+1];
+  const int *cs = m->cs[l], *ce = m->ce[l];
+  const int nn[3] = {ce[0]-cs[0]+1, ce[1]-cs[1]+1, ce[2]-cs[2]+1};
+  int i, j, k, n, dim;
+  {
+    Cons *r = m->rU[l];
+    for (k = F->ks; k <= F->ke; k += 2) for (j = F->js; j <= F->je; j += 2) for (i = F->is; i <= F->ie; i += 2)
+      *r++ = restrict_zone(F, i, j, k);
+    for (dim = 0; dim < 6; dim++) {
+      const int d = dim/2;
+      Cons *rf = m->rF[l][dim];
+      if (!m->prol[l][dim]) continue;
+      if (d == 0) { const int ii = (dim & 1) ? F->ie+1 : F->is;
+        for (k = F->ks; k <= F->ke; k += 2) for (j = F->js; j <= F->je; j += 2) *rf++ = restrict_flux(F, 0, ii, k, j); }
+      if (d == 1) { const int jj = (dim & 1) ? F->je+1 : F->js;
+        for (k = F->ks; k <= F->ke; k += 2) for (i = F->is; i <= F->ie; i += 2) *rf++ = restrict_flux(F, 1, jj, k, i); }
+      if (d == 2) { const int kk = (dim & 1) ? F->ke+1 : F->ks;
+        for (j = F->js; j <= F->je; j += 2) for (i = F->is; i <= F->ie; i += 2) *rf++ = restrict_flux(F, 2, kk, j, i); }
     }
-    /* Step 3: restrict this level for its parent */
-    if (l > 0) {
-      const OrcSim *F = G;
-      Cons *r = m->rU[l-1];
-      for (k = F->ks; k <= F->ke; k += 2) for (j = F->js; j <= F->je; j += 2) for (i = F->is; i <= F->ie; i += 2)
-        *r++ = restrict_zone(F, i, j, k);
-      for (dim = 0; dim < 6; dim++) {
-        const int d = dim/2;
-        Cons *rf = m->rF[l-1][dim];
-        if (!m->side[l-1][dim]) continue;
-        if (d == 0) { const int ii = (dim & 1) ? F->ie+1 : F->is;
-          for (k = F->ks; k <= F->ke; k += 2) for (j = F->js; j <= F->je; j += 2) *rf++ = restrict_flux(F, 0, ii, k, j); }
-        if (d == 1) { const int jj = (dim & 1) ? F->je+1 : F->js;
-          for (k = F->ks; k <= F->ke; k += 2) for (i = F->is; i <= F->ie; i += 2) *rf++ = restrict_flux(F, 1, jj, k, i); }
-        if (d == 2) { const int kk = (dim & 1) ? F->ke+1 : F->ks;
-          for (j = F->js; j <= F->je; j += 2) for (i = F->is; i <= F->ie; i += 2) *rf++ = restrict_flux(F, 2, kk, j, i); }
+  }
+  {
+    const Cons *r = m->rU[l];
+    for (k = cs[2]; k <= ce[2]; k++) for (j = cs[1]; j <= ce[1]; j++) for (i = cs[0]; i <= ce[0]; i++)
+      G->U[IDX(G,k,j,i)] = *r++;
+    for (dim = 0; dim < 6; dim++) {
+      const int d = dim/2, d1 = (d == 0) ? 1 : 0, d2 = (d == 2) ? 1 : 2;       /* fast, slow */
+      Real q; int a, b, idx[3];
+      if (!m->corr[l][dim]) continue;
+      if (dim & 1) { idx[d] = ce[d]+1; q =  (G->dt/G->dx[d]); }
+      else         { idx[d] = cs[d]-1; q = -(G->dt/G->dx[d]); }
+      for (b = 0; b < nn[d2]; b++) for (a = 0; a < nn[d1]; a++) {
+        size_t mc, mf; Real *u; const Real *mine, *fine;
+        idx[d1] = cs[d1] + a; idx[d2] = cs[d2] + b;
+        mc = IDX(G, idx[2], idx[1], idx[0]);
+        /* this level's own flux through the shared face (Step 12e of the integrator, :3072) */
+        idx[d] = (dim & 1) ? ce[d]+1 : cs[d];
+        mf = IDX(G, idx[2], idx[1], idx[0]);
+        idx[d] = (dim & 1) ? ce[d]+1 : cs[d]-1;
+        u = (Real*)&G->U[mc]; mine = (const Real*)&G->F[d][mf];
+        fine = (const Real*)&m->rF[l][dim][(size_t)b*nn[d1] + a];
+        for (n = 0; n < 6; n++) u[n] -= q*(mine[n] - fine[n]);
       }
     }
   }
+}
+
+/* smr.c:1207.  (Before the first step, main.c:401, all fluxes are still zero and dt = 0: the
+ * correction adds q*(0-0).) */
+static void restrict_correct(OrcMesh *m, int first)
+{
+  int l;
+  (void)first;
+  for (l = m->nl - 2; l >= 0; l--) restrict_correct_pair(m, l);
 }
 
 /* smr.c:85 ionradRestrictCorrect: E and s[0] only, after the radiation step */
@@ -1346,7 +1361,7 @@ static void prolongate(OrcMesh *m)
 #define BOX(kc,jc,ic) box[((size_t)(kc)*bn1 + (jc))*bn0 + (ic)]
       for (dim = 0; dim < 6; dim++) {
         int ps[3], pe[3], d;
-        if (!m->side[l-1][dim]) continue;
+        if (!m->prol[l-1][dim]) continue;
         for (d = 0; d < 3; d++) { ps[d] = lo[d] - NGHOST; pe[d] = hi[d] + NGHOST; }
         if (dim & 1) ps[dim/2] = hi[dim/2] + 1; else pe[dim/2] = lo[dim/2] - 1;
         for (k = ps[2]; k <= pe[2]; k += 2) for (j = ps[1]; j <= pe[1]; j += 2) for (i = ps[0]; i <= pe[0]; i += 2) {
@@ -1370,7 +1385,7 @@ static void prolongate(OrcMesh *m)
 static void ionrad_prolong_snd(OrcMesh *m, int l)
 {
   const OrcSim *G; const int *cs, *ce; int j, k, n0, n1, fixed, w;
-  if (l + 1 >= m->nl || !m->side[l][0]) return;
+  if (l + 1 >= m->nl || !m->prol[l][0]) return;
   G = m->lev[l]; cs = m->cs[l]; ce = m->ce[l];
   n0 = G->p.Nx[0]+1; n1 = G->p.Nx[1]+1;
   fixed = cs[0] - NGHOST; w = ce[1] - cs[1] + 2;
@@ -1383,7 +1398,7 @@ static void ionrad_prolong_rcv(OrcMesh *m, int l)
 {
   OrcSim *G = m->lev[l]; const int *cs, *ce; int j, k, n0, n1, w;
   const int fixed = 0;      /* (PGrid.ijks[0] - nghost)*2 with the child nested: ijks[0] = is */
-  if (l == 0 || !m->side[l-1][0]) return;
+  if (l == 0 || !m->prol[l-1][0]) return;
   cs = m->cs[l-1]; ce = m->ce[l-1];
   n0 = G->p.Nx[0]+1; n1 = G->p.Nx[1]+1; w = ce[1] - cs[1] + 2;
 #define EF(kk,jj) G->EdgeFlux[((size_t)(kk)*n1 + (jj))*n0 + fixed]
@@ -1391,7 +1406,7 @@ static void ionrad_prolong_rcv(OrcMesh *m, int l)
     const Real v = m->ionflx[l-1][(size_t)(k-(cs[2]-NGHOST))*w + j-(cs[1]-NGHOST)];
     /* fine index of coarse ray (j,k): coarse active index is relative to the PARENT Grid, Disp of the
      * child is relative to the root, both in the reference (ionrad_smr.c:97-98) */
-    const int ks = k*2 - m->disp[l][2], js = j*2 - m->disp[l][1];
+    const int ks = k*2 - m->cdisp[l-1][2], js = j*2 - m->cdisp[l-1][1];
     EF(ks,js) = v;
     if (j < ce[1]+1 - NGHOST) {
       if (k < ce[2]+1 - NGHOST) { EF(ks+1,js+1) = v; EF(ks,js+1) = v; EF(ks+1,js) = v; }
@@ -1451,6 +1466,40 @@ static void mesh_new_dt(OrcMesh *m)
   if (m->nstep == 0) m->dt = dtc; else m->dt = MINR(2.0*m->dt, dtc);
   if ((m->time < p->tlim) && ((p->tlim - m->time) < m->dt)) m->dt = p->tlim - m->time;
   for (l = 0; l < m->nl; l++) m->lev[l]->dt = m->dt;
+}
+
+/* ---- pieces for a driver that cuts every level into x3 slabs (one OrcMesh per slab stack) ---- */
+void orc_mesh_restrict_correct(OrcMesh *m) { restrict_correct(m, 0); }
+void orc_mesh_restrict_correct_pair(OrcMesh *m, int l) { restrict_correct_pair(m, l); }
+void orc_mesh_ion_restrict_correct(OrcMesh *m) { ion_restrict_correct(m); }
+void orc_mesh_prolongate(OrcMesh *m) { prolongate(m); }
+void orc_mesh_ionflux_prolong(OrcMesh *m, int l) { ionrad_prolong_snd(m, l-1); ionrad_prolong_rcv(m, l); }
+void orc_cfl_max_v(OrcSim *s, double v[3])
+{ Real dti = 0.0; v[0] = v[1] = v[2] = 0.0; cfl_accumulate(s, v, &dti); }
+
+/* restricted x3-flux of a child slab at its lower (side 0) / upper (side 1) boundary, [j/2][i/2][6]:
+ * what RestrictCorrect sends to the parent (smr.c:1592-1640) when the parent plane outside the
+ * boundary lives on another slab */
+void orc_flux_x3_export(OrcSim *c, int side, double *buf)
+{
+  int i, j; Cons *out = (Cons*)buf;
+  const int kk = side ? c->ke+1 : c->ks;
+  for (j = c->js; j <= c->je; j += 2) for (i = c->is; i <= c->ie; i += 2) *out++ = restrict_flux(c, 2, kk, j, i);
+}
+
+/* the matching correction on the parent slab (smr.c:1322-1340): side 0 = the child's LOWER boundary
+ * coincides with this slab's upper edge (plane ke, face ke+1), side 1 = its upper boundary with this
+ * slab's lower edge (plane ks, face ks); (i0,j0) = first parent zone under the child, n1 x n2 zones */
+void orc_flux_x3_apply(OrcSim *p, int side, int i0, int j0, int n1, int n2, const double *buf)
+{
+  const Cons *fine = (const Cons*)buf; int a, b, n;
+  const int kc = side ? p->ks : p->ke, kf = side ? p->ks : p->ke+1;
+  const Real q = side ? (p->dt/p->dx[2]) : -(p->dt/p->dx[2]);
+  for (b = 0; b < n2; b++) for (a = 0; a < n1; a++, fine++) {
+    Real *u = (Real*)&p->U[IDX(p, kc, j0+b, i0+a)];
+    const Real *mine = (const Real*)&p->F[2][IDX(p, kf, j0+b, i0+a)];
+    for (n = 0; n < 6; n++) u[n] -= q*(mine[n] - ((const Real*)fine)[n]);
+  }
 }
 
 /* main.c:395-447: after problem() ran on every level */

@@ -91,6 +91,19 @@ void     orc_mesh_destroy(OrcMesh *m);
 OrcSim  *orc_mesh_level(OrcMesh *m, int l);
 void     orc_mesh_start(OrcMesh *m);               /* main.c:395-447 */
 void     orc_mesh_step(OrcMesh *m, int *niter);    /* main.c:519-669; niter[nlevels] */
+/* pieces for drivers that cut every level into x3 slabs (tests of the multi-GPU SMR driver): a local
+ * stack of slabs with explicit links (21 ints per link: cs[3] local parent index incl. ghosts, n[3],
+ * prol[6], corr[6], cdisp[3]), the inter-level operations one by one, and the flux correction of a
+ * parent plane that lies on another slab */
+OrcMesh *orc_mesh_create_local(int nlevels, const OrcParams *p, const int *links);
+void     orc_mesh_restrict_correct(OrcMesh *m);
+void     orc_mesh_restrict_correct_pair(OrcMesh *m, int l);  /* level l+1 -> level l only */
+void     orc_mesh_ion_restrict_correct(OrcMesh *m);
+void     orc_mesh_prolongate(OrcMesh *m);
+void     orc_mesh_ionflux_prolong(OrcMesh *m, int l);       /* ionrad_prolong_snd(l-1) + _rcv(l) */
+void     orc_cfl_max_v(OrcSim *s, double v[3]);             /* new_dt.c:72-140, this Grid only  */
+void     orc_flux_x3_export(OrcSim *child, int side, double *buf);
+void     orc_flux_x3_apply(OrcSim *parent, int side, int i0, int j0, int n1, int n2, const double *buf);
 double   orc_mesh_time(const OrcMesh *m);
 double   orc_mesh_dt(const OrcMesh *m);
 int      orc_mesh_nstep(const OrcMesh *m);

@@ -79,6 +79,14 @@ def lib():
         L.orc_mesh_time.restype = D; L.orc_mesh_time.argtypes = [P]
         L.orc_mesh_dt.restype = D; L.orc_mesh_dt.argtypes = [P]
         L.orc_mesh_nstep.restype = C.c_int; L.orc_mesh_nstep.argtypes = [P]
+        L.orc_mesh_create_local.restype = P; L.orc_mesh_create_local.argtypes = [C.c_int, C.POINTER(OrcParams), C.POINTER(C.c_int)]
+        for f in ("orc_mesh_restrict_correct", "orc_mesh_ion_restrict_correct", "orc_mesh_prolongate"):
+            getattr(L, f).argtypes = [P]; getattr(L, f).restype = None
+        L.orc_mesh_restrict_correct_pair.argtypes = [P, C.c_int]; L.orc_mesh_restrict_correct_pair.restype = None
+        L.orc_mesh_ionflux_prolong.argtypes = [P, C.c_int]; L.orc_mesh_ionflux_prolong.restype = None
+        L.orc_cfl_max_v.argtypes = [P, dp]; L.orc_cfl_max_v.restype = None
+        L.orc_flux_x3_export.argtypes = [P, C.c_int, dp]; L.orc_flux_x3_export.restype = None
+        L.orc_flux_x3_apply.argtypes = [P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, dp]; L.orc_flux_x3_apply.restype = None
         L.orc_cons_to_prim.argtypes = [C.c_int, C.c_int, D, dp, dp]
         L.orc_cfast.argtypes = [C.c_int, C.c_int, D, dp, dp]
         L.orc_fluxes.argtypes = [C.c_int, C.c_int, D, dp, dp, dp, dp]
@@ -174,6 +182,18 @@ class Sim:
         return a.value, b.value
 
     def ion_update(self, dt): self.L.orc_ion_update(self.h, dt)
+
+    def cfl_max_v(self):
+        v = np.zeros(3); self.L.orc_cfl_max_v(self.h, _dp(v)); return list(v)
+
+    def flux_x3_export(self, side):
+        buf = np.zeros((self.grid.Nx[1] // 2, self.grid.Nx[0] // 2, 6))
+        self.L.orc_flux_x3_export(self.h, side, _dp(buf)); return buf
+
+    def flux_x3_apply(self, side, i0, j0, n1, n2, buf):
+        buf = np.ascontiguousarray(buf, dtype=np.float64)
+        self.L.orc_flux_x3_apply(self.h, side, i0, j0, n1, n2, _dp(buf))
+
     def ion_check_range_count(self): return self.L.orc_ion_check_range_count(self.h)
     def ion_dt_hydro(self): return self.L.orc_ion_dt_hydro(self.h)
 
@@ -188,12 +208,17 @@ def make_sim(problem, overrides=None, rank=0, nranks=1, integrator="ctu"):
 class Mesh:
     """Nested static-mesh-refinement levels (one Domain per level) on the oracle."""
 
-    def __init__(self, grids):
+    def __init__(self, grids, links=None):
+        """links: config.LinkConfig list for one rank's stack of slabs; None = the whole Mesh."""
         self.L = lib()
         n = len(grids)
         pa = (OrcParams * n)(*[params_from_grid(g) for g in grids])
-        da = (C.c_int * (3 * n))(*[g.disp[d] if g.level else 0 for g in grids for d in range(3)])
-        self.h = self.L.orc_mesh_create(n, pa, da)
+        if links is None:
+            da = (C.c_int * (3 * n))(*[g.disp[d] if g.level else 0 for g in grids for d in range(3)])
+            self.h = self.L.orc_mesh_create(n, pa, da)
+        else:
+            flat = [v for L_ in links for v in (*L_.cs, *L_.n, *L_.prol, *L_.corr, *L_.cdisp)]
+            self.h = self.L.orc_mesh_create_local(n, pa, (C.c_int * max(1, len(flat)))(*flat))
         if not self.h:
             raise ValueError("orc_mesh_create failed (levels not nested?)")
         self.lev = [Sim(g, handle=self.L.orc_mesh_level(self.h, l)) for l, g in enumerate(grids)]
@@ -212,6 +237,11 @@ class Mesh:
 
     def start(self):
         self.L.orc_mesh_start(self.h); return self
+
+    def restrict_correct_pair(self, l): self.L.orc_mesh_restrict_correct_pair(self.h, l)
+    def ion_restrict_correct(self): self.L.orc_mesh_ion_restrict_correct(self.h)
+    def prolongate(self): self.L.orc_mesh_prolongate(self.h)
+    def ionflux_prolong(self, l): self.L.orc_mesh_ionflux_prolong(self.h, l)
 
     def step(self):
         it = (C.c_int * len(self.lev))()

@@ -1,0 +1,173 @@
+"""Static mesh refinement over several ranks (driver.MeshDriver) on CPU: world_size 2 and 3 over gloo,
+with the oracle as the per-rank engine (test infrastructure), against the single-process oracle
+Mesh that is pinned to the reference's SMR build.  Every level is cut at the same root planes; the
+cases put cuts inside the refined levels, exactly on a level's boundary (the flux correction of the
+parent plane then crosses ranks) and leave some ranks without the finest level.  All reductions are
+MIN/MAX or integer sums and every zone sees the same operands, so position-independent problems must
+come out bit for bit."""
+import importlib
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.dirname(HERE))
+
+
+class OracleMeshEngine:
+    """Engine protocol of driver.MeshDriver on top of oracle/liborc.so (test infrastructure)."""
+
+    def __init__(self, cfg):
+        import torch
+        import orc
+        self.torch = torch
+        self.cfg = cfg
+        self.mesh = orc.Mesh(cfg.levels, links=cfg.links).problem()
+        self.lev = self.mesh.lev
+        self.recv = []
+        for s in self.lev:
+            nv = 5 + s.grid.run.nscal
+            self.recv.append([torch.empty(s.N[0] * s.N[1] * 4 * nv, dtype=torch.float64) for _ in range(2)])
+
+    nlev = property(lambda s: len(s.lev))
+
+    def bvals_local(self, l): self.lev[l].bvals()
+    def bvals_ionrad(self, l): self.lev[l].bvals_ionrad()
+    def integrate(self, l): self.lev[l].integrate()
+    def userwork(self, l): self.lev[l].userwork()
+    def ion_begin(self, l): self.lev[l].ion_begin()
+    def ion_rates(self, l): return self.lev[l].ion_rates()
+
+    def ion_update(self, l, dt):
+        s = self.lev[l]
+        s.ion_update(dt)
+        return (s.ion_check_range_count(), s.ion_dt_hydro()) if l == 0 else (0, float("inf"))
+
+    def set_level_state(self, l, time, dt, nstep):
+        s = self.lev[l]; s.time = time; s.dt = dt; s.nstep = nstep
+
+    def cfl_max_v(self, l): return self.lev[l].cfl_max_v()
+    def has_radiation(self): return bool(self.cfg.levels[0].run.ion)
+
+    def pack_x3(self, l, side):
+        s = self.lev[l]; nv = 5 + s.grid.run.nscal
+        k0 = 4 if side == 0 else s.N[2] - 8
+        blk = s.U[k0:k0 + 4, :, :, :nv]
+        return self.torch.from_numpy(np.ascontiguousarray(blk.transpose(3, 0, 1, 2)).reshape(-1).copy())
+
+    def recv_buffer(self, l, side): return self.recv[l][side]
+
+    def unpack_x3(self, l, side):
+        s = self.lev[l]; nv = 5 + s.grid.run.nscal
+        k0 = 0 if side == 0 else s.N[2] - 4
+        a = self.recv[l][side].numpy().reshape(nv, 4, s.N[1], s.N[0])
+        s.U[k0:k0 + 4, :, :, :nv] = a.transpose(1, 2, 3, 0)
+
+    def restrict_correct_pair(self, l): self.mesh.restrict_correct_pair(l)
+    def ion_restrict_correct(self): self.mesh.ion_restrict_correct()
+    def prolongate(self): self.mesh.prolongate()
+    def ionflux_prolong(self, l): self.mesh.ionflux_prolong(l)
+    def flux_buffer(self, n1, n2): return self.torch.empty(n1 * n2 * 6, dtype=self.torch.float64)
+    def flux_x3_export(self, l, side): return self.torch.from_numpy(self.lev[l].flux_x3_export(side).reshape(-1).copy())
+    def flux_x3_apply(self, l, side, i0, j0, n1, n2, t): self.lev[l].flux_x3_apply(side, i0, j0, n1, n2, t.numpy())
+    def download(self, l): return self.lev[l].U.copy()
+
+
+def _worker(rank, world, port, problem, overrides, cuts, nsteps, q):
+    import torch.distributed as dist
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    aa = importlib.import_module("atmospheric-athena_amd")
+    driver = importlib.import_module("atmospheric-athena_amd.driver")
+    import orc
+    par = aa.athinput.ParTable.from_file(os.path.join(orc.DECKS, "athinput." + problem)).cmdline(overrides)
+    run = aa.config.from_par(par, problem)
+    d = driver.MeshDriver(par, run, OracleMeshEngine, rank, world, cuts=cuts)
+    d.start()
+    its = [d.step() for _ in range(nsteps)]
+    out = [(g.level, g.disp[2], g.Nx[2], d.eng.download(l)[4:-4, 4:-4, 4:-4].copy(), d.eng.lev[l].edgeflux.copy())
+           for l, g in enumerate(d.cfg.levels)]
+    q.put((rank, out, its, d.time, d.dt, len(d.cfg.corr_in), sum(p >= 0 for L in d.cfg.links for p in L.corr_to)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def run_ranks(problem, overrides, cuts, nsteps, world):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ps = [ctx.Process(target=_worker, args=(r, world, port, problem, overrides, cuts, nsteps, q)) for r in range(world)]
+    for p in ps:
+        p.start()
+    res = [q.get(timeout=600) for _ in range(world)]
+    for p in ps:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    return sorted(res, key=lambda r: r[0])
+
+
+def dom(n, nx, disp=None):
+    o = [f"domain{n}/Nx{d + 1}={nx[d]}" for d in range(3)]
+    if disp:
+        o += [f"domain{n}/{k}Disp={disp[d]}" for d, k in enumerate("ijk")]
+    return o
+
+
+BLAST3 = ["job/num_domains=3"] + dom(1, (16, 24, 16)) + dom(2, (12, 16, 20), (8, 20, 6)) + dom(3, (12, 8, 16), (20, 48, 16))
+# level 1 starts exactly at root plane 4 and ends at plane 12: with cuts there the flux correction crosses ranks
+BLAST_ALIGNED = ["job/num_domains=2"] + dom(1, (12, 12, 16)) + dom(2, (12, 12, 16), (6, 6, 8))
+IFRONT2 = ["job/num_domains=2"] + dom(1, (16, 8, 16)) + dom(2, (16, 8, 16), (8, 4, 8))
+
+CASES = [
+    ("blast", BLAST3, None, 4, 2),                 # cut inside levels 1 and 2
+    ("blast", BLAST3, (0, 6, 10, 16), 3, 3),       # rank 2 has no level 2
+    ("blast", BLAST_ALIGNED, (0, 4, 12, 16), 4, 3),   # level 1 = exactly rank 1's planes: both x3 corrections are remote
+    ("blast", BLAST_ALIGNED, (0, 4, 16), 3, 2),    # lower boundary on the cut, upper one inside rank 1
+    ("ifront", IFRONT2, None, 3, 2),               # radiation: coarse->fine EdgeFlux hand-off per rank, sub-cycle reductions
+    ("ifront", IFRONT2, (0, 4, 9, 16), 2, 3),      # rank 0 holds no refined zones: neutral values in the fine-level reductions
+]
+
+
+@pytest.mark.parametrize("problem,overrides,cuts,nsteps,world", CASES)
+def test_slab_stacks_equal_single_mesh(problem, overrides, cuts, nsteps, world):
+    import orc
+    ref = orc.make_mesh(problem, None, overrides).start()
+    its_ref = [ref.step() for _ in range(nsteps)]
+    res = run_ranks(problem, overrides, cuts, nsteps, world)
+    nv = 5 + ref.lev[0].grid.run.nscal
+    seen = [0] * len(ref.lev)
+    for rank, out, its, t, dt, n_in, n_out in res:
+        assert its == its_ref, f"rank {rank}: sub-cycle counts"
+        assert t == ref.time and dt == ref.dt
+        for level, k0, n3, U, ef in out:
+            g = ref.lev[level].grid
+            off = k0 - (g.disp[2] if level else 0)
+            assert np.array_equal(U[..., :nv], ref.lev[level].active[off:off + n3, :, :, :nv], equal_nan=True), \
+                f"rank {rank} level {level}"
+            if ref.lev[0].grid.run.ion:
+                assert np.array_equal(ef[:n3], ref.lev[level].edgeflux[off:off + n3]), f"EdgeFlux rank {rank} level {level}"
+            seen[level] += n3
+    assert seen == [s.grid.Nx[2] for s in ref.lev]
+    if overrides is BLAST_ALIGNED:
+        assert sum(r[5] for r in res) > 0 and sum(r[5] for r in res) == sum(r[6] for r in res), "remote flux corrections expected"
+
+
+def test_mesh_slab_geometry():
+    aa = importlib.import_module("atmospheric-athena_amd")
+    import orc
+    par = aa.athinput.ParTable.from_file(os.path.join(orc.DECKS, "athinput.blast")).cmdline(BLAST_ALIGNED)
+    run = aa.config.from_par(par, "blast")
+    cfgs = [aa.config.mesh_slabs(par, run, r, 3, (0, 4, 12, 16)) for r in range(3)]
+    assert [len(c.levels) for c in cfgs] == [1, 2, 1]
+    assert cfgs[1].links[0].corr_to == (0, 2) and cfgs[1].links[0].prol == (1, 1, 1, 1, 1, 1)
+    assert cfgs[1].links[0].corr == (1, 1, 1, 1, 0, 0)
+    assert [(c[0], c[1], c[2]) for c in cfgs[0].corr_in] == [(0, 0, 1)] and [(c[0], c[1], c[2]) for c in cfgs[2].corr_in] == [(0, 1, 1)]
+    # balanced cuts put more planes where there is no refinement
+    cuts = aa.config.balanced_cuts(aa.config.levels(par, run), 2)
+    assert cuts[0] == 0 and cuts[-1] == 16 and 4 <= cuts[1] <= 12
+    with pytest.raises(aa.athinput.ParError):
+        aa.config.mesh_slabs(par, run, 0, 3, (0, 5, 6, 16))      # a 1-plane slab
