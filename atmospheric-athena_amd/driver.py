@@ -340,7 +340,8 @@ class MeshDriver:
         self.time, self.dt, self.nstep = 0.0, 0.0, 0
         self.dtl = [0.0] * self.NL                        # pGrid->dt of every level
         self.tcoarse = 0.0
-        self.distributed = nranks > 1
+        # AA_FORCE_DISTRIBUTED=1: issue the collectives even on one rank (rehearsal of the N>1 path)
+        self.distributed = nranks > 1 or bool(os.environ.get("AA_FORCE_DISTRIBUTED"))
         if self.distributed:
             assert dist.is_initialized() and dist.get_world_size() == nranks and dist.get_rank() == rank
         self._sdev = getattr(self.eng, "scalar_device", torch.device("cpu"))

@@ -71,54 +71,81 @@ def cpu_baseline(nx=64, nlim=40):
             "sample": f"ioniz_sphere {nx}^3, {nlim} steps, sub-cycles/step {its}, {wall:.1f} s wall"}
 
 
-def bench_smr(a, aa, torch):
-    """2-level nested mesh on one GPU: every step runs the radiation step on both levels (the fine one
-    sub-cycles to the time the root covered), ionradRestrictCorrect, both integrators, RestrictCorrect,
-    new_dt over both levels and Prolongate (main.c:519-669 with STATIC_MESH_REFINEMENT)."""
-    if a.gpus != 1:
-        sys.exit("--smr: the nested levels live on one GPU (multi-GPU SMR is not built)")
+def bench_smr(a, aa, torch, rank, world, local):
+    """2-level nested mesh: every step runs the radiation step on both levels (the fine one sub-cycles
+    to the time the root covered), ionradRestrictCorrect, both integrators, RestrictCorrect, new_dt over
+    both levels and Prolongate (main.c:519-669 with STATIC_MESH_REFINEMENT).  One GPU: the whole Mesh in
+    one aa_mesh.  N GPUs (weak scaling): root nx x nx x nx*N with level 1 over its central half, every
+    level cut at the same root planes (driver.MeshDriver)."""
     nx = a.nx if a.nx != 512 else 320
     if nx % 4:
         sys.exit("--smr: nx must be a multiple of 4")
     deck = os.path.join(ROOT, PKG, "decks", "athinput." + a.problem)
     par = aa.athinput.ParTable.from_file(deck)
-    par.cmdline(["job/num_domains=2"] + [f"domain1/Nx{d}={nx}" for d in (1, 2, 3)] + [f"domain2/Nx{d}={nx}" for d in (1, 2, 3)]
-                + [f"domain2/{k}Disp={nx // 2}" for k in "ijk"])
+    x3min, x3max = par.getd("domain1", "x3min"), par.getd("domain1", "x3max")
+    par.cmdline(["job/num_domains=2", f"domain1/Nx1={nx}", f"domain1/Nx2={nx}", f"domain1/Nx3={nx * world}",
+                 f"domain1/x3max={x3min + (x3max - x3min) * world!r}",
+                 f"domain2/Nx1={nx}", f"domain2/Nx2={nx}", f"domain2/Nx3={nx * world}",
+                 f"domain2/iDisp={nx // 2}", f"domain2/jDisp={nx // 2}", f"domain2/kDisp={nx * world // 2}"])
     run = aa.config.from_par(par, a.problem)
     run.integrator = a.integrator
     t_setup = time.time()
-    m = importlib.import_module(PKG + ".lib").Mesh(aa.config.levels(par, run), 0).start()
+    multi = world > 1 or bool(os.environ.get("AA_FORCE_DISTRIBUTED"))
+    if multi:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29511")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        m = importlib.import_module(PKG + ".driver").MeshDriver(par, run, None, rank, world, local).start()
+        grids = m.eng.lev
+    else:
+        m = importlib.import_module(PKG + ".lib").Mesh(aa.config.levels(par, run), local).start()
+        grids = m.lev
     torch.cuda.synchronize()
     t_setup = time.time() - t_setup
+
+    def barrier():
+        if multi:
+            dist.barrier()
+        torch.cuda.synchronize()
+
     trace = []
     for _ in range(a.warmup):
         m.step()
-    for g in m.lev:
+    for g in grids:
         g.profile_reset(); g.profile_enable(not a.no_kernel_times)
-    for g in m.lev:
-        g.sync()
+    barrier()
     t0 = time.perf_counter()
     for _ in range(a.steps):
         trace.append(m.step())
-    for g in m.lev:
-        g.sync()
+    barrier()
     elapsed = time.perf_counter() - t0
-    zones = 2 * nx ** 3
-    out = {"metric": "cell-updates/sec (hydro+ion-rad step)", "value": zones * a.steps / elapsed, "unit": "cell-updates/s",
-           "n_gpus": 1, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * elapsed / a.steps,
-           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
-           "data": "synthetic (deck values on a nested 2-level mesh, generated in place)",
-           "config": {"workload": f"{a.problem} 2-level SMR: root {nx}^3 + level 1 {nx}^3 at Disp {nx // 2} (zones of both levels counted, "
-                                  "as the reference's zone-cycles do)", "zones": zones, "subcycle_trace_per_level": trace,
-                      "final_dt": m.dt, "hbm_resident_GB": sum(g.device_bytes() for g in m.lev) / 1e9, "setup_s": t_setup}}
-    if not a.no_kernel_times:
-        prof = {}
-        for l, g in enumerate(m.lev):
-            for k, (ms, n) in g.profile().items():
-                prof[f"L{l}.{k}"] = ms / a.steps
-        out["kernel_ms_per_step"] = dict(sorted(prof.items(), key=lambda kv: -kv[1]))
-    print(json.dumps(out))
-    m.close()
+    if multi:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    zones = 2 * nx ** 3 * world
+    if rank == 0:
+        out = {"metric": "cell-updates/sec (hydro+ion-rad step)", "value": zones * a.steps / elapsed, "unit": "cell-updates/s",
+               "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * elapsed / a.steps,
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+               "data": "synthetic (deck values on a nested 2-level mesh, generated in place)",
+               "config": {"workload": f"{a.problem} 2-level SMR: root {nx}x{nx}x{nx * world} + level 1 {nx}x{nx}x{nx * world} over the "
+                                      "central half (zones of both levels counted, as the reference's zone-cycles do)",
+                          "zones": zones, "partition": (f"x3 cuts {list(m.cfg.cuts)} shared by both levels" if multi else "one aa_mesh"),
+                          "subcycle_trace_per_level": trace, "final_dt": m.dt,
+                          "hbm_resident_GB_rank0": sum(g.device_bytes() for g in grids) / 1e9, "setup_s": t_setup}}
+        if not a.no_kernel_times:
+            prof = {}
+            for l, g in enumerate(grids):
+                for k, (ms, n) in g.profile().items():
+                    prof[f"L{l}.{k}"] = ms / a.steps
+            out["kernel_ms_per_step_rank0"] = dict(sorted(prof.items(), key=lambda kv: -kv[1]))
+        print(json.dumps(out))
+    if multi:
+        dist.barrier()
+        dist.destroy_process_group()
+    else:
+        m.close()
 
 
 def main():
@@ -130,8 +157,8 @@ def main():
     ap.add_argument("--problem", default="ioniz_sphere", choices=["ioniz_sphere", "ifront", "blast"])
     ap.add_argument("--integrator", default="ctu", choices=["ctu", "vl"])
     ap.add_argument("--smr", action="store_true",
-                    help="BASELINE.json configs[4]: 2-level static mesh refinement, root nx^3 + a level-1 Domain of nx^3 "
-                         "zones over the central half (1 GPU; not the headline line)")
+                    help="BASELINE.json configs[4]: 2-level static mesh refinement, per GPU a root slab of nx^3 zones plus "
+                         "nx^3 level-1 zones over the central half of the box (not the headline line)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-times", action="store_true")
     a = ap.parse_args()
@@ -149,7 +176,7 @@ def main():
         sys.exit("bench.py needs an MI355X: the hot path has no CPU fallback")
     torch.cuda.set_device(local)
     if a.smr:
-        return bench_smr(a, aa, torch)
+        return bench_smr(a, aa, torch, rank, world, local)
     force = bool(os.environ.get("AA_FORCE_DISTRIBUTED"))
     if world > 1 or force:
         import torch.distributed as dist
