@@ -70,11 +70,11 @@ int aa_create(const aa_params *p, aa_grid **out)
     d.dx[a] = rootdx[a]/(Real)(1 << p->level);                    // :245
   }
   d.Gamma = p->gamma; d.Gamma_1 = p->gamma - 1.0;
-  // one pool: U 6 | LR 36 | F 18 | eta 3 | dhalf 1 | phi 4 | ion 6 + sign(1) | edgeflux
+  // one pool: U 6 | LR 36 | F 18 | eta 3 | dhalf 1 | phi 4 | ion 5 + sign(1) | edgeflux
   const size_t nc = (size_t)d.nc;
   const size_t nef = (size_t)(d.Nx1 + 1)*(d.Nx2 + 1)*(d.Nx3 + 1);
   size_t n = nc*(6 + 36 + 18 + 3 + 1 + 4);
-  if (p->ion) n += nc*7 + nef;
+  if (p->ion) n += nc*6 + nef;
   g->pool_doubles = n;
   hipError_t e = hipMalloc(&g->pool, n*sizeof(Real));
   if (e != hipSuccess) { delete g; return fail(-2, "[aa_create]: hipMalloc of %.2f GB failed: %s", n*8e-9, hipGetErrorString(e)); }
@@ -85,7 +85,7 @@ int aa_create(const aa_params *p, aa_grid **out)
   d.phi = q; q += 4*nc;
   if (p->ion) {
     d.ph_rate = q; q += nc; d.kin = q; q += nc; d.vmax = q; q += nc;
-    d.e_init = q; q += nc; d.e_th_init = q; q += nc; d.x_init = q; q += nc;
+    d.e_init = q; q += nc; d.x_init = q; q += nc;
     d.sign = (int2*)q; q += nc; d.edgeflux = q; q += nef;
     IonPar &ip = g->ion;
     ip.sigma_ph = p->sigma_ph; ip.m_H = p->m_H; ip.mu = p->mu; ip.e_gamma = p->e_gamma; ip.alpha_C = p->alpha_C;

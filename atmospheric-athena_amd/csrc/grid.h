@@ -12,7 +12,7 @@
 //     eta  : 3*nc   H-correction wave-speed spread per face   (eta1..3, :74)
 //     dhalf: nc                                               (:71)
 //     phi  : 4*nc   static potential at cell centres and at the lower x1/x2/x3 faces
-//   ion module (ionrad_3d.c:33-50): ph_rate, e_init, e_th_init, x_init, plus ke and max|v|/dx frozen
+//   ion module (ionrad_3d.c:33-50): ph_rate, e_init, x_init, plus ke and max|v|/dx frozen (e_th_init = e_init - ke is re-derived)
 //   at the start of the ion step (the reference's edot/nHdot arrays are recomputed, not stored),
 //   last_sign/sign_count packed in one int2 array; EdgeFlux [Nx3+1][Nx2+1][Nx1+1].
 #pragma once
@@ -33,7 +33,7 @@ struct DevGrid {
   Real *U, *LR, *F, *eta, *dhalf;
   Real *phi;                      // null when StaticGravPot == NULL; [0]=centre, [1+d]=lower face d
   // ion
-  Real *ph_rate, *kin, *vmax, *e_init, *e_th_init, *x_init;   // kin (kinetic energy), vmax: frozen during the ion step
+  Real *ph_rate, *kin, *vmax, *e_init, *x_init;   // kin (kinetic energy), vmax: frozen during the ion step
   int2 *sign;                     // .x = last_sign, .y = sign_count
   Real *edgeflux;
   int Nx1, Nx2, Nx3;

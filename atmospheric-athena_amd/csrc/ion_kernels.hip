@@ -132,7 +132,6 @@ k_ion_begin(DevGrid g, IonPar p)
   if (c.s != s0) Uq(g,5)[m] = c.s;
   IonQ q = ion_q(c, p, g.Gamma_1);
   g.e_init[m] = c.E;
-  g.e_th_init[m] = q.e_th;
   g.x_init[m] = q.x;
   g.sign[m] = make_int2(0, 0);
   g.kin[m] = c.ke;
@@ -355,7 +354,8 @@ k_ion_update(DevGrid g, IonPar p, Real dt, DevScalars *sc)
       bool counted = false;
       const bool dtype = (q.n_H > 0.0) ? (ph > 2.0*CION*p.min_area*q.n_H) : (ph / (p.min_area * q.n_H) > 2.0*CION);
       if (!dtype) {
-        const Real eth0 = g.e_th_init[m], e0 = g.e_init[m];
+        // e_th_init (ionrad_3d.c:176) = e_init - ke with ke frozen over the ion step: not stored
+        const Real e0 = g.e_init[m], eth0 = e0 - c.ke;
         const Real L1 = 1 + p.max_de_therm_step, L2 = 1 + p.max_de_step, L3 = 1 + p.max_dx_step;
         if (ratio_ge(q.e_th, eth0, L1) || ratio_ge(eth0, q.e_th, L1)) counted = true;
         else if ((p.max_de_step > 0) && (ratio_ge(c.E, e0, L2) || ratio_ge(e0, c.E, L2))) counted = true;

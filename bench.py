@@ -36,7 +36,7 @@ KERNEL_BYTES = {
     "vl_flux1": 8 * (6 + 18), "vl_uhalf": 8 * (6 + 18 + 6), "vl_flux2_x1": 8 * 12, "vl_flux2_x2": 8 * 12,
     "vl_flux2_x3": 8 * 12, "flux2_x1": 8 * (12 + 3 + 6), "flux2_x2": 8 * (12 + 3 + 6),
     "flux2_x3": 8 * (12 + 3 + 6), "update": 8 * (6 + 18 + 6),
-    "ray_sweep": 8 * (1 + 2), "ion_rates": 8 * (5 + 1), "ion_update": 8 * (5 + 1 + 3 + 0.5 + 2),
+    "ray_sweep": 8 * (1 + 2), "ion_rates": 8 * (5 + 1), "ion_update": 8 * (5 + 1 + 2 + 0.5 + 2),
     "ion_begin": 8 * (6 + 6), "bvals_mhd": 0, "new_dt": 8 * 5, "pinned_cells": 0,
 }
 
@@ -159,6 +159,8 @@ def main():
     ap.add_argument("--smr", action="store_true",
                     help="BASELINE.json configs[4]: 2-level static mesh refinement, per GPU a root slab of nx^3 zones plus "
                          "nx^3 level-1 zones over the central half of the box (not the headline line)")
+    ap.add_argument("--ionized-slab", action="store_true",
+                    help="SURVEY 8(d) worst case for the ray sweep: neutral fraction 1e-4 everywhere, so every ray crosses the whole box")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-times", action="store_true")
     a = ap.parse_args()
@@ -194,6 +196,12 @@ def main():
     run.integrator = a.integrator
     t_setup = time.time()
     drv = driver.Driver(run, None, rank, world, local)
+    if a.ionized_slab:
+        if not run.ion:
+            sys.exit("--ionized-slab needs a problem with ion radiation")
+        U = drv.eng.g.host_initial
+        U[..., 5] = 1.0e-4 * U[..., 0]
+        drv.eng.g.upload(U)
     drv.start()
     eng = drv.eng
     torch.cuda.synchronize()
@@ -232,7 +240,8 @@ def main():
             "metric": "cell-updates/sec (hydro+ion-rad step)", "value": value, "unit": "cell-updates/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * elapsed / a.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
-            "data": "synthetic (ioniz_sphere deck values on a uniform grid, generated in place)",
+            "data": "synthetic (deck values on a uniform grid, generated in place"
+                    + ("; neutral fraction reset to 1e-4 everywhere: fully ionized slab" if a.ionized_slab else "") + ")",
             "config": {"workload": f"{a.problem} {nx}x{nx}x{nx * world} single level, "
                                    + ("CTU+PLM+Roe+H-correction" if a.integrator == "ctu" else "VL+PLM+Roe")
                                    + (" + static gravity + plane-parallel ion radiation" if a.problem == "ioniz_sphere"
