@@ -30,6 +30,7 @@ PROBLEMS = {
     "ifront": (True, 1),
     "ioniz_sphere": (True, 1),
     "blast": (False, 0),
+    "shkset1d": (False, 0),      # tst/1D-hydro/athinput.sod run as a slab of a 3-D box
 }
 
 

@@ -147,3 +147,28 @@ int aa_problem_blast(const aa_params *p, double radius, double pamb, double damb
   }
   return 0;
 }
+
+/* ---- shock tube along x1, x2 or x3 (prob/shkset1d.c:41-215); wl, wr = {d, P, v1, v2, v3} ------- */
+int aa_problem_shkset1d(const aa_params *p, const double *wl, const double *wr, int shk_dir, double *U)
+{
+  const double Gamma_1 = p->gamma - 1.0;
+  const int N1 = p->Nx[0] + 2*NG, N2 = p->Nx[1] + 2*NG, N3 = p->Nx[2] + 2*NG;
+  double c[2][5];
+  int i, j, k, side;
+  if (p->nscal != 0 || shk_dir < 1 || shk_dir > 3) return -1;
+  for (side = 0; side < 2; side++) {                     /* Prim1D_to_Cons1D, convert_var.c:432 */
+    const double *w = side ? wr : wl;
+    c[side][0] = w[0]; c[side][1] = w[0]*w[2]; c[side][2] = w[0]*w[3]; c[side][3] = w[0]*w[4];
+    c[side][4] = w[1]/Gamma_1 + 0.5*w[0]*(SQR(w[2]) + SQR(w[3]) + SQR(w[4]));
+  }
+  for (k = 0; k < N3; k++) for (j = 0; j < N2; j++) for (i = 0; i < N1; i++) {    /* ghost zones too (:89-108) */
+    double *u = cell(p, U, i, j, k), x[3]; const double *q;
+    centre(p, i, j, k, x);
+    q = (x[shk_dir-1] <= 0.0) ? c[0] : c[1];
+    u[0] = q[0]; u[4] = q[4];
+    if (shk_dir == 1)      { u[1] = q[1]; u[2] = q[2]; u[3] = q[3]; }
+    else if (shk_dir == 2) { u[1] = q[3]; u[2] = q[1]; u[3] = q[2]; }
+    else                   { u[1] = q[2]; u[2] = q[3]; u[3] = q[1]; }
+  }
+  return 0;
+}

@@ -126,6 +126,7 @@ def host() -> C.CDLL:
         H.aa_problem_ifront.argtypes = [pp, D, D, dp]; H.aa_problem_ifront.restype = C.c_int
         H.aa_problem_ioniz_sphere.argtypes = [pp, D, D, D, D, dp]; H.aa_problem_ioniz_sphere.restype = C.c_int
         H.aa_problem_blast.argtypes = [pp, D, D, D, D, D, dp]; H.aa_problem_blast.restype = C.c_int
+        H.aa_problem_shkset1d.argtypes = [pp, dp, dp, C.c_int, dp]; H.aa_problem_shkset1d.restype = C.c_int
         H.aa_planet_pot.argtypes = [D, D, D]; H.aa_planet_pot.restype = D
         H.aa_ioniz_sphere_pinned.argtypes = [pp, C.POINTER(C.c_longlong), dp]
         H.aa_ioniz_sphere_pinned.restype = C.c_longlong
@@ -316,6 +317,10 @@ def setup_problem(grid: GridConfig, device: int = 0, strict: bool | None = None)
     elif r.problem == "blast":
         rc = H.aa_problem_blast(C.byref(g.params), pr["radius"], pr["pamb"], pr.get("damb", 1.0),
                                 pr.get("drat", 1.0), pr["prat"], _dp(U))
+    elif r.problem == "shkset1d":
+        wl = np.array([pr["dl"], pr["pl"], pr["v1l"], pr["v2l"], pr["v3l"]])
+        wr = np.array([pr["dr"], pr["pr"], pr["v1r"], pr["v2r"], pr["v3r"]])
+        rc = H.aa_problem_shkset1d(C.byref(g.params), _dp(wl), _dp(wr), int(pr["shk_dir"]), _dp(U))
     else:
         raise AthenaError(f"unknown problem {r.problem}")
     if rc != 0:

@@ -1604,6 +1604,26 @@ void orc_problem_blast(OrcSim *s, double radius, double pamb, double damb, doubl
   }
 }
 
+void orc_problem_shkset1d(OrcSim *s, const double *wl, const double *wr, int shk_dir)
+{                            /* prob/shkset1d.c:41-215; wl, wr = {d, P, v1, v2, v3} of the two states */
+  int i, j, k, side;
+  C1 c[2];
+  for (side = 0; side < 2; side++) {
+    const double *w = side ? wr : wl; P1 W;
+    W.d = w[0]; W.P = w[1]; W.Vx = w[2]; W.Vy = w[3]; W.Vz = w[4]; W.r = 0.0;
+    c[side] = prim_to_cons(&W, s->Gamma_1, 0);
+  }
+  for (k = 0; k < s->N[2]; k++) for (j = 0; j < s->N[1]; j++) for (i = 0; i < s->N[0]; i++) {   /* ghosts too (:89-108) */
+    Cons *u = &s->U[IDX(s,k,j,i)]; Real x[3]; const C1 *q;
+    cc_pos(s, i, j, k, x);
+    q = (x[shk_dir-1] <= 0.0) ? &c[0] : &c[1];
+    u->d = q->d; u->E = q->E; u->s = 0.0;
+    if (shk_dir == 1)      { u->M[0] = q->Mx; u->M[1] = q->My; u->M[2] = q->Mz; }     /* :121-123 */
+    else if (shk_dir == 2) { u->M[0] = q->Mz; u->M[1] = q->Mx; u->M[2] = q->My; }     /* :159-161 */
+    else                   { u->M[0] = q->My; u->M[1] = q->Mz; u->M[2] = q->Mx; }     /* :197-199 */
+  }
+}
+
 /* ------------------------------------------------------------------------------------ */
 /* lifecycle */
 

@@ -54,12 +54,13 @@ void    orc_set_time(OrcSim *s, double t);
 void    orc_set_dt(OrcSim *s, double dt);
 void    orc_set_nstep(OrcSim *s, int n);
 
-/* problem generators (prob/ifront.c, prob/ioniz_sphere.c, prob/blast.c) */
+/* problem generators (prob/ifront.c, prob/ioniz_sphere.c, prob/blast.c, prob/shkset1d.c) */
 void orc_problem_ifront(OrcSim *s, double n_H, double cs, double flux);
 void orc_problem_ioniz_sphere(OrcSim *s, double n_H, double cs, double flux,
                               double rp, double mp, double np);
 void orc_problem_blast(OrcSim *s, double radius, double pamb, double damb,
                        double drat, double prat);
+void orc_problem_shkset1d(OrcSim *s, const double *wl, const double *wr, int shk_dir); /* {d,P,v1,v2,v3} x 2 */
 void orc_add_radplane(OrcSim *s, int dir, double flux);
 
 /* main.c steps */

@@ -10,7 +10,7 @@ through oracle/_ref/libref_<cfg>.so to produce function-level known-answer vecto
 
 Fixtures are DATA (arrays + the scalar trace of each run); no reference text is stored.
 
-usage: python tests/golden/make_golden.py [whole] [dev] [kernels] [smr] [hst]
+usage: python tests/golden/make_golden.py [whole] [shk] [dev] [kernels] [smr] [hst]
 """
 import ctypes as C
 import os
@@ -122,6 +122,19 @@ def whole_runs():
                                      ["job/num_domains=1", "job/maxout=1", "output1/out_fmt=rst",
                                       "output1/dt=1e300"], "Blast", 0, False)
             save(f"blast_{nx[0]}x{nx[1]}x{nx[2]}_n{nlim}", f, l, it, nx, [])
+
+
+def shock_tubes():
+    """Sod's shock tube (tst/1D-hydro/athinput.sod, BASELINE configs[0]) on 3-D grids, along x1, x2 and
+    x3 (prob/shkset1d.c rotates the state), reference built with the 3-D CTU integrator + H-correction."""
+    sod = os.path.join(REF, "tst/1D-hydro/athinput.sod")
+    for d, nx in ((1, (48, 8, 6)), (2, (6, 48, 8)), (3, (8, 6, 48))):
+        over = [f"problem/shk_dir={d}", "time/cour_no=0.4"]
+        for e in (1, 2, 3):
+            over += [f"domain1/x{e}min=-0.5", f"domain1/x{e}max=0.5"]
+        f, l, it = run_reference("shk3d", sod, nx, 12, ["job/maxout=1", "output1/out_fmt=rst", "output1/out=cons", "output1/dt=1e300"] + over,
+                                 "Sod", 0, False)
+        save(f"shkset1d_d{d}_{nx[0]}x{nx[1]}x{nx[2]}_n12", f, l, it, nx, over)
 
 
 def developed_states():
@@ -330,11 +343,13 @@ def kernel_vectors():
 if __name__ == "__main__":
     if not os.path.isdir(REF) or not os.path.isdir(REFBIN):
         sys.exit("needs /root/reference and oracle/_ref (make -C oracle ref)")
-    which = sys.argv[1:] or ["whole", "dev", "kernels", "smr", "hst"]
+    which = sys.argv[1:] or ["whole", "shk", "dev", "kernels", "smr", "hst"]
     if "hst" in which:
         history_runs()
     if "whole" in which:
         whole_runs()
+    if "shk" in which:
+        shock_tubes()
     if "dev" in which:
         developed_states()
     if "kernels" in which:

@@ -62,6 +62,7 @@ def lib():
         L.orc_problem_ifront.argtypes = [P, D, D, D]
         L.orc_problem_ioniz_sphere.argtypes = [P, D, D, D, D, D, D]
         L.orc_problem_blast.argtypes = [P, D, D, D, D, D]
+        L.orc_problem_shkset1d.argtypes = [P, dp, dp, C.c_int]
         L.orc_add_radplane.argtypes = [P, C.c_int, D]
         for f in ("orc_start", "orc_bvals", "orc_bvals_ionrad", "orc_new_dt", "orc_integrate",
                   "orc_userwork", "orc_ion_begin"):
@@ -152,6 +153,10 @@ class Sim:
         elif r.problem == "blast":
             self.L.orc_problem_blast(self.h, pr["radius"], pr["pamb"], pr.get("damb", 1.0),
                                      pr.get("drat", 1.0), pr["prat"])
+        elif r.problem == "shkset1d":
+            wl = np.array([pr["dl"], pr["pl"], pr["v1l"], pr["v2l"], pr["v3l"]])
+            wr = np.array([pr["dr"], pr["pr"], pr["v1r"], pr["v2r"], pr["v3r"]])
+            self.L.orc_problem_shkset1d(self.h, _dp(wl), _dp(wr), int(pr["shk_dir"]))
         else:
             raise ValueError(r.problem)
         return self

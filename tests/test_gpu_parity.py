@@ -119,6 +119,33 @@ def test_blast_golden_fixture(aa, lib):
 
 
 @pytest.mark.parametrize("strict", [True, False])
+@pytest.mark.parametrize("name", ["shkset1d_d1_48x8x6_n12", "shkset1d_d2_6x48x8_n12", "shkset1d_d3_8x6x48_n12"])
+def test_sod_shock_tube_golden_fixtures(aa, lib, name, strict):
+    """BASELINE configs[0] on the GPU: Sod's shock tube (gamma 1.4, outflow boundaries) along x1, x2
+    and x3 of a 3-D box, against restart dumps of the reference's 3-D CTU + H-correction build."""
+    gz = np.load(os.path.join(GOLD, name + ".npz"))
+    nx = tuple(int(x) for x in gz["nx"])
+    ov = [f"domain1/Nx{d + 1}={nx[d]}" for d in range(3)] + [str(o) for o in gz["overrides"]]
+    run = aa.config.load(os.path.join(orc.DECKS, "athinput.shkset1d"), ov, "shkset1d")
+    g = lib.setup_problem(aa.config.slab(run), 0, strict)
+    assert np.array_equal(g.host_initial[4:-4, 4:-4, 4:-4, :5], gz["U0"][..., :5])
+    g.start()
+    for _ in range(int(gz["nstep"])):
+        g.step()
+    U = g.download()[4:-4, 4:-4, 4:-4, :5]
+    if strict:
+        assert g.time == float(gz["time"]) and g.dt == float(gz["dt"])
+        assert np.array_equal(U, gz["U"][..., :5]), relerr(U, gz["U"][..., :5])
+    else:
+        assert max(relerr(U, gz["U"][..., :5])) < 1e-11      # FMA contraction only
+    # the tube stays uniform across the two transverse directions, bit for bit
+    d = int(name.split("_d")[1][0]) - 1                     # shock direction 0,1,2 -> array axis 2,1,0
+    line = np.moveaxis(U, 2 - d, 0)
+    assert np.array_equal(line, np.broadcast_to(line[:, :1, :1, :], line.shape))
+    g.close()
+
+
+@pytest.mark.parametrize("strict", [True, False])
 @pytest.mark.parametrize("nx,nsteps", [((16, 8, 8), 3), ((8, 12, 16), 4), ((32, 16, 16), 3)])
 def test_ifront_vs_oracle(aa, lib, nx, nsteps, strict):
     """Hydro + ion radiation.  Same sub-cycle counts; fields within 1e-9 of each field's max

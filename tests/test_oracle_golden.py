@@ -47,8 +47,11 @@ def test_whole_run_bitwise(name):
     integrator = "ctu"
     if prob.startswith("vl_"):
         prob, integrator = prob[3:], "vl"
+    if prob.startswith("shkset1d"):
+        prob = "shkset1d"                       # shkset1d_d<dir>_...
     nx = g["nx"]
-    s = orc.make_sim(prob, [f"domain1/Nx{d + 1}={int(nx[d])}" for d in range(3)], integrator=integrator)
+    s = orc.make_sim(prob, [f"domain1/Nx{d + 1}={int(nx[d])}" for d in range(3)] + [str(o) for o in g["overrides"]],
+                     integrator=integrator)
     nv = 5 + s.grid.run.nscal
     assert _same(s.active[..., :nv], g["U0"][..., :nv]), "initial condition"
     s.start()
