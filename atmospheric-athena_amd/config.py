@@ -54,6 +54,9 @@ class RunConfig:
     # README.rst:25 configuration) or "vl" (no H-correction: integrate_2d_vl.c:533 does not compile
     # with it, so that is the only VL build the reference has)
     integrator: str = "ctu"
+    # configure --with-order: 2 = piecewise linear (lr_states_plm.c, the default), 3 = piecewise parabolic
+    # (lr_states_ppm.c); characteristic variables in both cases
+    order: int = 2
 
     @property
     def dx(self) -> Tuple[float, float, float]:

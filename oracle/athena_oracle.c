@@ -238,9 +238,13 @@ static void flux_roe(const C1 *Ul, const C1 *Ur, const P1 *Wl, const P1 *Wr, Rea
 
 static void lr_states_x(const P1 *W, Real dt, Real dx, int il, int iu, P1 *Wl, P1 *Wr,
                         Real Gamma, int nscal, int trace);
+static void lr_states_ppm(const P1 *W, Real dt, Real dx, int il, int iu, P1 *Wl, P1 *Wr, Real Gamma, int nscal);
 static void lr_states(const P1 *W, Real dt, Real dx, int il, int iu, P1 *Wl, P1 *Wr,
-                      Real Gamma, int nscal)
-{ lr_states_x(W, dt, dx, il, iu, Wl, Wr, Gamma, nscal, 1); }
+                      Real Gamma, int nscal, int order)
+{
+  if (order == 3) lr_states_ppm(W, dt, dx, il, iu, Wl, Wr, Gamma, nscal);
+  else lr_states_x(W, dt, dx, il, iu, Wl, Wr, Gamma, nscal, 1);
+}
 
 static void lr_states_x(const P1 *W, Real dt, Real dx, int il, int iu, P1 *Wl, P1 *Wr,
                         Real Gamma, int nscal, int trace)
@@ -343,6 +347,145 @@ static void lr_states_x(const P1 *W, Real dt, Real dx, int il, int iu, P1 *Wl, P
 }
 
 /* ------------------------------------------------------------------------------------ */
+/* reconstruction/lr_states_ppm.c:91-610 (THIRD_ORDER_CHAR, --with-order=3): piecewise parabolic
+ * interpolation with the same characteristic slope limiting as PLM (Steps 1-6 / 8-13 are
+ * lr_states_plm.c:131-202 word for word), parabola monotonisation (CW84 eqn 1.10) and
+ * characteristic tracing (eqn 3.5ff).  Needs W over [il-3, iu+3].
+ *
+ * With passive scalars the reference indexes its work arrays dWm[][] and Wim1h[][] with
+ * n < NWAVE+NSCALARS although lr_states_init allocates NWAVE columns (:689-692), so column
+ * NWAVE of row i IS column 0 of row i+1.  Followed through the loop order, the scalar sees
+ *   left  parabola edge  = the DENSITY interface value W_{i+1/2}[0] just computed,
+ *   right parabola edge  = (r_i + r_{i+1})/2 - (dr_{i+1} - d(rho)_{i+1})/6,
+ * both then clamped between the neighbouring scalar values by Step 16.  Restated as such. */
+#define FOUR_3RDS 1.333333333333333     /* defs.h.in:159 */
+#define TWO_3RDS  0.6666666666666667    /* :158 */
+
+static void limited_slopes(const P1 *W, int i, Real Gamma, int nscal, Real dWm[6])
+{
+  const Real *w = (const Real*)&W[i], *wm = (const Real*)&W[i-1], *wp = (const Real*)&W[i+1];
+  const int nv = NW + nscal; int n;
+  Real d = W[i].d, asq = (Gamma*W[i].P)/d, a = sqrt(asq);
+  Real r10 = -a/d, r14 = -r10, l01 = -0.5*d/a, l04 = 0.5/asq, l14 = -1.0/asq, l41 = -l01;
+  Real dWc[6], dWl[6], dWr[6], dWg[6], dac[6], dal[6], dar[6], dag[6], da[6], lim1, lim2;
+  for (n = 0; n < nv; n++) {
+    dWc[n] = wp[n] - wm[n]; dWl[n] = w[n] - wm[n]; dWr[n] = wp[n] - w[n];
+    dWg[n] = (dWl[n]*dWr[n] > 0.0) ? 2.0*dWl[n]*dWr[n]/(dWl[n]+dWr[n]) : 0.0;
+  }
+#define PROJ(o,x) do { o[0] = l01*x[1]; o[0] += l04*x[4]; o[1] = x[0]; o[1] += l14*x[4]; \
+                       o[2] = x[2]; o[3] = x[3]; o[4] = l41*x[1]; o[4] += l04*x[4]; \
+                       if (nscal) o[5] = x[5]; } while (0)
+  PROJ(dac,dWc); PROJ(dal,dWl); PROJ(dar,dWr); PROJ(dag,dWg);
+#undef PROJ
+  for (n = 0; n < nv; n++) {
+    da[n] = 0.0;
+    if (dal[n]*dar[n] > 0.0) {
+      lim1 = MINR(fabs(dal[n]), fabs(dar[n]));
+      lim2 = MINR(0.5*fabs(dac[n]), fabs(dag[n]));
+      da[n] = ((dac[n] < 0.) ? -1. : 1.)*MINR(2.0*lim1, lim2);
+    }
+  }
+  dWm[0] = da[0]; dWm[0] += da[1]; dWm[0] += da[4];
+  dWm[1] = da[0]*r10; dWm[1] += da[4]*r14;
+  dWm[2] = da[2]; dWm[3] = da[3];
+  dWm[4] = da[0]*asq; dWm[4] += da[4]*asq;
+  dWm[5] = nscal ? da[5] : 0.0;
+}
+
+static void lr_states_ppm(const P1 *W, Real dt, Real dx, int il, int iu, P1 *Wl, P1 *Wr, Real Gamma, int nscal)
+{
+  const Real dtodx = dt/dx;
+  const int nv = NW + nscal;
+  int i, n;
+  for (i = il-1; i <= iu+1; i++) {
+    const Real *w = (const Real*)&W[i], *wm = (const Real*)&W[i-1], *wp = (const Real*)&W[i+1];
+    Real d = W[i].d, vx = W[i].Vx, asq = (Gamma*W[i].P)/d, a = sqrt(asq);
+    Real ev0 = vx - a, ev4 = vx + a;
+    Real r10 = -a/d, r14 = -r10, l01 = -0.5*d/a, l04 = 0.5/asq, l14 = -1.0/asq, l41 = -l01;
+    Real Dm[6], D0[6], Dp[6], Wlv[6], Wrv[6], dW[6], W6[6], *pWl = (Real*)&Wl[i+1], *pWr = (Real*)&Wr[i];
+    Real qa, qb, qc, qx1, qx2, qxx1 = 0.0, qxx2 = 0.0;
+    const Real gamma_curv = 0.0;
+    limited_slopes(W, i-1, Gamma, nscal, Dm); limited_slopes(W, i, Gamma, nscal, D0); limited_slopes(W, i+1, Gamma, nscal, Dp);
+    for (n = 0; n < NW; n++) {                                          /* Steps 7/14 :258-263, :398-408 */
+      Wlv[n] = 0.5*(w[n] + wm[n]) - (D0[n] - Dm[n])/6.0;
+      Wrv[n] = 0.5*(wp[n] + w[n]) - (Dp[n] - D0[n])/6.0;
+    }
+    if (nscal) {                                                        /* the aliased column, see above */
+      Wlv[5] = Wrv[0];
+      Wrv[5] = 0.5*(wp[5] + w[5]) - (Dp[5] - Dp[0])/6.0;
+    }
+    for (n = 0; n < nv; n++) {                                          /* Step 16 :421-446 */
+      qa = (Wrv[n]-w[n])*(w[n]-Wlv[n]);
+      qb = Wrv[n]-Wlv[n];
+      qc = 6.0*(w[n] - 0.5*(Wlv[n]*(1.0-gamma_curv) + Wrv[n]*(1.0+gamma_curv)));
+      if (qa <= 0.0) { Wlv[n] = w[n]; Wrv[n] = w[n]; }
+      else if ((qb*qc) > (qb*qb)) Wlv[n] = (6.0*w[n] - Wrv[n]*(4.0+3.0*gamma_curv))/(2.0-3.0*gamma_curv);
+      else if ((qb*qc) < -(qb*qb)) Wrv[n] = (6.0*w[n] - Wlv[n]*(4.0-3.0*gamma_curv))/(2.0+3.0*gamma_curv);
+    }
+    for (n = 0; n < nv; n++) {
+      Wlv[n] = MAXR(MINR(w[n],wm[n]),Wlv[n]);
+      Wlv[n] = MINR(MAXR(w[n],wm[n]),Wlv[n]);
+      Wrv[n] = MAXR(MINR(w[n],wp[n]),Wrv[n]);
+      Wrv[n] = MINR(MAXR(w[n],wp[n]),Wrv[n]);
+    }
+    for (n = 0; n < nv; n++) {                                          /* Step 17 :451-455 */
+      dW[n] = Wrv[n] - Wlv[n];
+      W6[n] = 6.0*(w[n] - 0.5*(Wlv[n]*(1.0-gamma_curv) + Wrv[n]*(1.0+gamma_curv)));
+    }
+    qx1 = 0.5*MAXR(ev4,0.0)*dtodx;                                      /* Step 18 :461-500 */
+    for (n = 0; n < nv; n++)
+      pWl[n] = Wrv[n] - qx1 *(dW[n] - (1.0-FOUR_3RDS*qx1)*W6[n])
+                      + qxx1*(dW[n] - (1.0-      2.0*qx1)*W6[n]);
+    qx2 = -0.5*MINR(ev0,0.0)*dtodx;
+    for (n = 0; n < nv; n++)
+      pWr[n] = Wlv[n] + qx2 *(dW[n] + (1.0-FOUR_3RDS*qx2)*W6[n])
+                      + qxx2*(dW[n] + (1.0-      2.0*qx2)*W6[n]);
+    if (!nscal) { pWl[5] = 0.0; pWr[5] = 0.0; }
+    /* Step 19 :508-560, sparse form of the loops over the eigenmatrices (wave n=4 / n=0 of the first /
+     * second block have qb = qc = 0 and add exact zeros) */
+#define TERML(m) (qb*(dW[m]-W6[m]) + qc*W6[m])
+#define TERMR(m) (qb*(dW[m]+W6[m]) + qc*W6[m])
+    qx1 = 0.5*dtodx*ev4;
+    if (ev0 >= 0.0) {
+      qx2 = 0.5*dtodx*ev0; qb = qx1 - qx2; qc = FOUR_3RDS*(SQR(qx1) - SQR(qx2));
+      qa = 0.0; qa += l01*TERML(1); qa += l04*TERML(4);
+      pWl[0] += qa; pWl[1] += qa*r10; pWl[4] += qa*asq;
+    }
+    if (vx >= 0.0) {
+      qx2 = 0.5*dtodx*vx; qb = qx1 - qx2; qc = FOUR_3RDS*(SQR(qx1) - SQR(qx2));
+      qa = 0.0; qa += 1.0*TERML(0); qa += l14*TERML(4);  pWl[0] += qa;
+      qa = 0.0; qa += 1.0*TERML(2);                      pWl[2] += qa;
+      qa = 0.0; qa += 1.0*TERML(3);                      pWl[3] += qa;
+    }
+    qx1 = 0.5*dtodx*ev0;
+    if (vx <= 0.0) {
+      qx2 = 0.5*dtodx*vx; qb = qx1 - qx2; qc = FOUR_3RDS*(SQR(qx1) - SQR(qx2));
+      qa = 0.0; qa += 1.0*TERMR(0); qa += l14*TERMR(4);  pWr[0] += qa;
+      qa = 0.0; qa += 1.0*TERMR(2);                      pWr[2] += qa;
+      qa = 0.0; qa += 1.0*TERMR(3);                      pWr[3] += qa;
+    }
+    if (ev4 <= 0.0) {
+      qx2 = 0.5*dtodx*ev4; qb = qx1 - qx2; qc = FOUR_3RDS*(SQR(qx1) - SQR(qx2));
+      qa = 0.0; qa += l41*TERMR(1); qa += l04*TERMR(4);
+      pWr[0] += qa; pWr[1] += qa*r14; pWr[4] += qa*asq;
+    }
+    if (nscal) {                                                        /* :563-575 (dW[m], W6[m] with m = NWAVE) */
+      if (vx > 0.) {
+        qb = 0.5*dtodx*(ev4-vx);
+        qc = 0.5*dtodx*dtodx*TWO_3RDS*(SQR(ev4) - SQR(vx));
+        pWl[5] += qb*(dW[5]-W6[5]) + qc*W6[5];
+      } else if (vx < 0.) {
+        qb = 0.5*dtodx*(ev0-vx);
+        qc = 0.5*dtodx*dtodx*TWO_3RDS*(ev0*ev0 - vx*vx);
+        pWr[5] += qb*(dW[5]+W6[5]) + qc*W6[5];
+      }
+    }
+#undef TERML
+#undef TERMR
+  }
+}
+
+/* ------------------------------------------------------------------------------------ */
 /* static gravitational potential: prob/ioniz_sphere.c:316-330 (PlanetPot, non-shearing-box) */
 
 static Real potential(const OrcSim *s, Real x1, Real x2, Real x3)
@@ -425,7 +568,7 @@ void orc_integrate(OrcSim *s)
         C1 u1 = to_sweep(&s->U[base + c*str[d]], d);
         W[c] = cons_to_prim(&u1, Gamma_1, nscal);
       }
-      lr_states(W, dt, s->dx[d], l[d]+1, u[d]-1, Wl, Wr, Gamma, nscal);
+      lr_states(W, dt, s->dx[d], l[d]+1, u[d]-1, Wl, Wr, Gamma, nscal, s->p.order);
       if (grav) {                                                      /* :318-342 etc. */
         for (c = l[d]+1; c <= u[d]; c++) {
           Real x[3], phicr, phicl, phifc;
@@ -1720,8 +1863,8 @@ void orc_fluxes(int n, int nscal, double gamma, const double *Ul, const double *
   }
 }
 
-void orc_lr_states(int n, int nscal, double gamma, const double *W, double dt, double dx,
-                   int il, int iu, double *Wl, double *Wr)
+static void lr_states_any(int order, int n, int nscal, double gamma, const double *W, double dt, double dx,
+                          int il, int iu, double *Wl, double *Wr)
 {
   int i, nv = NW + nscal;
   P1 *w = (P1*)calloc(n, sizeof(P1)), *wl = (P1*)calloc(n, sizeof(P1)), *wr = (P1*)calloc(n, sizeof(P1));
@@ -1730,10 +1873,16 @@ void orc_lr_states(int n, int nscal, double gamma, const double *W, double dt, d
     memcpy(&wl[i], Wl + (size_t)i*nv, nv*sizeof(double));
     memcpy(&wr[i], Wr + (size_t)i*nv, nv*sizeof(double));
   }
-  lr_states(w, dt, dx, il, iu, wl, wr, gamma, nscal);
+  lr_states(w, dt, dx, il, iu, wl, wr, gamma, nscal, order);
   for (i = 0; i < n; i++) {
     memcpy(Wl + (size_t)i*nv, &wl[i], nv*sizeof(double));
     memcpy(Wr + (size_t)i*nv, &wr[i], nv*sizeof(double));
   }
   free(w); free(wl); free(wr);
 }
+void orc_lr_states(int n, int nscal, double gamma, const double *W, double dt, double dx,
+                   int il, int iu, double *Wl, double *Wr)
+{ lr_states_any(2, n, nscal, gamma, W, dt, dx, il, iu, Wl, Wr); }
+void orc_lr_states_ppm(int n, int nscal, double gamma, const double *W, double dt, double dx,
+                       int il, int iu, double *Wl, double *Wr)
+{ lr_states_any(3, n, nscal, gamma, W, dt, dx, il, iu, Wl, Wr); }

@@ -38,6 +38,8 @@ typedef struct OrcParams {
   double uw_K, uw_Cp, uw_rho0, uw_rreset2;
   int    integrator;   /* 0: CTU + H-correction (README.rst:25); 1: VL, no H-correction (the
                           only VL combination the reference compiles)                  */
+  int    order;        /* 2 (0 = default): PLM, configure --with-order=2; 3: PPM, --with-order=3
+                          (reconstruction/lr_states_ppm.c), CTU integrator only          */
 } OrcParams;
 
 typedef struct OrcSim OrcSim;
@@ -116,6 +118,8 @@ void orc_fluxes(int n, int nscal, double gamma, const double *Ul, const double *
                 const double *eta, double *F);
 void orc_lr_states(int n, int nscal, double gamma, const double *W, double dt, double dx,
                    int il, int iu, double *Wl, double *Wr);
+void orc_lr_states_ppm(int n, int nscal, double gamma, const double *W, double dt, double dx,
+                       int il, int iu, double *Wl, double *Wr);
 
 #ifdef __cplusplus
 }

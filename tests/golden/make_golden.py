@@ -10,7 +10,7 @@ through oracle/_ref/libref_<cfg>.so to produce function-level known-answer vecto
 
 Fixtures are DATA (arrays + the scalar trace of each run); no reference text is stored.
 
-usage: python tests/golden/make_golden.py [whole] [shk] [dev] [kernels] [smr] [hst]
+usage: python tests/golden/make_golden.py [whole] [shk] [dev] [kernels] [ppm] [smr] [hst]
 """
 import ctypes as C
 import os
@@ -135,6 +135,38 @@ def shock_tubes():
         f, l, it = run_reference("shk3d", sod, nx, 12, ["job/maxout=1", "output1/out_fmt=rst", "output1/out=cons", "output1/dt=1e300"] + over,
                                  "Sod", 0, False)
         save(f"shkset1d_d{d}_{nx[0]}x{nx[1]}x{nx[2]}_n12", f, l, it, nx, over)
+
+
+def ppm_runs():
+    """--with-order=3 (piecewise parabolic reconstruction, lr_states_ppm.c): function-level vectors on
+    the pencils of kernels_nscal*.npz through libref_<cfg>_ppm.so, and whole runs."""
+    for cfg, nscal in (("ifront_ppm", 1), ("blast_ppm", 0)):
+        L = C.CDLL(os.path.join(REFBIN, f"libref_{cfg}.so"))
+        k = np.load(os.path.join(HERE, f"kernels_nscal{nscal}.npz"))
+        L.ref_set_gamma.argtypes = [C.c_double]
+        L.ref_set_gamma(float(k["gamma"]))
+        Wp = np.ascontiguousarray(k["Wp"]); m = Wp.shape[0]
+        il, iu = 3, m - 4                                   # needs W over [il-3, iu+3]
+        Wl = np.zeros_like(Wp); Wr = np.zeros_like(Wp)
+        L.ref_lr_states.argtypes = [C.c_int, C.POINTER(C.c_double), C.c_double, C.c_double, C.c_int, C.c_int,
+                                    C.POINTER(C.c_double), C.POINTER(C.c_double)]
+        L.ref_lr_states(m, dp(Wp), float(k["dt"]), float(k["dx"]), il, iu, dp(Wl), dp(Wr))
+        np.savez_compressed(os.path.join(HERE, f"kernels_ppm_nscal{nscal}.npz"), gamma=k["gamma"], Wp=Wp, dt=k["dt"], dx=k["dx"],
+                            il=il, iu=iu, Wl=Wl, Wr=Wr)
+        print(f"kernels_ppm_nscal{nscal}: pencil of {m}")
+    ifront = os.path.join(REF, "tst/ionradiation/athinput.ifront")
+    sphere = os.path.join(REF, "tst/massloss/athinput.ioniz_sphere_hires")
+    blast = os.path.join(REF, "tst/3D-hydro/athinput.blast")
+    f, l, it = run_reference("blast_ppm", blast, (16, 12, 20), 5,
+                             ["job/num_domains=1", "job/maxout=1", "output1/out_fmt=rst", "output1/dt=1e300"], "Blast", 0, False)
+    save("ppm_blast_16x12x20_n5", f, l, it, (16, 12, 20), [])
+    f, l, it = run_reference("ifront_ppm", ifront, (16, 8, 8), 4,
+                             ["job/maxout=3", "output3/out_fmt=rst", "output3/dt=1e300", "output1/dt=1e300", "output2/dt=1e300"],
+                             "ifront", 1, True)
+    save("ppm_ifront_16x8x8_n4", f, l, it, (16, 8, 8), [])
+    f, l, it = run_reference("ioniz_sphere_ppm", sphere, (32, 32, 32), 2,
+                             ["job/num_domains=1", "job/maxout=1", "output1/dt=1e300", "problem/rp=2.1e10"], "ioniz_sphere", 1, True)
+    save("ppm_ioniz_sphere_32x32x32_n2", f, l, it, (32, 32, 32), ["problem/rp=2.1e10"])
 
 
 def developed_states():
@@ -343,11 +375,13 @@ def kernel_vectors():
 if __name__ == "__main__":
     if not os.path.isdir(REF) or not os.path.isdir(REFBIN):
         sys.exit("needs /root/reference and oracle/_ref (make -C oracle ref)")
-    which = sys.argv[1:] or ["whole", "shk", "dev", "kernels", "smr", "hst"]
+    which = sys.argv[1:] or ["whole", "shk", "dev", "kernels", "ppm", "smr", "hst"]
     if "hst" in which:
         history_runs()
     if "whole" in which:
         whole_runs()
+    if "ppm" in which:
+        ppm_runs()
     if "shk" in which:
         shock_tubes()
     if "dev" in which:

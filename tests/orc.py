@@ -32,7 +32,7 @@ class OrcParams(C.Structure):
         ("pot_GM", C.c_double), ("pot_Rsoft", C.c_double),
         ("userwork", C.c_int),
         ("uw_K", C.c_double), ("uw_Cp", C.c_double), ("uw_rho0", C.c_double), ("uw_rreset2", C.c_double),
-        ("integrator", C.c_int),
+        ("integrator", C.c_int), ("order", C.c_int),
     ]
 
 
@@ -92,6 +92,7 @@ def lib():
         L.orc_cfast.argtypes = [C.c_int, C.c_int, D, dp, dp]
         L.orc_fluxes.argtypes = [C.c_int, C.c_int, D, dp, dp, dp, dp]
         L.orc_lr_states.argtypes = [C.c_int, C.c_int, D, dp, D, D, C.c_int, C.c_int, dp, dp]
+        L.orc_lr_states_ppm.argtypes = [C.c_int, C.c_int, D, dp, D, D, C.c_int, C.c_int, dp, dp]
         _lib = L
     return _lib
 
@@ -112,6 +113,7 @@ def params_from_grid(g) -> OrcParams:
     p.nscal = r.nscal; p.ion = 1 if r.ion else 0
     p.gamma = r.gamma; p.cour_no = r.cour_no; p.tlim = r.tlim
     p.integrator = 1 if getattr(r, "integrator", "ctu") == "vl" else 0
+    p.order = getattr(r, "order", 2)
     if r.ionp:
         for k, v in r.ionp.items():
             setattr(p, k, v)
@@ -203,10 +205,11 @@ class Sim:
     def ion_dt_hydro(self): return self.L.orc_ion_dt_hydro(self.h)
 
 
-def make_sim(problem, overrides=None, rank=0, nranks=1, integrator="ctu"):
+def make_sim(problem, overrides=None, rank=0, nranks=1, integrator="ctu", order=2):
     aa = importlib.import_module("atmospheric-athena_amd")
     run = aa.config.load(os.path.join(DECKS, "athinput." + problem), overrides, problem)
     run.integrator = integrator
+    run.order = order
     return Sim(aa.config.slab(run, rank, nranks)).problem()
 
 
@@ -283,8 +286,9 @@ def fluxes(Ul, Ur, eta, gamma, nscal):
     lib().orc_fluxes(Ul.shape[0], nscal, gamma, _dp(Ul), _dp(Ur), _dp(eta), _dp(F)); return F
 
 
-def lr_states(W, dt, dx, il, iu, gamma, nscal):
+def lr_states(W, dt, dx, il, iu, gamma, nscal, order=2):
     W = np.ascontiguousarray(W, dtype=np.float64)
     Wl = np.zeros_like(W); Wr = np.zeros_like(W)
-    lib().orc_lr_states(W.shape[0], nscal, gamma, _dp(W), dt, dx, il, iu, _dp(Wl), _dp(Wr))
+    f = lib().orc_lr_states_ppm if order == 3 else lib().orc_lr_states
+    f(W.shape[0], nscal, gamma, _dp(W), dt, dx, il, iu, _dp(Wl), _dp(Wr))
     return Wl, Wr

@@ -26,6 +26,15 @@ def test_kernels_bitwise(nscal):
     assert _same(Wl, g["Wl"]) and _same(Wr, g["Wr"])
 
 
+@pytest.mark.parametrize("nscal", [0, 1])
+def test_ppm_reconstruction_bitwise(nscal):
+    """lr_states_ppm.c (--with-order=3) on the 2048-cell pencils, incl. the scalar column whose work
+    arrays overlap in the reference (see the oracle's comment)."""
+    g = np.load(os.path.join(GOLD, f"kernels_ppm_nscal{nscal}.npz"))
+    Wl, Wr = orc.lr_states(g["Wp"], float(g["dt"]), float(g["dx"]), int(g["il"]), int(g["iu"]), float(g["gamma"]), nscal, order=3)
+    assert _same(Wl, g["Wl"]) and _same(Wr, g["Wr"])
+
+
 def test_kernel_vectors_cover_all_roe_branches():
     """The Riemann vectors must exercise the HLLE fallback and the supersonic returns."""
     import ctypes as C
@@ -45,13 +54,16 @@ def test_whole_run_bitwise(name):
     g = np.load(os.path.join(GOLD, name + ".npz"))
     prob = name.rsplit("_", 2)[0]
     integrator = "ctu"
+    order = 2
     if prob.startswith("vl_"):
         prob, integrator = prob[3:], "vl"
+    if prob.startswith("ppm_"):
+        prob, order = prob[4:], 3
     if prob.startswith("shkset1d"):
         prob = "shkset1d"                       # shkset1d_d<dir>_...
     nx = g["nx"]
     s = orc.make_sim(prob, [f"domain1/Nx{d + 1}={int(nx[d])}" for d in range(3)] + [str(o) for o in g["overrides"]],
-                     integrator=integrator)
+                     integrator=integrator, order=order)
     nv = 5 + s.grid.run.nscal
     assert _same(s.active[..., :nv], g["U0"][..., :nv]), "initial condition"
     s.start()
