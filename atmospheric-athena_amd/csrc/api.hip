@@ -75,6 +75,9 @@ int aa_create(const aa_params *p, aa_grid **out)
   const size_t nef = (size_t)(d.Nx1 + 1)*(d.Nx2 + 1)*(d.Nx3 + 1);
   size_t n = nc*(6 + 36 + 18 + 3 + 1 + 4);
   if (p->ion) n += nc*6 + nef;
+  if (p->order != 0 && p->order != 2 && p->order != 3) { delete g; return fail(-1, "[aa_create]: order %d (2: PLM, 3: PPM)", p->order); }
+  if (p->order == 3 && p->integrator == 1) { delete g; return fail(-1, "[aa_create]: order 3 is built for the CTU integrator only"); }
+  if (p->order == 3) n += nc*18;
   g->pool_doubles = n;
   hipError_t e = hipMalloc(&g->pool, n*sizeof(Real));
   if (e != hipSuccess) { delete g; return fail(-2, "[aa_create]: hipMalloc of %.2f GB failed: %s", n*8e-9, hipGetErrorString(e)); }
@@ -83,6 +86,7 @@ int aa_create(const aa_params *p, aa_grid **out)
   Real *q = g->pool;
   d.U = q; q += 6*nc; d.LR = q; q += 36*nc; d.F = q; q += 18*nc; d.eta = q; q += 3*nc; d.dhalf = q; q += nc;
   d.phi = q; q += 4*nc;
+  if (p->order == 3) { d.slope = q; q += 18*nc; }
   if (p->ion) {
     d.ph_rate = q; q += nc; d.kin = q; q += nc; d.vmax = q; q += nc;
     d.e_init = q; q += nc; d.x_init = q; q += nc;
@@ -312,6 +316,7 @@ int aa_new_dt(aa_grid *g)
 int aa_integrate_3d_ctu(aa_grid *g)
 {
   const DevGrid &d = g->d; const int ns = g->p.nscal; const Real dt = g->dt;
+  if (d.slope) { Scope s(g, "ppm_slopes"); for (int dir = 0; dir < 3; dir++) launch_slopes(d, ns, dir, g->st); }
   // x2 and x3 first, so that the x1 sweep can do its first pass and its correct pass in one go
   { Scope s(g, "sweep_x2"); launch_sweep(d, ns, 1, dt, g->grav, g->st); }
   { Scope s(g, "sweep_x3"); launch_sweep(d, ns, 2, dt, g->grav, g->st); }
@@ -465,21 +470,27 @@ int aa_test_fluxes(int nscal, double gamma, int n, const double *Ul, const doubl
   hipFree(d);
   return 0;
 }
-int aa_test_lr_states(int nscal, double gamma, int n, const double *W, double dt, double dx, int il, int iu, double *Wl, double *Wr)
+static int test_lr_any(int order, int nscal, double gamma, int n, const double *W, double dt, double dx, int il, int iu, double *Wl, double *Wr)
 {
   const size_t nv = 5 + nscal, nb = (size_t)n*nv*sizeof(Real);
-  if (il < 2 || iu > n - 3) return fail(-1, "[aa_test_lr_states]: W must cover [il-2, iu+2]");
+  const int h = (order == 3) ? 3 : 2;
+  if (il < h || iu > n - 1 - h) return fail(-1, "[aa_test_lr_states]: W must cover [il-%d, iu+%d]", h, h);
   Real *d = nullptr;
   HIPCHK(hipMalloc(&d, 3*nb));
   Real *dW = d, *dWl = d + (size_t)n*nv, *dWr = d + 2*(size_t)n*nv;
   HIPCHK(hipMemcpy(dW, W, nb, hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(dWl, Wl, nb, hipMemcpyHostToDevice)); HIPCHK(hipMemcpy(dWr, Wr, nb, hipMemcpyHostToDevice));
-  launch_test_lr(nscal, gamma, n, dW, dt, dx, il, iu, dWl, dWr, 0);
+  if (order == 3) launch_test_lr_ppm(nscal, gamma, n, dW, dt, dx, il, iu, dWl, dWr, 0);
+  else launch_test_lr(nscal, gamma, n, dW, dt, dx, il, iu, dWl, dWr, 0);
   HIPCHK(hipDeviceSynchronize());
   HIPCHK(hipMemcpy(Wl, dWl, nb, hipMemcpyDeviceToHost)); HIPCHK(hipMemcpy(Wr, dWr, nb, hipMemcpyDeviceToHost));
   hipFree(d);
   return 0;
 }
+int aa_test_lr_states(int nscal, double gamma, int n, const double *W, double dt, double dx, int il, int iu, double *Wl, double *Wr)
+{ return test_lr_any(2, nscal, gamma, n, W, dt, dx, il, iu, Wl, Wr); }
+int aa_test_lr_states_ppm(int nscal, double gamma, int n, const double *W, double dt, double dx, int il, int iu, double *Wl, double *Wr)
+{ return test_lr_any(3, nscal, gamma, n, W, dt, dx, il, iu, Wl, Wr); }
 
 // ---- history sums (dump_history.c:157-200) ---------------------------------------------------
 int aa_history(aa_grid *g, double *sums)

@@ -32,6 +32,7 @@ struct DevGrid {
   Real Gamma, Gamma_1;
   Real *U, *LR, *F, *eta, *dhalf;
   Real *phi;                      // null when StaticGravPot == NULL; [0]=centre, [1+d]=lower face d
+  Real *slope;                    // --with-order=3 only: 18*nc, [dir][prim var] monotonised slopes (lr_states_ppm.c dWm)
   // ion
   Real *ph_rate, *kin, *vmax, *e_init, *x_init;   // kin (kinetic energy), vmax: frozen during the ion step
   int2 *sign;                     // .x = last_sign, .y = sign_count
@@ -63,6 +64,7 @@ struct DevScalars {
 };
 
 // ---- launch wrappers (hydro_kernels.hip) ------------------------------------------
+void launch_slopes(const DevGrid &g, int nscal, int dir, hipStream_t st);          // order 3: before the sweeps of a step
 void launch_sweep(const DevGrid &g, int nscal, int dir, Real dt, bool grav, hipStream_t st);
 void launch_correct(const DevGrid &g, int nscal, int dir, Real dt, bool grav, hipStream_t st);
 void launch_sweep_correct_x1(const DevGrid &g, int nscal, Real dt, bool grav, hipStream_t st);
@@ -84,6 +86,8 @@ void launch_test_fluxes(int nscal, Real gamma, int n, const Real *Ul, const Real
                         Real *F, hipStream_t st);
 void launch_test_lr(int nscal, Real gamma, int n, const Real *W, Real dt, Real dx, int il, int iu,
                     Real *Wl, Real *Wr, hipStream_t st);
+void launch_test_lr_ppm(int nscal, Real gamma, int n, const Real *W, Real dt, Real dx, int il, int iu,
+                        Real *Wl, Real *Wr, hipStream_t st);
 
 // ---- launch wrappers (ion_kernels.hip) ---------------------------------------------
 void launch_ion_begin(const DevGrid &g, const IonPar &p, hipStream_t st);

@@ -287,4 +287,146 @@ AA_DEV void plm_cell(const Real wm[6], const Real w[6], const Real wp[6], Real d
   }
 }
 
+// ---- reconstruction/lr_states_ppm.c:91-610 (THIRD_ORDER_CHAR, --with-order=3) -----------------
+// Monotonised characteristic slope of one cell (Steps 1-5 / 8-12; identical to lr_states_plm.c:
+// 131-202).  Evaluated once per cell and direction by k_slopes and kept in HBM: a cell's parabola
+// needs the slopes of both neighbours as well.
+template <int NS>
+AA_DEV void limited_slopes(const Real wm[6], const Real w[6], const Real wp[6], Real Gamma, Real dWm[6])
+{
+  constexpr int NV = 5 + NS;
+  Real d = w[0];
+  Real asq = (Gamma*w[4])/d, a = sqrt(asq);
+  Real r10 = -a/d, r14 = -r10;
+  Real l01 = -0.5*d/a, l04 = 0.5/asq, l14 = -1.0/asq, l41 = -l01;
+  Real dWc[6], dWl[6], dWr[6], dWg[6];
+#pragma unroll
+  for (int n = 0; n < NV; n++) {
+    dWc[n] = wp[n] - wm[n]; dWl[n] = w[n] - wm[n]; dWr[n] = wp[n] - w[n];
+    dWg[n] = (dWl[n]*dWr[n] > 0.0) ? 2.0*dWl[n]*dWr[n]/(dWl[n] + dWr[n]) : 0.0;
+  }
+  Real dac[6], dal[6], dar[6], dag[6];
+#define AA_PROJ(o, x) { o[0] = l01*x[1]; o[0] += l04*x[4]; o[1] = x[0]; o[1] += l14*x[4]; \
+                        o[2] = x[2]; o[3] = x[3]; o[4] = l41*x[1]; o[4] += l04*x[4]; \
+                        if (NS) o[5] = x[5]; }
+  AA_PROJ(dac, dWc) AA_PROJ(dal, dWl) AA_PROJ(dar, dWr) AA_PROJ(dag, dWg)
+#undef AA_PROJ
+  Real da[6];
+#pragma unroll
+  for (int n = 0; n < NV; n++) {
+    da[n] = 0.0;
+    if (dal[n]*dar[n] > 0.0) {
+      Real lim1 = rmin(fabs(dal[n]), fabs(dar[n]));
+      Real lim2 = rmin(0.5*fabs(dac[n]), fabs(dag[n]));
+      da[n] = ((dac[n] < 0.) ? -1. : 1.)*rmin(2.0*lim1, lim2);
+    }
+  }
+  dWm[0] = da[0]; dWm[0] += da[1]; dWm[0] += da[4];
+  dWm[1] = da[0]*r10; dWm[1] += da[4]*r14;
+  dWm[2] = da[2]; dWm[3] = da[3];
+  dWm[4] = da[0]*asq; dWm[4] += da[4]*asq;
+  dWm[5] = NS ? da[5] : 0.0;
+}
+
+// Parabola of one cell from its own and its neighbours' slopes (Steps 14-19), traced over the
+// domain of dependence: Wl of the upper interface, Wr of the lower one.  With a passive scalar the
+// reference's work arrays overlap (NWAVE columns allocated, NWAVE+NSCALARS indexed, :689-692): the
+// scalar's left parabola edge is the density interface value and its right edge mixes the scalar
+// and density slopes of cell i+1; reproduced as is (see oracle/athena_oracle.c lr_states_ppm).
+template <int NS>
+AA_DEV void ppm_cell(const Real wm[6], const Real w[6], const Real wp[6], const Real Dm[6], const Real D0[6],
+                     const Real Dp[6], Real dtodx, Real Gamma, Real wl_next[6], Real wr_here[6])
+{
+  constexpr int NV = 5 + NS;
+  constexpr Real FOUR_3RDS = 1.333333333333333, TWO_3RDS = 0.6666666666666667;     // defs.h.in:158-159
+  const Real gamma_curv = 0.0, qxx1 = 0.0, qxx2 = 0.0;
+  Real d = w[0], vx = w[1];
+  Real asq = (Gamma*w[4])/d, a = sqrt(asq);
+  Real ev0 = vx - a, ev4 = vx + a;
+  Real r10 = -a/d, r14 = -r10;
+  Real l01 = -0.5*d/a, l04 = 0.5/asq, l14 = -1.0/asq, l41 = -l01;
+  Real Wlv[6], Wrv[6], dW[6], W6[6];
+#pragma unroll
+  for (int n = 0; n < 5; n++) {
+    Wlv[n] = 0.5*(w[n] + wm[n]) - (D0[n] - Dm[n])/6.0;
+    Wrv[n] = 0.5*(wp[n] + w[n]) - (Dp[n] - D0[n])/6.0;
+  }
+  if (NS) {
+    Wlv[5] = Wrv[0];
+    Wrv[5] = 0.5*(wp[5] + w[5]) - (Dp[5] - Dp[0])/6.0;
+  }
+#pragma unroll
+  for (int n = 0; n < NV; n++) {
+    Real qa = (Wrv[n] - w[n])*(w[n] - Wlv[n]);
+    Real qb = Wrv[n] - Wlv[n];
+    Real qc = 6.0*(w[n] - 0.5*(Wlv[n]*(1.0 - gamma_curv) + Wrv[n]*(1.0 + gamma_curv)));
+    if (qa <= 0.0) { Wlv[n] = w[n]; Wrv[n] = w[n]; }
+    else if ((qb*qc) > (qb*qb)) Wlv[n] = (6.0*w[n] - Wrv[n]*(4.0 + 3.0*gamma_curv))/(2.0 - 3.0*gamma_curv);
+    else if ((qb*qc) < -(qb*qb)) Wrv[n] = (6.0*w[n] - Wlv[n]*(4.0 - 3.0*gamma_curv))/(2.0 + 3.0*gamma_curv);
+  }
+#pragma unroll
+  for (int n = 0; n < NV; n++) {
+    Wlv[n] = rmax(rmin(w[n], wm[n]), Wlv[n]);
+    Wlv[n] = rmin(rmax(w[n], wm[n]), Wlv[n]);
+    Wrv[n] = rmax(rmin(w[n], wp[n]), Wrv[n]);
+    Wrv[n] = rmin(rmax(w[n], wp[n]), Wrv[n]);
+  }
+#pragma unroll
+  for (int n = 0; n < NV; n++) {
+    dW[n] = Wrv[n] - Wlv[n];
+    W6[n] = 6.0*(w[n] - 0.5*(Wlv[n]*(1.0 - gamma_curv) + Wrv[n]*(1.0 + gamma_curv)));
+  }
+  Real qx1 = 0.5*rmax(ev4, 0.0)*dtodx;
+#pragma unroll
+  for (int n = 0; n < NV; n++)
+    wl_next[n] = Wrv[n] - qx1 *(dW[n] - (1.0 - FOUR_3RDS*qx1)*W6[n])
+                        + qxx1*(dW[n] - (1.0 -       2.0*qx1)*W6[n]);
+  Real qx2 = -0.5*rmin(ev0, 0.0)*dtodx;
+#pragma unroll
+  for (int n = 0; n < NV; n++)
+    wr_here[n] = Wlv[n] + qx2 *(dW[n] + (1.0 - FOUR_3RDS*qx2)*W6[n])
+                        + qxx2*(dW[n] + (1.0 -       2.0*qx2)*W6[n]);
+  if (!NS) { wl_next[5] = 0.0; wr_here[5] = 0.0; }
+  Real qa, qb, qc;
+#define AA_TL(m) (qb*(dW[m] - W6[m]) + qc*W6[m])
+#define AA_TR(m) (qb*(dW[m] + W6[m]) + qc*W6[m])
+  qx1 = 0.5*dtodx*ev4;
+  if (ev0 >= 0.0) {
+    qx2 = 0.5*dtodx*ev0; qb = qx1 - qx2; qc = FOUR_3RDS*(qx1*qx1 - qx2*qx2);
+    qa = 0.0; qa += l01*AA_TL(1); qa += l04*AA_TL(4);
+    wl_next[0] += qa; wl_next[1] += qa*r10; wl_next[4] += qa*asq;
+  }
+  if (vx >= 0.0) {
+    qx2 = 0.5*dtodx*vx; qb = qx1 - qx2; qc = FOUR_3RDS*(qx1*qx1 - qx2*qx2);
+    qa = 0.0; qa += 1.0*AA_TL(0); qa += l14*AA_TL(4);  wl_next[0] += qa;
+    qa = 0.0; qa += 1.0*AA_TL(2);                      wl_next[2] += qa;
+    qa = 0.0; qa += 1.0*AA_TL(3);                      wl_next[3] += qa;
+  }
+  qx1 = 0.5*dtodx*ev0;
+  if (vx <= 0.0) {
+    qx2 = 0.5*dtodx*vx; qb = qx1 - qx2; qc = FOUR_3RDS*(qx1*qx1 - qx2*qx2);
+    qa = 0.0; qa += 1.0*AA_TR(0); qa += l14*AA_TR(4);  wr_here[0] += qa;
+    qa = 0.0; qa += 1.0*AA_TR(2);                      wr_here[2] += qa;
+    qa = 0.0; qa += 1.0*AA_TR(3);                      wr_here[3] += qa;
+  }
+  if (ev4 <= 0.0) {
+    qx2 = 0.5*dtodx*ev4; qb = qx1 - qx2; qc = FOUR_3RDS*(qx1*qx1 - qx2*qx2);
+    qa = 0.0; qa += l41*AA_TR(1); qa += l04*AA_TR(4);
+    wr_here[0] += qa; wr_here[1] += qa*r14; wr_here[4] += qa*asq;
+  }
+#undef AA_TL
+#undef AA_TR
+  if (NS) {
+    if (vx > 0.) {
+      qb = 0.5*dtodx*(ev4 - vx);
+      qc = 0.5*dtodx*dtodx*TWO_3RDS*(ev4*ev4 - vx*vx);
+      wl_next[5] += qb*(dW[5] - W6[5]) + qc*W6[5];
+    } else if (vx < 0.) {
+      qb = 0.5*dtodx*(ev0 - vx);
+      qc = 0.5*dtodx*dtodx*TWO_3RDS*(ev0*ev0 - vx*vx);
+      wr_here[5] += qb*(dW[5] + W6[5]) + qc*W6[5];
+    }
+  }
+}
+
 }  // namespace aa

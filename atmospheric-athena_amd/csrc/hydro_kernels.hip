@@ -47,6 +47,47 @@ AA_DEV void store_sweep(Real *fam, long nc, long m, const Real in[6])
   for (int n = 0; n < 5 + NS; n++) fam[(long)gv<D>(n)*nc + m] = in[n];
 }
 
+// L/R states of one cell: piecewise linear (ORD 2, lr_states_plm.c) or piecewise parabolic (ORD 3,
+// lr_states_ppm.c; the slopes of the cell and of its two neighbours along D come from k_slopes)
+AA_DEV Real *Sf(const DevGrid &g, int d, int n) { return g.slope + (long)(d*6 + n)*g.nc; }
+template <int NS, bool TRACE, int ORD, int D>
+AA_DEV void recon_cell(const DevGrid &g, long mcell, const Real wm[6], const Real w[6], const Real wp[6], Real dtodx,
+                       Real wl_next[6], Real wr_here[6])
+{
+  if (ORD == 3) {
+    const long s = stride<D>(g);
+    Real Dm[6], D0[6], Dp[6];
+#pragma unroll
+    for (int n = 0; n < 5 + NS; n++) { const Real *q = Sf(g, D, n) + mcell; Dm[n] = q[-s]; D0[n] = q[0]; Dp[n] = q[s]; }
+    if (!NS) { Dm[5] = 0.0; D0[5] = 0.0; Dp[5] = 0.0; }
+    ppm_cell<NS>(wm, w, wp, Dm, D0, Dp, dtodx, g.Gamma, wl_next, wr_here);
+  } else plm_cell<NS, TRACE>(wm, w, wp, dtodx, g.Gamma, wl_next, wr_here);
+}
+
+// ---- order 3: monotonised slopes of every cell along D (Steps 1-5 of lr_states_ppm.c) -----------
+// cells: along D [s-3, e+3] (a parabola of cell c in [s-2, e+2] needs c-1 and c+1), transverse
+// [s-2, e+2] as the sweeps
+template <int NS, int D>
+__global__ void __launch_bounds__(256)
+k_slopes(DevGrid g)
+{
+  const int lo[3] = {g.is, g.js, g.ks}, hi[3] = {g.ie, g.je, g.ke};
+  int n3[3], o3[3];
+#pragma unroll
+  for (int d = 0; d < 3; d++) { o3[d] = lo[d] - (d == D ? 3 : 2); n3[d] = hi[d] - lo[d] + 1 + (d == D ? 6 : 4); }
+  const long lin = (long)blockIdx.x*blockDim.x + threadIdx.x;
+  if (lin >= (long)n3[0]*n3[1]*n3[2]) return;
+  const int i = o3[0] + (int)(lin % n3[0]), j = o3[1] + (int)((lin / n3[0]) % n3[1]), k = o3[2] + (int)(lin / ((long)n3[0]*n3[1]));
+  const long m = (long)k*g.sK + (long)j*g.sJ + i, s = stride<D>(g);
+  Real u[6], wm[6], w[6], wp[6], dWm[6];
+  load_sweep<D, NS>(g.U, g.nc, m - s, u); cons_to_prim<NS>(u, wm, g.Gamma_1);
+  load_sweep<D, NS>(g.U, g.nc, m,     u); cons_to_prim<NS>(u, w,  g.Gamma_1);
+  load_sweep<D, NS>(g.U, g.nc, m + s, u); cons_to_prim<NS>(u, wp, g.Gamma_1);
+  limited_slopes<NS>(wm, w, wp, g.Gamma, dWm);
+#pragma unroll
+  for (int n = 0; n < 5 + NS; n++) Sf(g, D, n)[m] = dWm[n];
+}
+
 // What a sweep does at each interface once the L/R primitive states are known.
 //   MODE_FLUX1  CTU steps 1c-1d: gravity kick, conversion to conserved, first-pass flux (etah=0);
 //               only the flux is stored
@@ -178,7 +219,7 @@ AA_DEV bool decode_zone(const Order o, int ni, int nj, int nk, int &i, int &j, i
 // ---- steps 2,3: x2 / x3 sweeps, register sliding window along the sweep direction ---------
 // One thread owns one (i, transverse) column and a chunk of `chunk` interfaces; lanes are
 // consecutive in i.  Cells reconstructed: l..u = s-2..e+2; interfaces l+1..u (:179-184).
-template <int NS, int D, bool GRAV, int MODE>
+template <int NS, int D, bool GRAV, int MODE, int ORD>
 __global__ void __launch_bounds__(256)
 k_sweep_march(DevGrid g, const Real *src, Real dt, int chunk)
 {
@@ -202,12 +243,12 @@ k_sweep_march(DevGrid g, const Real *src, Real dt, int chunk)
   load_sweep<D, NS>(src, g.nc, base + (long)(f0 - 2)*s, u); cons_to_prim<NS>(u, wm, g.Gamma_1);
   load_sweep<D, NS>(src, g.nc, base + (long)(f0 - 1)*s, u); cons_to_prim<NS>(u, w,  g.Gamma_1);
   load_sweep<D, NS>(src, g.nc, base + (long)(f0    )*s, u); cons_to_prim<NS>(u, wp, g.Gamma_1);
-  plm_cell<NS, MODE != MODE_VL>(wm, w, wp, dtodx, g.Gamma, wl_cur, wr);    // cell f0-1 -> Wl[f0]
+  recon_cell<NS, MODE != MODE_VL, ORD, D>(g, base + (long)(f0 - 1)*s, wm, w, wp, dtodx, wl_cur, wr);    // cell f0-1 -> Wl[f0]
   for (int f = f0; f <= f1; f++) {
 #pragma unroll
     for (int n = 0; n < 6; n++) { wm[n] = w[n]; w[n] = wp[n]; }
     load_sweep<D, NS>(src, g.nc, base + (long)(f + 1)*s, u); cons_to_prim<NS>(u, wp, g.Gamma_1);
-    plm_cell<NS, MODE != MODE_VL>(wm, w, wp, dtodx, g.Gamma, wl_next, wr);  // cell f -> Wl[f+1], Wr[f]
+    recon_cell<NS, MODE != MODE_VL, ORD, D>(g, base + (long)f*s, wm, w, wp, dtodx, wl_next, wr);  // cell f -> Wl[f+1], Wr[f]
     face_work<NS, D, GRAV, MODE>(g, base + (long)f*s, i, D == 1 ? f : t, D == 1 ? t : f, dt, wl_cur, wr);
 #pragma unroll
     for (int n = 0; n < 6; n++) wl_cur[n] = wl_next[n];
@@ -220,7 +261,7 @@ k_sweep_march(DevGrid g, const Real *src, Real dt, int chunk)
 // 64 consecutive doubles, conflict-free), neighbours and the Wl hand-off come from LDS, blocks
 // overlap by one cell.  One cell per thread keeps the correct pass at ~130 VGPRs (3 waves/SIMD)
 // where the marching form needs 255 (1 wave/SIMD, latency-bound: 32 ms instead of 9 at 512^3).
-template <int NS, int D, bool GRAV, int MODE, int BT>
+template <int NS, int D, bool GRAV, int MODE, int BT, int ORD>
 __global__ void __launch_bounds__(64*BT, 4)
 k_sweep_tile(DevGrid g, const Real *src, Real dt)
 {
@@ -268,7 +309,7 @@ k_sweep_tile(DevGrid g, const Real *src, Real dt)
   for (int n = 0; n < 5 + NS; n++) { wm[n] = sm[n*P + t*64 + lane]; wp[n] = sm[n*P + (t + 2)*64 + lane]; }
   if (!NS) { wm[5] = 0.0; wp[5] = 0.0; }
   const bool recon = colok && (c <= hi + 2);
-  if (recon) plm_cell<NS, MODE != MODE_VL>(wm, w, wp, dtodx, g.Gamma, wl_next, wr);
+  if (recon) recon_cell<NS, MODE != MODE_VL, ORD, D>(g, base + (long)c*s, wm, w, wp, dtodx, wl_next, wr);
   else {
 #pragma unroll
     for (int n = 0; n < 6; n++) { wl_next[n] = 1.0; wr[n] = 1.0; }
@@ -289,7 +330,7 @@ k_sweep_tile(DevGrid g, const Real *src, Real dt)
 // ---- step 1: x1 sweep, neighbours through LDS ------------------------------------------
 // A block of B threads reconstructs B consecutive cells of one (j,k) row and solves the B-1
 // interfaces between them; blocks overlap by one cell.
-template <int NS, bool GRAV, int MODE>
+template <int NS, bool GRAV, int MODE, int ORD>
 __global__ void __launch_bounds__(256, 4)
 k_sweep_x1(DevGrid g, const Real *src, Real dt)
 {
@@ -332,7 +373,7 @@ k_sweep_x1(DevGrid g, const Real *src, Real dt)
   for (int n = 0; n < 5 + NS; n++) { wm[n] = sm[n*P + t]; wp[n] = sm[n*P + t + 2]; }
   if (!NS) { wm[5] = 0.0; wp[5] = 0.0; }
   const bool recon = (c <= g.ie + 2);                  // cells l..u
-  if (recon) plm_cell<NS, MODE != MODE_VL>(wm, w, wp, dtodx, g.Gamma, wl_next, wr);
+  if (recon) recon_cell<NS, MODE != MODE_VL, ORD, 0>(g, row + c, wm, w, wp, dtodx, wl_next, wr);
   else {
 #pragma unroll
     for (int n = 0; n < 6; n++) { wl_next[n] = 1.0; wr[n] = 1.0; }
@@ -641,6 +682,18 @@ __global__ void k_test_fluxes(Real Gamma, int n, const Real *Ul, const Real *Ur,
   for (int v = 0; v < NV; v++) F[(long)t*NV + v] = f[v];
 }
 template <int NS>
+__global__ void k_test_lr_ppm(Real Gamma, int n, const Real *W, Real dt, Real dx, int il, int iu, Real *Wl, Real *Wr)
+{
+  const int c = il - 1 + blockIdx.x*blockDim.x + threadIdx.x;     // cells il-1 .. iu+1
+  if (c > iu + 1) return;
+  constexpr int NV = 5 + NS;
+  Real w5[5][6], D[3][6], a[6], b[6];
+  for (int q = 0; q < 5; q++) for (int v = 0; v < 6; v++) w5[q][v] = (v < NV) ? W[(long)(c - 2 + q)*NV + v] : 0.0;
+  for (int q = 0; q < 3; q++) limited_slopes<NS>(w5[q], w5[q + 1], w5[q + 2], Gamma, D[q]);
+  ppm_cell<NS>(w5[1], w5[2], w5[3], D[0], D[1], D[2], dt/dx, Gamma, a, b);
+  for (int v = 0; v < NV; v++) { Wl[(long)(c + 1)*NV + v] = a[v]; Wr[(long)c*NV + v] = b[v]; }
+}
+template <int NS>
 __global__ void k_test_lr(Real Gamma, int n, const Real *W, Real dt, Real dx, int il, int iu, Real *Wl, Real *Wr)
 {
   const int c = il - 1 + blockIdx.x*blockDim.x + threadIdx.x;     // cells il-1 .. iu+1
@@ -667,8 +720,8 @@ static Order zone_order()
 }
 static inline unsigned nblk8(long n, int b) { unsigned x = nblk(n, b); return ((x + 7u)/8u)*8u; }   // for xcd_block()
 
-template <int NS, bool GRAV, int MODE>
-static void sweep_impl(const DevGrid &g, const Real *src, int dir, Real dt, hipStream_t st)
+template <int NS, bool GRAV, int MODE, int ORD>
+static void sweep_impl_o(const DevGrid &g, const Real *src, int dir, Real dt, hipStream_t st)
 {
   if (dir == 0) {
     const int nfaces = (g.ie - g.is + 1) + 3;          // interfaces l+1..u
@@ -678,7 +731,7 @@ static void sweep_impl(const DevGrid &g, const Real *src, int dir, Real dt, hipS
     nb = (nfaces + (B - 1) - 1)/(B - 1);
     dim3 grid(nb, g.je - g.js + 5, g.ke - g.ks + 5);
     size_t lds = (size_t)(5 + NS)*(B + 2)*sizeof(Real);
-    hipLaunchKernelGGL((k_sweep_x1<NS, GRAV, MODE>), grid, dim3(B), lds, st, g, src, dt);
+    hipLaunchKernelGGL((k_sweep_x1<NS, GRAV, MODE, ORD>), grid, dim3(B), lds, st, g, src, dt);
   } else if (MODE == MODE_CORR) {
     constexpr int BT = 8;     // 8 beats 16 (12.0 ms) despite the 10-rows-for-7-faces halo: more blocks in flight
     const long ni = g.ie - g.is + 5;
@@ -686,18 +739,39 @@ static void sweep_impl(const DevGrid &g, const Real *src, int dir, Real dt, hipS
     const int nfaces = (dir == 1 ? g.je - g.js : g.ke - g.ks) + 1 + 3;
     dim3 grid(nblk(ni*nt, 64), (nfaces + BT - 2)/(BT - 1)), blk(64, BT);
     const size_t lds = (size_t)(5 + NS)*(BT + 2)*64*sizeof(Real);
-    if (dir == 1) hipLaunchKernelGGL((k_sweep_tile<NS, 1, GRAV, MODE, BT>), grid, blk, lds, st, g, src, dt);
-    else          hipLaunchKernelGGL((k_sweep_tile<NS, 2, GRAV, MODE, BT>), grid, blk, lds, st, g, src, dt);
+    if (dir == 1) hipLaunchKernelGGL((k_sweep_tile<NS, 1, GRAV, MODE, BT, ORD>), grid, blk, lds, st, g, src, dt);
+    else          hipLaunchKernelGGL((k_sweep_tile<NS, 2, GRAV, MODE, BT, ORD>), grid, blk, lds, st, g, src, dt);
   } else {
     const int chunk = 32;
     const long ni = g.ie - g.is + 5;
     const long nt = (dir == 1 ? g.ke - g.ks : g.je - g.js) + 5;
     const int nfaces = (dir == 1 ? g.je - g.js : g.ke - g.ks) + 1 + 3;
     dim3 grid(nblk(ni*nt, 64), (nfaces + chunk - 1)/chunk);
-    if (dir == 1) hipLaunchKernelGGL((k_sweep_march<NS, 1, GRAV, MODE>), grid, dim3(64), 0, st, g, src, dt, chunk);
-    else          hipLaunchKernelGGL((k_sweep_march<NS, 2, GRAV, MODE>), grid, dim3(64), 0, st, g, src, dt, chunk);
+    if (dir == 1) hipLaunchKernelGGL((k_sweep_march<NS, 1, GRAV, MODE, ORD>), grid, dim3(64), 0, st, g, src, dt, chunk);
+    else          hipLaunchKernelGGL((k_sweep_march<NS, 2, GRAV, MODE, ORD>), grid, dim3(64), 0, st, g, src, dt, chunk);
   }
 }
+template <int NS, bool GRAV, int MODE>
+static void sweep_impl(const DevGrid &g, const Real *src, int dir, Real dt, hipStream_t st)
+{
+  // the van Leer integrator is second order only (MODE_VL never sees a slope array)
+  if (MODE != MODE_VL && g.slope) sweep_impl_o<NS, GRAV, MODE, (MODE == MODE_VL ? 2 : 3)>(g, src, dir, dt, st);
+  else sweep_impl_o<NS, GRAV, MODE, 2>(g, src, dir, dt, st);
+}
+template <int NS>
+static void slopes_impl(const DevGrid &g, int dir, hipStream_t st)
+{
+  long n = 1;
+  const int lo[3] = {g.is, g.js, g.ks}, hi[3] = {g.ie, g.je, g.ke};
+  for (int d = 0; d < 3; d++) n *= hi[d] - lo[d] + 1 + (d == dir ? 6 : 4);
+  dim3 grid(nblk(n, 256)), blk(256);
+  if (dir == 0) hipLaunchKernelGGL((k_slopes<NS, 0>), grid, blk, 0, st, g);
+  else if (dir == 1) hipLaunchKernelGGL((k_slopes<NS, 1>), grid, blk, 0, st, g);
+  else hipLaunchKernelGGL((k_slopes<NS, 2>), grid, blk, 0, st, g);
+}
+void launch_slopes(const DevGrid &g, int nscal, int dir, hipStream_t st)
+{ if (nscal) slopes_impl<1>(g, dir, st); else slopes_impl<0>(g, dir, st); }
+
 void launch_sweep(const DevGrid &g, int nscal, int dir, Real dt, bool grav, hipStream_t st)
 {
   if (nscal) { if (grav) sweep_impl<1, true, MODE_FLUX1>(g, g.U, dir, dt, st); else sweep_impl<1, false, MODE_FLUX1>(g, g.U, dir, dt, st); }
@@ -801,6 +875,12 @@ void launch_test_fluxes(int nscal, Real gamma, int n, const Real *Ul, const Real
 {
   if (nscal) hipLaunchKernelGGL((k_test_fluxes<1>), dim3(nblk(n, 128)), dim3(128), 0, st, gamma, n, Ul, Ur, eta, F);
   else       hipLaunchKernelGGL((k_test_fluxes<0>), dim3(nblk(n, 128)), dim3(128), 0, st, gamma, n, Ul, Ur, eta, F);
+}
+void launch_test_lr_ppm(int nscal, Real gamma, int n, const Real *W, Real dt, Real dx, int il, int iu, Real *Wl, Real *Wr, hipStream_t st)
+{
+  const int nc = iu - il + 3;
+  if (nscal) hipLaunchKernelGGL((k_test_lr_ppm<1>), dim3(nblk(nc, 128)), dim3(128), 0, st, gamma, n, W, dt, dx, il, iu, Wl, Wr);
+  else       hipLaunchKernelGGL((k_test_lr_ppm<0>), dim3(nblk(nc, 128)), dim3(128), 0, st, gamma, n, W, dt, dx, il, iu, Wl, Wr);
 }
 void launch_test_lr(int nscal, Real gamma, int n, const Real *W, Real dt, Real dx, int il, int iu, Real *Wl, Real *Wr, hipStream_t st)
 {

@@ -64,6 +64,17 @@ static int use_vl(void)
 #endif
 }
 
+/* configure --with-order=3  <->  -DAA_THIRD_ORDER at compile time, or AA_ORDER=3 */
+static int recon_order(void)
+{
+#ifdef AA_THIRD_ORDER
+  return 3;
+#else
+  const char *e = getenv("AA_ORDER");
+  return (e && atoi(e) == 3) ? 3 : 2;
+#endif
+}
+
 static void ensure_grid(MeshS *pM)
 {
   aa_params p; DomainS *pD; int d, l, irefine; const char *env;
@@ -122,6 +133,7 @@ static void ensure_grid(MeshS *pM)
     }
     env = getenv("AA_DEVICE"); p.device = env ? atoi(env) : 0;
     p.integrator = use_vl();
+    p.order = recon_order();
     CHK(aa_create(&p, &G[l]));
     ncell[l] = (size_t)(PG[l]->Nx[0] + 2*AA_NGHOST)*(PG[l]->Nx[1] + 2*AA_NGHOST)*(PG[l]->Nx[2] + 2*AA_NGHOST);
     host_newer[l] = 1; snap[l] = NULL;

@@ -33,6 +33,7 @@ class aa_params(C.Structure):
         ("max_de_step", C.c_double), ("max_de_therm_step", C.c_double), ("max_dx_step", C.c_double),
         ("tfloor", C.c_double), ("tceil", C.c_double),
         ("maxiter", C.c_int), ("device", C.c_int), ("integrator", C.c_int), ("level", C.c_int),
+        ("order", C.c_int),
     ]
 
 
@@ -103,6 +104,7 @@ def load(strict: bool | None = None) -> C.CDLL:
         "aa_flux_x3_export": (I, [P, I, P]), "aa_flux_x3_apply": (I, [P, I, I, I, I, I, P]), "aa_cfl_max_v": (I, [P, dp]),
         "aa_test_fluxes": (I, [I, D, I, dp, dp, dp, dp]),
         "aa_test_lr_states": (I, [I, D, I, dp, D, D, I, I, dp, dp]),
+        "aa_test_lr_states_ppm": (I, [I, D, I, dp, D, D, I, I, dp, dp]),
         "aa_history": (I, [P, dp]),
         "aa_profile_enable": (I, [P, I]), "aa_profile_reset": (I, [P]), "aa_profile_count": (I, [P]),
         "aa_profile_name": (C.c_char_p, [P, I]), "aa_profile_get": (I, [P, I, dp, llp]),
@@ -154,6 +156,7 @@ def params_from_grid(g: GridConfig, device: int = 0) -> aa_params:
     p.device = device
     p.integrator = 1 if r.integrator == "vl" else 0
     p.level = g.level
+    p.order = getattr(r, "order", 2)
     return p
 
 

@@ -37,7 +37,7 @@ KERNEL_BYTES = {
     "vl_flux2_x3": 8 * 12, "flux2_x1": 8 * (12 + 3 + 6), "flux2_x2": 8 * (12 + 3 + 6),
     "flux2_x3": 8 * (12 + 3 + 6), "update": 8 * (6 + 18 + 6),
     "ray_sweep": 8 * (1 + 2), "ion_rates": 8 * (5 + 1), "ion_update": 8 * (5 + 1 + 2 + 0.5 + 2),
-    "ion_begin": 8 * (6 + 6), "bvals_mhd": 0, "new_dt": 8 * 5, "pinned_cells": 0,
+    "ion_begin": 8 * (6 + 6), "bvals_mhd": 0, "new_dt": 8 * 5, "pinned_cells": 0, "ppm_slopes": 3 * 8 * (6 + 6),
 }
 
 
@@ -156,6 +156,7 @@ def main():
     ap.add_argument("--nx", type=int, default=512, help="zones per direction per GPU (default: the 512^3 workload)")
     ap.add_argument("--problem", default="ioniz_sphere", choices=["ioniz_sphere", "ifront", "blast"])
     ap.add_argument("--integrator", default="ctu", choices=["ctu", "vl"])
+    ap.add_argument("--order", type=int, default=2, choices=[2, 3], help="reconstruction: 2 PLM (default), 3 PPM (--with-order=3)")
     ap.add_argument("--smr", action="store_true",
                     help="BASELINE.json configs[4]: 2-level static mesh refinement, per GPU a root slab of nx^3 zones plus "
                          "nx^3 level-1 zones over the central half of the box (not the headline line)")
@@ -194,6 +195,7 @@ def main():
                  f"domain1/x3max={x3min + (x3max - x3min) * world!r}"])
     run = aa.config.from_par(par, a.problem)
     run.integrator = a.integrator
+    run.order = a.order
     t_setup = time.time()
     drv = driver.Driver(run, None, rank, world, local)
     if a.ionized_slab:
@@ -243,7 +245,7 @@ def main():
             "data": "synthetic (deck values on a uniform grid, generated in place"
                     + ("; neutral fraction reset to 1e-4 everywhere: fully ionized slab" if a.ionized_slab else "") + ")",
             "config": {"workload": f"{a.problem} {nx}x{nx}x{nx * world} single level, "
-                                   + ("CTU+PLM+Roe+H-correction" if a.integrator == "ctu" else "VL+PLM+Roe")
+                                   + ((f"CTU+{'PPM' if a.order == 3 else 'PLM'}+Roe+H-correction") if a.integrator == "ctu" else "VL+PLM+Roe")
                                    + (" + static gravity + plane-parallel ion radiation" if a.problem == "ioniz_sphere"
                                       else (" + plane-parallel ion radiation" if a.problem == "ifront" else "")),
                        "zones_per_gpu": nx ** 3, "partition": f"x3 slabs x{world}", "nvar": 5 + run.nscal,

@@ -43,6 +43,8 @@ typedef struct aa_params {
                               1: van Leer, no H-correction (--with-integrator=vl)              */
   int    level;            /* DomainS.Level (static mesh refinement): dx = root dx / 2^level
                               (init_mesh.c:245); 0 for a single-level run                      */
+  int    order;            /* configure --with-order: 2 (or 0) piecewise linear, lr_states_plm.c;
+                              3 piecewise parabolic, lr_states_ppm.c (CTU integrator only)    */
 } aa_params;
 
 typedef struct aa_grid aa_grid;
@@ -148,6 +150,8 @@ int aa_test_fluxes(int nscal, double gamma, int n, const double *Ul, const doubl
                    const double *etah, double *F);                      /* roe.c:59        */
 int aa_test_lr_states(int nscal, double gamma, int n, const double *W, double dt, double dx,
                       int il, int iu, double *Wl, double *Wr);          /* lr_states_plm.c:62 */
+int aa_test_lr_states_ppm(int nscal, double gamma, int n, const double *W, double dt, double dx,
+                          int il, int iu, double *Wl, double *Wr);      /* lr_states_ppm.c:91  */
 
 /* ---- dump_history.c:157-200: volume integrals over the active zones of this Grid, in the column
  *      order of the .hst file: mass, total E, x1/x2/x3 Mom., x1/x2/x3-KE, scalar 0 (0 if NSCALARS=0).

@@ -118,6 +118,51 @@ def test_blast_golden_fixture(aa, lib):
     g.close()
 
 
+@pytest.mark.parametrize("nscal", [0, 1])
+def test_ppm_pencils_vs_reference_vectors(lib, nscal):
+    """--with-order=3: lr_states_ppm.c on 2048-cell pencils (vectors from the reference's own routine),
+    strict build bit for bit, incl. the scalar column whose work arrays overlap in the reference."""
+    g = np.load(os.path.join(GOLD, f"kernels_ppm_nscal{nscal}.npz"))
+    Wp = np.ascontiguousarray(g["Wp"])
+    for strict in (True, False):
+        L = lib.load(strict)
+        Wl = np.zeros_like(Wp); Wr = np.zeros_like(Wp)
+        assert L.aa_test_lr_states_ppm(nscal, float(g["gamma"]), Wp.shape[0], _dp(Wp), float(g["dt"]), float(g["dx"]),
+                                       int(g["il"]), int(g["iu"]), _dp(Wl), _dp(Wr)) == 0
+        if strict:
+            assert np.array_equal(Wl, g["Wl"]) and np.array_equal(Wr, g["Wr"])
+        else:
+            assert np.allclose(Wl, g["Wl"], rtol=1e-11, atol=1e-12) and np.allclose(Wr, g["Wr"], rtol=1e-11, atol=1e-12)
+
+
+@pytest.mark.parametrize("strict", [True, False])
+@pytest.mark.parametrize("name", ["ppm_blast_16x12x20_n5", "ppm_ifront_16x8x8_n4", "ppm_ioniz_sphere_32x32x32_n2"])
+def test_ppm_golden_fixtures(aa, lib, name, strict):
+    """Whole runs of the reference configured with --with-order=3 (CTU + PPM + Roe + H-correction)."""
+    gz = np.load(os.path.join(GOLD, name + ".npz"))
+    prob = name[4:].rsplit("_", 2)[0]
+    nx = tuple(int(x) for x in gz["nx"])
+    ov = [f"domain1/Nx{d + 1}={nx[d]}" for d in range(3)] + [str(o) for o in gz["overrides"]]
+    run = aa.config.load(os.path.join(orc.DECKS, "athinput." + prob), ov, prob)
+    run.order = 3
+    g = lib.setup_problem(aa.config.slab(run), 0, strict)
+    nv = 5 + run.nscal
+    g.start()
+    niter = [g.step() for _ in range(int(gz["nstep"]))]
+    U = g.download()[4:-4, 4:-4, 4:-4, :nv]
+    if not run.ion:
+        if strict:
+            assert g.time == float(gz["time"]) and g.dt == float(gz["dt"])
+            assert np.array_equal(U, gz["U"][..., :nv]), relerr(U, gz["U"][..., :nv])
+        else:
+            assert max(relerr(U, gz["U"][..., :nv])) < 1e-11
+    else:
+        assert niter == [int(x) for x in gz["niter"]]
+        assert abs(g.time / float(gz["time"]) - 1) < 1e-9
+        assert max(relerr(U, gz["U"][..., :nv])) < 1e-8, relerr(U, gz["U"][..., :nv])     # north_star: 1e-6
+    g.close()
+
+
 @pytest.mark.parametrize("strict", [True, False])
 @pytest.mark.parametrize("name", ["shkset1d_d1_48x8x6_n12", "shkset1d_d2_6x48x8_n12", "shkset1d_d3_8x6x48_n12"])
 def test_sod_shock_tube_golden_fixtures(aa, lib, name, strict):
