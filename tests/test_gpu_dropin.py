@@ -152,3 +152,36 @@ def test_reference_smr_driver_on_gpu_library(fixture, cfg, env):
         scale = np.abs(b).max(axis=(0, 1, 2)); scale[scale == 0] = 1
         e = (np.abs(a - b).max(axis=(0, 1, 2)) / scale).max()
         assert e < 1e-8, (l, e)                  # north_star bar: 1e-6
+
+
+def test_restart_of_the_reference_driver_on_gpu_library():
+    """`athena -r file.rst` through the reference's own restart_grids() (restart.c:52-456) and main():
+    the host block it fills reaches the device on the shim's first call, time / dt / nstep travel in
+    MeshS.  A run restarted from its own step-2 dump must arrive at step 4 exactly where the straight
+    run does (the same library computes both: bit for bit)."""
+    if not os.path.exists(os.path.join(REFBIN, "athena_blast_amd")):
+        pytest.skip("oracle/_ref drop-in executables not built (make -C oracle ref)")
+    from make_golden import read_rst
+    nx = (20, 16, 12)
+    tmp = tempfile.mkdtemp(prefix="dropin_rst_")
+    deck = os.path.join(tmp, "athinput")
+    text = open(os.path.join(ROOT, "atmospheric-athena_amd", "decks", "athinput.blast")).read()
+    text = text.replace("maxout      = 0", "maxout      = 1") + "\n<output1>\nout_fmt = rst\ndt = 1e300\n"
+    open(deck, "w").write(text)
+    size = [f"domain1/Nx1={nx[0]}", f"domain1/Nx2={nx[1]}", f"domain1/Nx3={nx[2]}"]
+    exe = os.path.join(REFBIN, "athena_blast_amd")
+
+    def go(args, rundir):
+        pr = subprocess.run([exe] + args + ["-d", os.path.join(tmp, rundir)], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                            text=True, cwd=tmp, timeout=600)
+        assert pr.returncode == 0, pr.stdout[-1500:] + pr.stderr[-1500:]
+        d = os.path.join(tmp, rundir)
+        return sorted(os.path.join(d, f) for f in os.listdir(d) if f.endswith(".rst"))
+
+    straight = go(["-i", deck, "time/nlim=4"] + size, "a")
+    half = go(["-i", deck, "time/nlim=2"] + size, "b")
+    resumed = go(["-r", half[-1], "time/nlim=4"], "c")
+    a = read_rst(straight[-1], nx, 0, False); c = read_rst(resumed[-1], nx, 0, False)
+    shutil.rmtree(tmp)
+    assert a["nstep"] == c["nstep"] == 4 and a["time"] == c["time"] and a["dt"] == c["dt"]
+    assert np.array_equal(a["U"][..., :5], c["U"][..., :5])
