@@ -246,6 +246,10 @@ def smr_runs():
          + ["domain1/bc_ix1=2", "domain1/bc_ox1=2", "domain1/bc_ix2=2", "domain1/bc_ox2=2", "domain1/bc_ix3=1",
             "domain1/bc_ox3=1", "domain1/x2min=-0.5", "domain1/x2max=0.5", "problem/radius=0.3"]),
     ]
+    # the same 2-level blast with the van Leer integrator and with third-order reconstruction
+    two = ["job/num_domains=2"] + dom(1, (16, 24, 16)) + dom(2, (12, 16, 20), (8, 20, 6))
+    cases += [("smr_vl_blast_2lev_s5", "blast_smr_vl", blast, ["job/maxout=1", "output1/out_fmt=rst", "output1/dt=1e300"], 5, 0, False, two),
+              ("smr_ppm_blast_2lev_s5", "blast_smr_ppm", blast, ["job/maxout=1", "output1/out_fmt=rst", "output1/dt=1e300"], 5, 0, False, two)]
     for name, cfg, deck, refextra, nlim, nscal, ion, over in cases:
         nlev = int(over[0].split("=")[1])
         nxs = [tuple(int(next(o for o in over if o.startswith(f"domain{n}/Nx{d}=")).split("=")[1]) for d in (1, 2, 3))

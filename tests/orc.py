@@ -261,11 +261,12 @@ class Mesh:
     nstep = property(lambda s: s.L.orc_mesh_nstep(s.h))
 
 
-def make_mesh(problem, deck_path=None, overrides=None, integrator="ctu"):
+def make_mesh(problem, deck_path=None, overrides=None, integrator="ctu", order=2):
     aa = importlib.import_module("atmospheric-athena_amd")
     par = aa.athinput.ParTable.from_file(deck_path or os.path.join(DECKS, "athinput." + problem)).cmdline(overrides)
     run = aa.config.from_par(par, problem)
     run.integrator = integrator
+    run.order = order
     return Mesh(aa.config.levels(par, run)).problem()
 
 

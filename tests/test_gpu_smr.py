@@ -29,9 +29,10 @@ def aa():
     return importlib.import_module("atmospheric-athena_amd")
 
 
-def make_gpu_mesh(aa, lib, problem, overrides, strict):
+def make_gpu_mesh(aa, lib, problem, overrides, strict, integrator="ctu", order=2):
     par = aa.athinput.ParTable.from_file(os.path.join(orc.DECKS, "athinput." + problem)).cmdline(overrides)
     run = aa.config.from_par(par, problem)
+    run.integrator, run.order = integrator, order
     return lib.Mesh(aa.config.levels(par, run), 0, strict)
 
 
@@ -43,11 +44,14 @@ def relerr(a, b):
     return out
 
 
-@pytest.mark.parametrize("name", ["smr_blast_3lev_s6", "smr_blast_3lev_edge_s8"])
+@pytest.mark.parametrize("name", ["smr_blast_3lev_s6", "smr_blast_3lev_edge_s8", "smr_vl_blast_2lev_s5", "smr_ppm_blast_2lev_s5"])
 @pytest.mark.parametrize("strict", [True, False])
 def test_blast_three_levels_vs_reference(aa, lib, name, strict):
+    """(also 2 levels with the van Leer integrator and with third-order reconstruction: the reference's
+    --enable-smr --with-integrator=vl and --with-order=3 builds)"""
     g = np.load(os.path.join(GOLD, name + ".npz"))
-    m = make_gpu_mesh(aa, lib, "blast", [str(o) for o in g["overrides"]], strict)
+    m = make_gpu_mesh(aa, lib, "blast", [str(o) for o in g["overrides"]], strict,
+                      "vl" if name.startswith("smr_vl_") else "ctu", 3 if name.startswith("smr_ppm_") else 2)
     try:
         m.start()
         assert m.dt == float(g["dt0"]) if strict else abs(m.dt / float(g["dt0"]) - 1) < 1e-13
