@@ -28,8 +28,11 @@ def make(problem, nx, strict=False):
     return lib.setup_problem(aa.config.slab(run), 0, strict), run
 
 
-def test_blast_512_conservation_and_symmetry():
-    g, run = make("blast", (512, 512, 512))
+@pytest.mark.parametrize("n", [512, 640])
+def test_blast_conservation_and_symmetry(n):
+    """512^3 is BASELINE's size; 640^3 (2.7e8 zones incl. ghosts, 75 fields = 139 GB of the 288 GB) is the
+    largest cube one GPU holds comfortably: field offsets there exceed 2^33 doubles."""
+    g, run = make("blast", (n, n, n))
     U0 = g.host_initial[4:-4, 4:-4, 4:-4]
     tot0 = U0.sum(axis=(0, 1, 2), dtype=np.longdouble)
     g.start()
