@@ -48,6 +48,7 @@ if len(sys.argv) > 5:
              (r"k_sweep_x1<1, true, 3", "sweep_correct_x1"), (r"k_sweep_x1<1, true, 0", "sweep_x1"),
              (r"k_sweep_x1<1, true, 1", "correct_x1"),
              (r"k_sweep_march<1, 1, true, 0", "sweep_x2"), (r"k_sweep_march<1, 2, true, 0", "sweep_x3"),
+             (r"k_slopes<", "ppm_slopes"),
              (r"k_flux2<1, 0", "flux2_x1"), (r"k_flux2<1, 1", "flux2_x2"), (r"k_flux2<1, 2", "flux2_x3")]
     out = {}
     for n in set(fs) | set(ws):
