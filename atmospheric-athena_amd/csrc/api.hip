@@ -253,10 +253,8 @@ int aa_add_radplane_3d(aa_grid *g, int dir, double flux)
 int aa_bvals_mhd(aa_grid *g)
 {
   Scope s(g, "bvals_mhd");
-  for (int d = 0; d < 3; d++) {          // x1, x2, x3 so the corners fill (bvals_mhd.c:170)
-    if (g->p.bc[2*d])     launch_bc(g->d, g->p.nscal, d, 0, g->p.bc[2*d], g->st);
-    if (g->p.bc[2*d + 1]) launch_bc(g->d, g->p.nscal, d, 1, g->p.bc[2*d + 1], g->st);
-  }
+  for (int d = 0; d < 3; d++)            // x1, x2, x3 so the corners fill (bvals_mhd.c:170)
+    launch_bc_dir(g->d, g->p.nscal, d, g->p.bc[2*d], g->p.bc[2*d + 1], g->st);
   return 0;
 }
 
@@ -389,6 +387,39 @@ int aa_ion_update(aa_grid *g, double dt, long long *cellcount, double *dt_hydro)
   return 0;
 }
 
+// One sub-cycle of ion_radtransfer_3d with the step chosen on the device (ionrad_3d.c:919-971): ray
+// sweep, rates, k_ion_pick, update -- and ONE read-back.  `limit` is the hydro dt (root) or the coarse
+// time (refined level).  The first call of an ion step must find the reductions armed (aa_ion_arm).
+int aa_ion_arm(aa_grid *g)
+{
+  DevScalars init; memset(&init, 0, sizeof init);
+  init.dt_chem = double_to_bits(DBL_MAX); init.dt_therm = double_to_bits(DBL_MAX);
+  *g->sc_host = init;
+  HIPCHK(hipMemcpyAsync(g->sc, g->sc_host, sizeof(DevScalars), hipMemcpyHostToDevice, g->st));
+  return 0;
+}
+int aa_ion_subcycle(aa_grid *g, double dt_done, double limit, double *dt, int *limit_hit, double *dt_chem,
+                    double *dt_therm, long long *cellcount, double *dt_hydro)
+{
+  if (g->nradplane > 0) {
+    const Real flux0 = g->flux_i*(5.*(erf((g->time - 1.2e5)/8e4)+1)+0.1);     // ionradplane_3d.c:265
+    Scope s(g, "ray_sweep");
+    launch_ray_sweep(g->d, g->ion, flux0, g->level > 0, g->st);
+  } else {
+    HIPCHK(hipMemsetAsync(g->d.ph_rate, 0, (size_t)g->d.nc*sizeof(Real), g->st));
+  }
+  { Scope s(g, "ion_rates"); launch_ion_rates(g->d, g->ion, g->sc, g->st); }
+  launch_ion_pick(g->sc, dt_done, limit, g->st);
+  { Scope s(g, "ion_update"); launch_ion_update_sel(g->d, g->ion, g->sc, g->st); }
+  int rc = fetch_scalars(g); if (rc) return rc;
+  if (g->sc_host->neg_out) return fail(-4, "[compute_chem_rates]: negative dt_chem");   // ionrad_3d.c:389-391
+  *dt = g->sc_host->dt_sel; *limit_hit = g->sc_host->limit_hit;
+  *dt_chem = g->sc_host->dt_chem_out; *dt_therm = g->sc_host->dt_therm_out;
+  *cellcount = (long long)g->sc_host->cellcount;
+  *dt_hydro = g->p.cour_no/bits_to_double(g->sc_host->max_dti);
+  return 0;
+}
+
 int aa_ion_radtransfer_3d(aa_grid *g, int *niter_out)
 {
   // ionrad_3d.c:862-1047, root level
@@ -396,11 +427,9 @@ int aa_ion_radtransfer_3d(aa_grid *g, int *niter_out)
   long long cellcount;
   int niter = 0, hydro_done = 0, rc;
   if ((rc = aa_ion_begin(g))) return rc;
+  if ((rc = aa_ion_arm(g))) return rc;
   while (!hydro_done) {
-    if ((rc = aa_ion_rates(g, &dt_chem, &dt_therm))) return rc;
-    dt = (dt_therm < dt_chem) ? dt_therm : dt_chem;
-    if (dt_done + dt > g->dt) { dt = g->dt - dt_done; hydro_done = 1; }
-    if ((rc = aa_ion_update(g, dt, &cellcount, &dt_hydro))) return rc;
+    if ((rc = aa_ion_subcycle(g, dt_done, g->dt, &dt, &hydro_done, &dt_chem, &dt_therm, &cellcount, &dt_hydro))) return rc;
     dt_done += dt;
     niter++;
     if (cellcount > MAXCELLCOUNT) { g->dt = dt_done; break; }

@@ -52,3 +52,8 @@ struct Scope {
 static inline double bits_to_double(unsigned long long b) { double x; memcpy(&x, &b, 8); return x; }
 static inline unsigned long long double_to_bits(double x) { unsigned long long b; memcpy(&b, &x, 8); return b; }
 extern "C" int aa_fetch_scalars(aa_grid *g);     // DevScalars device -> pinned host, synchronous
+// one radiation sub-cycle with the step chosen on the device (api.hip); used by the single-Grid and the
+// Mesh drivers (the multi-rank drivers need the reductions on the host and use aa_ion_rates/_update)
+extern "C" int aa_ion_arm(aa_grid *g);
+extern "C" int aa_ion_subcycle(aa_grid *g, double dt_done, double limit, double *dt, int *limit_hit, double *dt_chem,
+                               double *dt_therm, long long *cellcount, double *dt_hydro);

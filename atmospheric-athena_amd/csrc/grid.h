@@ -61,6 +61,10 @@ struct DevScalars {
   unsigned long long cellcount;      // check_range
   int neg_dt_chem;                   // error flag (ionrad_3d.c:389-391)
   int pad;
+  // written by k_ion_pick (the step of one sub-cycle chosen on the device, so that the host reads the
+  // scalars once per sub-cycle): the dt handed to k_ion_update, the values it was derived from
+  Real dt_sel, dt_chem_out, dt_therm_out;
+  int limit_hit, neg_out;
 };
 
 // ---- launch wrappers (hydro_kernels.hip) ------------------------------------------
@@ -74,6 +78,7 @@ void launch_vl_flux1(const DevGrid &g, int nscal, int dir, hipStream_t st);
 void launch_vl_uhalf(const DevGrid &g, int nscal, Real dt, bool grav, hipStream_t st);
 void launch_vl_flux2(const DevGrid &g, int nscal, int dir, Real dt, hipStream_t st);
 void launch_bc(const DevGrid &g, int nscal, int dir, int side, int flag, hipStream_t st);
+void launch_bc_dir(const DevGrid &g, int nscal, int dir, int flag_in, int flag_out, hipStream_t st);   // both sides, one launch
 void launch_cfl(const DevGrid &g, DevScalars *sc, hipStream_t st);
 int  launch_history(const DevGrid &g, int nscal, Real *partial, hipStream_t st);   // returns the number of partial rows
 void launch_aos_to_soa(const DevGrid &g, int nvar, const Real *aos, hipStream_t st);
@@ -94,6 +99,8 @@ void launch_ion_begin(const DevGrid &g, const IonPar &p, hipStream_t st);
 void launch_ray_sweep(const DevGrid &g, const IonPar &p, Real flux0, bool from_edgeflux, hipStream_t st);
 void launch_ion_rates(const DevGrid &g, const IonPar &p, DevScalars *sc, hipStream_t st);
 void launch_ion_update(const DevGrid &g, const IonPar &p, Real dt, DevScalars *sc, hipStream_t st);
+void launch_ion_pick(DevScalars *sc, Real dt_done, Real dt_limit, hipStream_t st);      // ionrad_3d.c:941-963 on the device
+void launch_ion_update_sel(const DevGrid &g, const IonPar &p, DevScalars *sc, hipStream_t st);   // dt = sc->dt_sel
 void launch_edgeflux_bc(const DevGrid &g, Real flux_i, hipStream_t st);
 
 }  // namespace aa

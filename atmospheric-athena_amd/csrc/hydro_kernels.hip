@@ -531,8 +531,10 @@ k_vl_uhalf(DevGrid g, Real dt)
 
 // ---- physical boundary conditions: bvals_mhd.c reflect :959, outflow :1319, periodic :1637 ---
 // dir d, side 0/1; transverse extents: x1 -> active j,k; x2 -> all i, active k; x3 -> all i,j.
-__global__ void k_bc(DevGrid g, int nvar, int d, int side, int flag)
+// side < 0: both sides in one launch, blockIdx.y = side, (flag, flag1) = the two flags (0 = leave alone)
+__global__ void k_bc(DevGrid g, int nvar, int d, int side, int flag, int flag1)
 {
+  if (side < 0) { side = blockIdx.y; if (side) flag = flag1; if (!flag) return; }
   const int lo3[3] = {g.is, g.js, g.ks}, hi3[3] = {g.ie, g.je, g.ke}, N[3] = {g.N1, g.N2, g.N3};
   int r0[3], n[3];
   for (int a = 0; a < 3; a++) {
@@ -842,7 +844,17 @@ void launch_bc(const DevGrid &g, int nscal, int dir, int side, int flag, hipStre
   const int lo3[3] = {g.is, g.js, g.ks}, hi3[3] = {g.ie, g.je, g.ke}, N[3] = {g.N1, g.N2, g.N3};
   long n = 1;
   for (int a = 0; a < 3; a++) n *= (a == dir) ? 4 : (a < dir ? N[a] : hi3[a] - lo3[a] + 1);
-  hipLaunchKernelGGL(k_bc, dim3(nblk(n, 256)), dim3(256), 0, st, g, 5 + nscal, dir, side, flag);
+  hipLaunchKernelGGL(k_bc, dim3(nblk(n, 256)), dim3(256), 0, st, g, 5 + nscal, dir, side, flag, 0);
+}
+// the two sides of one direction never read each other's ghost zones (sources are active zones along
+// `dir`, bvals_mhd.c:959-2317): one launch for both
+void launch_bc_dir(const DevGrid &g, int nscal, int dir, int flag_in, int flag_out, hipStream_t st)
+{
+  if (!flag_in && !flag_out) return;
+  const int lo3[3] = {g.is, g.js, g.ks}, hi3[3] = {g.ie, g.je, g.ke}, N[3] = {g.N1, g.N2, g.N3};
+  long n = 1;
+  for (int a = 0; a < 3; a++) n *= (a == dir) ? 4 : (a < dir ? N[a] : hi3[a] - lo3[a] + 1);
+  hipLaunchKernelGGL(k_bc, dim3(nblk(n, 256), 2), dim3(256), 0, st, g, 5 + nscal, dir, -1, flag_in, flag_out);
 }
 
 void launch_cfl(const DevGrid &g, DevScalars *sc, hipStream_t st)

@@ -316,8 +316,9 @@ __global__ void k_edgeflux_bc(DevGrid g, Real flux_i)
 
 // ---- update + floors + range check + hydro CFL --------------------------------------------------
 __global__ void __launch_bounds__(256)
-k_ion_update(DevGrid g, IonPar p, Real dt, DevScalars *sc)
+k_ion_update(DevGrid g, IonPar p, Real dt_arg, DevScalars *sc, int dt_from_sc)
 {
+  const Real dt = dt_from_sc ? sc->dt_sel : dt_arg;
   __shared__ Real red[256];
   __shared__ unsigned int cnt;
   if (threadIdx.x == 0) cnt = 0;
@@ -404,7 +405,27 @@ void launch_ion_rates(const DevGrid &g, const IonPar &p, DevScalars *sc, hipStre
   hipLaunchKernelGGL(k_ion_rates, dim3(nb), dim3(256), 0, st, g, p, sc); }
 void launch_ion_update(const DevGrid &g, const IonPar &p, Real dt, DevScalars *sc, hipStream_t st)
 { const long n = (long)g.Nx1*g.Nx2*g.Nx3; unsigned nb = nblk(n, 256); if (nb > 4096) nb = 4096;
-  hipLaunchKernelGGL(k_ion_update, dim3(nb), dim3(256), 0, st, g, p, dt, sc); }
+  hipLaunchKernelGGL(k_ion_update, dim3(nb), dim3(256), 0, st, g, p, dt, sc, 0); }
+void launch_ion_update_sel(const DevGrid &g, const IonPar &p, DevScalars *sc, hipStream_t st)
+{ const long n = (long)g.Nx1*g.Nx2*g.Nx3; unsigned nb = nblk(n, 256); if (nb > 4096) nb = 4096;
+  hipLaunchKernelGGL(k_ion_update, dim3(nb), dim3(256), 0, st, g, p, 0.0, sc, 1); }
+
+// ionrad_3d.c:941-963 for one sub-cycle, on the device: dt = MIN(dt_therm, dt_chem), cut back to what is
+// left of the hydro step (root) or of the coarse time (refined level).  Also re-arms the reductions of the
+// next round, so that a sub-cycle costs one read-back of the scalars instead of two plus two resets.
+__global__ void k_ion_pick(DevScalars *sc, Real dt_done, Real dt_limit)
+{
+  const Real dt_chem = __longlong_as_double((long long)sc->dt_chem), dt_therm = __longlong_as_double((long long)sc->dt_therm);
+  Real dt = (dt_therm < dt_chem) ? dt_therm : dt_chem;
+  int hit = 0;
+  if (dt_done + dt > dt_limit) { dt = dt_limit - dt_done; hit = 1; }
+  sc->dt_sel = dt; sc->limit_hit = hit;
+  sc->dt_chem_out = dt_chem; sc->dt_therm_out = dt_therm; sc->neg_out = sc->neg_dt_chem;
+  sc->dt_chem = (unsigned long long)__double_as_longlong(DBL_MAX); sc->dt_therm = sc->dt_chem; sc->neg_dt_chem = 0;
+  sc->max_dti = 0; sc->cellcount = 0;
+}
+void launch_ion_pick(DevScalars *sc, Real dt_done, Real dt_limit, hipStream_t st)
+{ hipLaunchKernelGGL(k_ion_pick, dim3(1), dim3(1), 0, st, sc, dt_done, dt_limit); }
 void launch_edgeflux_bc(const DevGrid &g, Real flux_i, hipStream_t st)
 { const long n = (long)(g.Nx2 + 1)*(g.Nx3 + 1); hipLaunchKernelGGL(k_edgeflux_bc, dim3(nblk(n, 256)), dim3(256), 0, st, g, flux_i); }
 

@@ -497,12 +497,11 @@ int aa_mesh_ion_radtransfer(aa_mesh *m, int l, int *niter_out)
   if (finegrid) { if ((rc = aa_mesh_ionflux_prolong(m, l))) return rc; }
   else m->tcoarse = 0;
   if ((rc = aa_ion_begin(g))) return rc;
+  if ((rc = aa_ion_arm(g))) return rc;
   while (finegrid || !hydro_done) {
-    if ((rc = aa_ion_rates(g, &dt_chem, &dt_therm))) return rc;
-    dt = (dt_therm < dt_chem) ? dt_therm : dt_chem;
-    if (!finegrid) { if (dt_done + dt > g->dt) { dt = g->dt - dt_done; hydro_done = 1; } }
-    else           { if (dt_done + dt > m->tcoarse) { dt = m->tcoarse - dt_done; coarsetime_done = 1; } }
-    if ((rc = aa_ion_update(g, dt, &cellcount, &dt_hydro))) return rc;
+    int hit = 0;
+    if ((rc = aa_ion_subcycle(g, dt_done, finegrid ? m->tcoarse : g->dt, &dt, &hit, &dt_chem, &dt_therm, &cellcount, &dt_hydro))) return rc;
+    if (finegrid) coarsetime_done = hit; else hydro_done = hit;
     dt_done += dt;
     niter++;
     if (!finegrid) {
