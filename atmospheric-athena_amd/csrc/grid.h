@@ -79,6 +79,7 @@ void launch_vl_uhalf(const DevGrid &g, int nscal, Real dt, bool grav, hipStream_
 void launch_vl_flux2(const DevGrid &g, int nscal, int dir, Real dt, hipStream_t st);
 void launch_bc(const DevGrid &g, int nscal, int dir, int side, int flag, hipStream_t st);
 void launch_bc_dir(const DevGrid &g, int nscal, int dir, int flag_in, int flag_out, hipStream_t st);   // both sides, one launch
+unsigned reduce_blocks(long nzones);      // launch size of the grid-stride reduction kernels
 void launch_cfl(const DevGrid &g, DevScalars *sc, hipStream_t st);
 int  launch_history(const DevGrid &g, int nscal, Real *partial, hipStream_t st);   // returns the number of partial rows
 void launch_aos_to_soa(const DevGrid &g, int nvar, const Real *aos, hipStream_t st);

@@ -720,6 +720,10 @@ static Order zone_order()
   }
   return o;
 }
+// Grid-stride reduction kernels end in a few same-address atomics per block (one word sustains ~90
+// atomics/us): at least 8 zones per thread, between 256 and 4096 blocks.
+unsigned reduce_blocks(long n)
+{ long nb = (n + 256L*8 - 1)/(256L*8); if (nb < 256) nb = 256; if (nb > 4096) nb = 4096; if (nb*256 > n) nb = (n + 255)/256; return (unsigned)nb; }
 static inline unsigned nblk8(long n, int b) { unsigned x = nblk(n, b); return ((x + 7u)/8u)*8u; }   // for xcd_block()
 
 template <int NS, bool GRAV, int MODE, int ORD>
@@ -744,10 +748,14 @@ static void sweep_impl_o(const DevGrid &g, const Real *src, int dir, Real dt, hi
     if (dir == 1) hipLaunchKernelGGL((k_sweep_tile<NS, 1, GRAV, MODE, BT, ORD>), grid, blk, lds, st, g, src, dt);
     else          hipLaunchKernelGGL((k_sweep_tile<NS, 2, GRAV, MODE, BT, ORD>), grid, blk, lds, st, g, src, dt);
   } else {
-    const int chunk = 32;
     const long ni = g.ie - g.is + 5;
     const long nt = (dir == 1 ? g.ke - g.ks : g.je - g.js) + 5;
     const int nfaces = (dir == 1 ? g.je - g.js : g.ke - g.ks) + 1 + 3;
+    // 32 interfaces per thread amortise the 3-cell start-up of a chunk on big Grids; small Grids need the
+    // parallelism more (80^3 has only 110 wavefronts of columns): halve the chunk until the launch has
+    // a few wavefronts per SIMD (1024 SIMDs)
+    int chunk = 32;
+    while (chunk > 4 && (long)nblk(ni*nt, 64)*((nfaces + chunk - 1)/chunk) < 4096) chunk >>= 1;
     dim3 grid(nblk(ni*nt, 64), (nfaces + chunk - 1)/chunk);
     if (dir == 1) hipLaunchKernelGGL((k_sweep_march<NS, 1, GRAV, MODE, ORD>), grid, dim3(64), 0, st, g, src, dt, chunk);
     else          hipLaunchKernelGGL((k_sweep_march<NS, 2, GRAV, MODE, ORD>), grid, dim3(64), 0, st, g, src, dt, chunk);
@@ -860,7 +868,7 @@ void launch_bc_dir(const DevGrid &g, int nscal, int dir, int flag_in, int flag_o
 void launch_cfl(const DevGrid &g, DevScalars *sc, hipStream_t st)
 {
   const long n = (long)(g.ie - g.is + 1)*(g.je - g.js + 1)*(g.ke - g.ks + 1);
-  unsigned nb = nblk(n, 256); if (nb > 4096) nb = 4096;
+  const unsigned nb = reduce_blocks(n);
   hipLaunchKernelGGL(k_cfl, dim3(nb), dim3(256), 0, st, g, sc);
 }
 

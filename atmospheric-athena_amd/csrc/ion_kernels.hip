@@ -401,13 +401,13 @@ void launch_ion_begin(const DevGrid &g, const IonPar &p, hipStream_t st)
 void launch_ray_sweep(const DevGrid &g, const IonPar &p, Real flux0, bool from_edgeflux, hipStream_t st)
 { hipLaunchKernelGGL(k_ray_sweep, dim3((g.Nx2 + RS_RAYS - 1)/RS_RAYS, g.Nx3), dim3(256), 0, st, g, p, flux0, from_edgeflux ? 1 : 0); }
 void launch_ion_rates(const DevGrid &g, const IonPar &p, DevScalars *sc, hipStream_t st)
-{ const long n = (long)g.Nx1*g.Nx2*g.Nx3; unsigned nb = nblk(n, 256); if (nb > 4096) nb = 4096;
+{ const long n = (long)g.Nx1*g.Nx2*g.Nx3; const unsigned nb = reduce_blocks(n);
   hipLaunchKernelGGL(k_ion_rates, dim3(nb), dim3(256), 0, st, g, p, sc); }
 void launch_ion_update(const DevGrid &g, const IonPar &p, Real dt, DevScalars *sc, hipStream_t st)
-{ const long n = (long)g.Nx1*g.Nx2*g.Nx3; unsigned nb = nblk(n, 256); if (nb > 4096) nb = 4096;
+{ const long n = (long)g.Nx1*g.Nx2*g.Nx3; const unsigned nb = reduce_blocks(n);
   hipLaunchKernelGGL(k_ion_update, dim3(nb), dim3(256), 0, st, g, p, dt, sc, 0); }
 void launch_ion_update_sel(const DevGrid &g, const IonPar &p, DevScalars *sc, hipStream_t st)
-{ const long n = (long)g.Nx1*g.Nx2*g.Nx3; unsigned nb = nblk(n, 256); if (nb > 4096) nb = 4096;
+{ const long n = (long)g.Nx1*g.Nx2*g.Nx3; const unsigned nb = reduce_blocks(n);
   hipLaunchKernelGGL(k_ion_update, dim3(nb), dim3(256), 0, st, g, p, 0.0, sc, 1); }
 
 // ionrad_3d.c:941-963 for one sub-cycle, on the device: dt = MIN(dt_therm, dt_chem), cut back to what is
