@@ -83,10 +83,15 @@ def bench_smr(a, aa, torch, rank, world, local):
     deck = os.path.join(ROOT, PKG, "decks", "athinput." + a.problem)
     par = aa.athinput.ParTable.from_file(deck)
     x3min, x3max = par.getd("domain1", "x3min"), par.getd("domain1", "x3max")
-    par.cmdline(["job/num_domains=2", f"domain1/Nx1={nx}", f"domain1/Nx2={nx}", f"domain1/Nx3={nx * world}",
-                 f"domain1/x3max={x3min + (x3max - x3min) * world!r}",
-                 f"domain2/Nx1={nx}", f"domain2/Nx2={nx}", f"domain2/Nx3={nx * world}",
-                 f"domain2/iDisp={nx // 2}", f"domain2/jDisp={nx // 2}", f"domain2/kDisp={nx * world // 2}"])
+    if a.smr_deck:
+        if world != 1:
+            sys.exit("--smr-deck is a one-GPU measurement")
+        par.cmdline(["job/num_domains=2"])
+    else:
+        par.cmdline(["job/num_domains=2", f"domain1/Nx1={nx}", f"domain1/Nx2={nx}", f"domain1/Nx3={nx * world}",
+                     f"domain1/x3max={x3min + (x3max - x3min) * world!r}",
+                     f"domain2/Nx1={nx}", f"domain2/Nx2={nx}", f"domain2/Nx3={nx * world}",
+                     f"domain2/iDisp={nx // 2}", f"domain2/jDisp={nx // 2}", f"domain2/kDisp={nx * world // 2}"])
     run = aa.config.from_par(par, a.problem)
     run.integrator = a.integrator
     t_setup = time.time()
@@ -124,13 +129,16 @@ def bench_smr(a, aa, torch, rank, world, local):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     zones = 2 * nx ** 3 * world
+    lv = aa.config.levels(par, run)
+    if a.smr_deck:
+        zones = sum(g.Nx[0] * g.Nx[1] * g.Nx[2] for g in lv)
     if rank == 0:
         out = {"metric": "cell-updates/sec (hydro+ion-rad step)", "value": zones * a.steps / elapsed, "unit": "cell-updates/s",
                "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * elapsed / a.steps,
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
                "data": "synthetic (deck values on a nested 2-level mesh, generated in place)",
-               "config": {"workload": f"{a.problem} 2-level SMR: root {nx}x{nx}x{nx * world} + level 1 {nx}x{nx}x{nx * world} over the "
-                                      "central half (zones of both levels counted, as the reference's zone-cycles do)",
+               "config": {"workload": f"{a.problem} 2-level SMR: " + " + ".join(f"level {g.level} {g.Nx[0]}x{g.Nx[1]}x{g.Nx[2]}" for g in lv)
+                                      + " (zones of both levels counted, as the reference's zone-cycles do)",
                           "zones": zones, "partition": (f"x3 cuts {list(m.cfg.cuts)} shared by both levels" if multi else "one aa_mesh"),
                           "subcycle_trace_per_level": trace, "final_dt": m.dt,
                           "hbm_resident_GB_rank0": sum(g.device_bytes() for g in grids) / 1e9, "setup_s": t_setup}}
@@ -160,6 +168,9 @@ def main():
     ap.add_argument("--smr", action="store_true",
                     help="BASELINE.json configs[4]: 2-level static mesh refinement, per GPU a root slab of nx^3 zones plus "
                          "nx^3 level-1 zones over the central half of the box (not the headline line)")
+    ap.add_argument("--smr-deck", action="store_true",
+                    help="with --smr: the deck's own root and level-1 Domains (80^3 + 52^3, the first two levels of "
+                         "tst/massloss/athinput.ioniz_sphere_hires) instead of nx^3 + nx^3")
     ap.add_argument("--ionized-slab", action="store_true",
                     help="SURVEY 8(d) worst case for the ray sweep: neutral fraction 1e-4 everywhere, so every ray crosses the whole box")
     ap.add_argument("--no-cpu-baseline", action="store_true")
