@@ -239,17 +239,22 @@ k_sweep_march(DevGrid g, const Real *src, Real dt, int chunk)
   const long base = (D == 1) ? ((long)t*g.sK + i) : ((long)t*g.sJ + i);
   const Real dtodx = dt/g.dx[D];
 
+  // ONE inlined instance of the reconstruction serves every cell, also the cell below the chunk's
+  // first interface (iteration f0-1, whose face work is skipped): with fused multiply-adds allowed, two
+  // instances may round differently, and the result must not depend on where the chunks start (the
+  // chunk size follows the Grid size, hence the decomposition).
   Real wm[6], w[6], wp[6], wl_cur[6], wl_next[6], wr[6], u[6];
-  load_sweep<D, NS>(src, g.nc, base + (long)(f0 - 2)*s, u); cons_to_prim<NS>(u, wm, g.Gamma_1);
-  load_sweep<D, NS>(src, g.nc, base + (long)(f0 - 1)*s, u); cons_to_prim<NS>(u, w,  g.Gamma_1);
-  load_sweep<D, NS>(src, g.nc, base + (long)(f0    )*s, u); cons_to_prim<NS>(u, wp, g.Gamma_1);
-  recon_cell<NS, MODE != MODE_VL, ORD, D>(g, base + (long)(f0 - 1)*s, wm, w, wp, dtodx, wl_cur, wr);    // cell f0-1 -> Wl[f0]
-  for (int f = f0; f <= f1; f++) {
+  load_sweep<D, NS>(src, g.nc, base + (long)(f0 - 2)*s, u); cons_to_prim<NS>(u, w,  g.Gamma_1);
+  load_sweep<D, NS>(src, g.nc, base + (long)(f0 - 1)*s, u); cons_to_prim<NS>(u, wp, g.Gamma_1);
+#pragma unroll
+  for (int n = 0; n < 6; n++) wl_cur[n] = 0.0;
+#pragma nounroll
+  for (int f = f0 - 1; f <= f1; f++) {
 #pragma unroll
     for (int n = 0; n < 6; n++) { wm[n] = w[n]; w[n] = wp[n]; }
     load_sweep<D, NS>(src, g.nc, base + (long)(f + 1)*s, u); cons_to_prim<NS>(u, wp, g.Gamma_1);
     recon_cell<NS, MODE != MODE_VL, ORD, D>(g, base + (long)f*s, wm, w, wp, dtodx, wl_next, wr);  // cell f -> Wl[f+1], Wr[f]
-    face_work<NS, D, GRAV, MODE>(g, base + (long)f*s, i, D == 1 ? f : t, D == 1 ? t : f, dt, wl_cur, wr);
+    if (f >= f0) face_work<NS, D, GRAV, MODE>(g, base + (long)f*s, i, D == 1 ? f : t, D == 1 ? t : f, dt, wl_cur, wr);
 #pragma unroll
     for (int n = 0; n < 6; n++) wl_cur[n] = wl_next[n];
   }
