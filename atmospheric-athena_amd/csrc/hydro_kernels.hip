@@ -743,7 +743,7 @@ static void sweep_impl_o(const DevGrid &g, const Real *src, int dir, Real dt, hi
     dim3 grid(nb, g.je - g.js + 5, g.ke - g.ks + 5);
     size_t lds = (size_t)(5 + NS)*(B + 2)*sizeof(Real);
     hipLaunchKernelGGL((k_sweep_x1<NS, GRAV, MODE, ORD>), grid, dim3(B), lds, st, g, src, dt);
-  } else if (MODE == MODE_CORR) {
+  } else if constexpr (MODE == MODE_CORR) {
     constexpr int BT = 8;     // 8 beats 16 (12.0 ms) despite the 10-rows-for-7-faces halo: more blocks in flight
     const long ni = g.ie - g.is + 5;
     const long nt = (dir == 1 ? g.ke - g.ks : g.je - g.js) + 5;
@@ -752,7 +752,7 @@ static void sweep_impl_o(const DevGrid &g, const Real *src, int dir, Real dt, hi
     const size_t lds = (size_t)(5 + NS)*(BT + 2)*64*sizeof(Real);
     if (dir == 1) hipLaunchKernelGGL((k_sweep_tile<NS, 1, GRAV, MODE, BT, ORD>), grid, blk, lds, st, g, src, dt);
     else          hipLaunchKernelGGL((k_sweep_tile<NS, 2, GRAV, MODE, BT, ORD>), grid, blk, lds, st, g, src, dt);
-  } else {
+  } else if constexpr (MODE == MODE_FLUX1 || MODE == MODE_VL) {
     const long ni = g.ie - g.is + 5;
     const long nt = (dir == 1 ? g.ke - g.ks : g.je - g.js) + 5;
     const int nfaces = (dir == 1 ? g.je - g.js : g.ke - g.ks) + 1 + 3;
