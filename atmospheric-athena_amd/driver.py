@@ -300,8 +300,8 @@ class HipMeshEngine:
     def ionflux_prolong(self, l): self.mesh.ionflux_prolong(l)
 
     # flux correction across a cut
-    def flux_buffer(self, n1, n2):
-        key = (n1, n2)
+    def flux_buffer(self, n1, n2, side=0):
+        key = (n1, n2, side)
         if key not in self._fbuf:
             self._fbuf[key] = self.torch.empty(n1 * n2 * 6, dtype=self.torch.float64, device=self.scalar_device)
         return self._fbuf[key]
@@ -416,7 +416,7 @@ class MeshDriver:
                         sends.append((self.eng.flux_x3_export(l + 1, side), peer))
             for (lp, side, src, i0, j0, n1, n2) in self.cfg.corr_in:
                 if lp == l:
-                    buf = self.eng.flux_buffer(n1, n2)
+                    buf = self.eng.flux_buffer(n1, n2, side)
                     recvs.append((buf, src)); todo.append((side, i0, j0, n1, n2, buf))
             self._p2p(sends, recvs)
             for side, i0, j0, n1, n2, buf in todo:

@@ -71,7 +71,7 @@ class OracleMeshEngine:
     def ion_restrict_correct(self): self.mesh.ion_restrict_correct()
     def prolongate(self): self.mesh.prolongate()
     def ionflux_prolong(self, l): self.mesh.ionflux_prolong(l)
-    def flux_buffer(self, n1, n2): return self.torch.empty(n1 * n2 * 6, dtype=self.torch.float64)
+    def flux_buffer(self, n1, n2, side=0): return self.torch.empty(n1 * n2 * 6, dtype=self.torch.float64)
     def flux_x3_export(self, l, side): return self.torch.from_numpy(self.lev[l].flux_x3_export(side).reshape(-1).copy())
     def flux_x3_apply(self, l, side, i0, j0, n1, n2, t): self.lev[l].flux_x3_apply(side, i0, j0, n1, n2, t.numpy())
     def download(self, l): return self.lev[l].U.copy()
