@@ -170,9 +170,10 @@ class Driver:
                 self.eng.unpack_x3(side)
 
     # ---- the reference's call sites ---------------------------------------------------------
-    def bvals_mhd(self):
+    def bvals_mhd(self, exchange: bool = True):
         self.eng.bvals_local()      # x1, x2 and physical x3 faces
-        self.exchange_x3()
+        if exchange:
+            self.exchange_x3()
 
     def new_dt(self):               # new_dt.c:169-185
         dtc = self._min(self.eng.new_dt_local())[0] if self.distributed else self.eng.new_dt_local()
@@ -245,7 +246,10 @@ class Driver:
         self.nstep += 1
         self.time += self.dt
         self.new_dt()
-        self.bvals_mhd()
+        # main.c:635-644.  With radiation on, nothing reads the neighbour's planes before the bvals_mhd
+        # that follows the next ion step (the ion kernels, new_dt and the dumps touch active zones only,
+        # and that call re-sends every field anyway): the x3 halo of this call is left to it.
+        self.bvals_mhd(exchange=not self.eng.has_radiation())
         self.niter_trace.append(niter)
         return niter
 
