@@ -14,6 +14,7 @@ x3 slabs are produced.
 """
 from __future__ import annotations
 
+import os
 from dataclasses import dataclass, field, replace
 from typing import Dict, List, Optional, Sequence, Tuple
 
@@ -197,6 +198,13 @@ def levels(par: ParTable, run: RunConfig) -> List[GridConfig]:
                 bc[2 * d + 1] = 0
         out.append(GridConfig(run=run, rank=0, nranks=1, Nx=Nx, disp=disp, MinX=MinX, bc=tuple(bc),
                               lx3=-1, rx3=-1, level=lev))
+    # ionrad_smr.c:97-98: the coarse->fine radiation hand-off is only defined while the parent is not
+    # displaced across the rays (2 levels); AA_SMR_DEEP_RADIATION=fixed opts into the corrected index
+    if run.ion and os.environ.get("AA_SMR_DEEP_RADIATION") != "fixed":
+        for g in out[1:-1]:
+            if g.disp[1] or g.disp[2]:
+                raise ParError(f"[config]: radiation across a displaced parent (level {g.level}) is undefined in the "
+                               "reference; set AA_SMR_DEEP_RADIATION=fixed for the corrected hand-off")
     return out
 
 

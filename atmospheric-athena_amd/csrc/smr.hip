@@ -305,9 +305,17 @@ int aa_mesh_create(int nlevels, aa_grid **levels, const int *disp, aa_mesh **out
         delete m; return aa_fail(-1, "[init_mesh] child Domain of level %d touches its parent in x%d", l + 1, d + 1);
       }
     }
-    // ionrad_smr.c:97-98 mixes a parent-local index with the child's root-relative Disp
+    // ionrad_smr.c:97-98 mixes a parent-local index with the child's root-relative Disp: with a displaced
+    // parent (3+ levels) the reference writes out of bounds.  Refused by default; AA_SMR_DEEP_RADIATION=fixed
+    // uses the index the formula evidently means (child origin - 2 x parent origin), a documented
+    // departure from the reference for decks like its own 5-level one.
     if (P->p.ion && (dp[1] || dp[2])) {
-      delete m; return aa_fail(-1, "[aa_mesh_create]: radiation across a displaced parent (level %d) is undefined in the reference", l);
+      const char *e = getenv("AA_SMR_DEEP_RADIATION");
+      if (!(e && strcmp(e, "fixed") == 0)) {
+        delete m; return aa_fail(-1, "[aa_mesh_create]: radiation across a displaced parent (level %d) is undefined in the reference "
+                                     "(set AA_SMR_DEEP_RADIATION=fixed for the corrected hand-off)", l);
+      }
+      for (int d = 0; d < 3; d++) L.cdisp[d] = dc[d] - 2*dp[d];
     }
   }
   return mesh_finish(m, levels, out);

@@ -1292,10 +1292,16 @@ OrcMesh *orc_mesh_create(int nlevels, const OrcParams *p, const int *disp)
       L[6+2*d+1] = L[12+2*d+1] = ((dc[d] + p[l+1].Nx[d])/irefine != p[l+1].rootNx[d]);
     }
     /* ionrad_smr.c:97-98 mixes an index local to the parent Grid with the child's root-relative Disp:
-     * only meaningful while the parent is not displaced across the rays */
+     * only meaningful while the parent is not displaced across the rays.  ORC_SMR_DEEP_RADIATION=fixed
+     * selects what the formula evidently means (child origin minus twice the parent's); that mode has
+     * no reference behaviour behind it and only serves to check the product's same-named mode. */
     if (p[0].ion && (dp[1] || dp[2])) {
-      fprintf(stderr, "[orc_mesh_create]: radiation across a displaced parent (level %d) is undefined in the reference\n", l);
-      return NULL;
+      const char *e = getenv("ORC_SMR_DEEP_RADIATION");
+      if (!(e && strcmp(e, "fixed") == 0)) {
+        fprintf(stderr, "[orc_mesh_create]: radiation across a displaced parent (level %d) is undefined in the reference\n", l);
+        return NULL;
+      }
+      for (d = 0; d < 3; d++) L[18+d] = dc[d] - 2*dp[d];
     }
   }
   return orc_mesh_create_local(nlevels, p, links);

@@ -156,6 +156,43 @@ def test_slab_stacks_equal_single_mesh(problem, overrides, cuts, nsteps, world):
         assert sum(r[5] for r in res) > 0 and sum(r[5] for r in res) == sum(r[6] for r in res), "remote flux corrections expected"
 
 
+SPHERE3 = (["job/num_domains=3"] + dom(1, (32, 32, 32)) + dom(2, (32, 28, 24), (16, 18, 20)) + dom(3, (16, 16, 16), (48, 52, 56))
+           + ["problem/rp=2.1e10"])
+
+
+def test_three_levels_with_radiation_fixed_handoff(monkeypatch):
+    """3 levels with radiation: the reference's coarse->fine hand-off indexes out of bounds once the
+    parent is displaced (ionrad_smr.c:97-98), so this only exists as the opt-in corrected mode.  There is
+    no reference behaviour to match; what must hold is that the refusal is in place by default, that the
+    finest level is actually lit through two hand-offs, and that the slab-stack driver agrees with the
+    single-process mesh (to rounding: slab origins enter cc_pos, hence the potential)."""
+    import orc
+    aa = importlib.import_module("atmospheric-athena_amd")
+    monkeypatch.delenv("AA_SMR_DEEP_RADIATION", raising=False)
+    with pytest.raises(aa.athinput.ParError):
+        orc.make_mesh("ioniz_sphere", None, SPHERE3)
+    monkeypatch.setenv("AA_SMR_DEEP_RADIATION", "fixed"); monkeypatch.setenv("ORC_SMR_DEEP_RADIATION", "fixed")
+    ref = orc.make_mesh("ioniz_sphere", None, SPHERE3).start()
+    its_ref = [ref.step() for _ in range(2)]
+    assert all(len(it) == 3 and min(it) > 0 for it in its_ref)
+    lit = ref.lev[2].edgeflux[:-1, :-1, 0] > 0
+    assert lit.mean() > 0.5, "most rays of the finest level must arrive lit (the planet shadows the rest)"
+    res = run_ranks("ioniz_sphere", SPHERE3, None, 2, 2)
+    for rank, out, its, t, dt, n_in, n_out in res:
+        assert its == its_ref and abs(t / ref.time - 1) < 1e-12
+        for level, k0, n3, U, ef in out:
+            g = ref.lev[level].grid
+            off = k0 - (g.disp[2] if level else 0)
+            R = ref.lev[level].active[off:off + n3]
+            assert np.array_equal(np.isnan(U), np.isnan(R))          # (this tiny sphere develops NaN zones, as the reference's do)
+            scale = np.nanmax(np.abs(R), axis=(0, 1, 2)); scale[scale == 0] = 1
+            err = np.nanmax(np.abs(U - R), axis=(0, 1, 2)) / scale
+            # d, E, s to 1e-9; the momenta are still ~1e-13 after two steps and carry the last-bit difference of
+            # the potential (slab origins enter cc_pos) at 1e-5 of that
+            assert err[[0, 4, 5]].max() < 1e-9 and err[1:4].max() < 1e-4, f"rank {rank} level {level}: {err}"
+            assert np.allclose(ef[:n3], ref.lev[level].edgeflux[off:off + n3], rtol=1e-9, atol=0, equal_nan=True)
+
+
 def test_mesh_slab_geometry():
     aa = importlib.import_module("atmospheric-athena_amd")
     import orc

@@ -163,3 +163,28 @@ def test_mesh_create_rejects_bad_nesting(aa, lib):
         assert b"level" in g0.L.aa_last_error()
     finally:
         g0.close(); g1.close()
+
+
+def test_three_levels_with_radiation_fixed_handoff(aa, lib, monkeypatch):
+    """AA_SMR_DEEP_RADIATION=fixed: refused by default; in the corrected mode the
+    GPU mesh agrees with the oracle's same mode."""
+    ov = ["job/num_domains=3", "domain1/Nx1=32", "domain1/Nx2=32", "domain1/Nx3=32", "problem/rp=2.1e10",
+          "domain2/Nx1=32", "domain2/Nx2=28", "domain2/Nx3=24", "domain2/iDisp=16", "domain2/jDisp=18", "domain2/kDisp=20",
+          "domain3/Nx1=16", "domain3/Nx2=16", "domain3/Nx3=16", "domain3/iDisp=48", "domain3/jDisp=52", "domain3/kDisp=56"]
+    monkeypatch.delenv("AA_SMR_DEEP_RADIATION", raising=False)
+    with pytest.raises(aa.athinput.ParError):
+        make_gpu_mesh(aa, lib, "ioniz_sphere", ov, False)
+    monkeypatch.setenv("AA_SMR_DEEP_RADIATION", "fixed"); monkeypatch.setenv("ORC_SMR_DEEP_RADIATION", "fixed")
+    o = orc.make_mesh("ioniz_sphere", None, ov).start()
+    m = make_gpu_mesh(aa, lib, "ioniz_sphere", ov, True)
+    try:
+        m.start()
+        for _ in range(3):
+            assert m.step() == o.step()
+        for l, lev in enumerate(m.lev):
+            err = relerr(lev.download()[4:-4, 4:-4, 4:-4, :], o.lev[l].active)
+            assert max(err) < 1e-8, (l, err)
+            assert np.allclose(lev.download_edgeflux(), o.lev[l].edgeflux, rtol=1e-8, atol=0)
+        assert (o.lev[2].edgeflux[:-1, :-1, 0] > 0).mean() > 0.5
+    finally:
+        m.close()
