@@ -86,7 +86,7 @@ def bench_smr(a, aa, torch, rank, world, local):
     if a.smr_deck:
         if world != 1:
             sys.exit("--smr-deck is a one-GPU measurement")
-        par.cmdline(["job/num_domains=2"])
+        par.cmdline([f"job/num_domains={a.smr_levels}"])
     else:
         par.cmdline(["job/num_domains=2", f"domain1/Nx1={nx}", f"domain1/Nx2={nx}", f"domain1/Nx3={nx * world}",
                      f"domain1/x3max={x3min + (x3max - x3min) * world!r}",
@@ -137,8 +137,8 @@ def bench_smr(a, aa, torch, rank, world, local):
                "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * elapsed / a.steps,
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
                "data": "synthetic (deck values on a nested 2-level mesh, generated in place)",
-               "config": {"workload": f"{a.problem} 2-level SMR: " + " + ".join(f"level {g.level} {g.Nx[0]}x{g.Nx[1]}x{g.Nx[2]}" for g in lv)
-                                      + " (zones of both levels counted, as the reference's zone-cycles do)",
+               "config": {"workload": f"{a.problem} {len(lv)}-level SMR: " + " + ".join(f"level {g.level} {g.Nx[0]}x{g.Nx[1]}x{g.Nx[2]}" for g in lv)
+                                      + " (zones of all levels counted, as the reference's zone-cycles do)",
                           "zones": zones, "partition": (f"x3 cuts {list(m.cfg.cuts)} shared by both levels" if multi else "one aa_mesh"),
                           "subcycle_trace_per_level": trace, "final_dt": m.dt,
                           "hbm_resident_GB_rank0": sum(g.device_bytes() for g in grids) / 1e9, "setup_s": t_setup}}
@@ -171,6 +171,9 @@ def main():
     ap.add_argument("--smr-deck", action="store_true",
                     help="with --smr: the deck's own root and level-1 Domains (80^3 + 52^3, the first two levels of "
                          "tst/massloss/athinput.ioniz_sphere_hires) instead of nx^3 + nx^3")
+    ap.add_argument("--smr-levels", type=int, default=2,
+                    help="with --smr-deck: how many of the deck's 5 nested Domains to use; more than 2 need "
+                         "AA_SMR_DEEP_RADIATION=fixed (DESIGN.md section 6)")
     ap.add_argument("--ionized-slab", action="store_true",
                     help="SURVEY 8(d) worst case for the ray sweep: neutral fraction 1e-4 everywhere, so every ray crosses the whole box")
     ap.add_argument("--no-cpu-baseline", action="store_true")
