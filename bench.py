@@ -136,7 +136,7 @@ def bench_smr(a, aa, torch, rank, world, local):
         out = {"metric": "cell-updates/sec (hydro+ion-rad step)", "value": zones * a.steps / elapsed, "unit": "cell-updates/s",
                "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * elapsed / a.steps,
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
-               "data": "synthetic (deck values on a nested 2-level mesh, generated in place)",
+               "data": "synthetic (deck values on a nested mesh, generated in place)",
                "config": {"workload": f"{a.problem} {len(lv)}-level SMR: " + " + ".join(f"level {g.level} {g.Nx[0]}x{g.Nx[1]}x{g.Nx[2]}" for g in lv)
                                       + " (zones of all levels counted, as the reference's zone-cycles do)",
                           "zones": zones, "partition": (f"x3 cuts {list(m.cfg.cuts)} shared by both levels" if multi else "one aa_mesh"),
