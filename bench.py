@@ -26,6 +26,19 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 PKG = "atmospheric-athena_amd"
 
+# Rehearsal of the N>1 code path on a ONE-GPU box (not a measurement): AA_BENCH_REHEARSAL=1 puts every rank on
+# cuda:0 and uses gloo (RCCL refuses two ranks on one device); messages are staged through the host.
+REHEARSAL = bool(os.environ.get("AA_BENCH_REHEARSAL"))
+
+
+def init_pg(dist, torch, rank, world, local):
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29511")
+    if REHEARSAL:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    else:
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+
+
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/s measured copy)
 
 # Compulsory bytes per cell of each kernel = distinct doubles it must read + write per zone
@@ -98,8 +111,7 @@ def bench_smr(a, aa, torch, rank, world, local):
     multi = world > 1 or bool(os.environ.get("AA_FORCE_DISTRIBUTED"))
     if multi:
         import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29511")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        init_pg(dist, torch, rank, world, local)
         m = importlib.import_module(PKG + ".driver").MeshDriver(par, run, None, rank, world, local).start()
         grids = m.eng.lev
     else:
@@ -184,7 +196,7 @@ def main():
     aa = importlib.import_module(PKG)
     driver = importlib.import_module(PKG + ".driver")
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
+    local = 0 if REHEARSAL else int(os.environ.get("LOCAL_RANK", "0"))
     if world != a.gpus:
         if world == 1 and a.gpus > 1:
             sys.exit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N bench.py --gpus N")
@@ -197,8 +209,7 @@ def main():
     force = bool(os.environ.get("AA_FORCE_DISTRIBUTED"))
     if world > 1 or force:
         import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29511")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        init_pg(dist, torch, rank, world, local)
 
     # weak scaling: every GPU holds nx^3 zones; the box grows along x3 with the same dx
     nx = a.nx
