@@ -208,3 +208,76 @@ def test_mesh_slab_geometry():
     assert cuts[0] == 0 and cuts[-1] == 16 and 4 <= cuts[1] <= 12
     with pytest.raises(aa.athinput.ParError):
         aa.config.mesh_slabs(par, run, 0, 3, (0, 5, 6, 16))      # a 1-plane slab
+
+
+def test_mesh_slab_invariants_random():
+    """config.mesh_slabs over random nested levels and cuts: every level is tiled exactly once, a child slab
+    lies over its parent slab, fine/coarse sides are flagged where (and only where) the LEVEL ends, and every
+    flux correction that leaves a rank arrives on the neighbour that owns the parent plane."""
+    import random
+    aa = importlib.import_module("atmospheric-athena_amd")
+    import orc
+    rng = random.Random(7)
+    tried = 0
+    while tried < 60:
+        n3 = rng.choice([16, 24, 32, 40])
+        nlev = rng.choice([2, 3])
+        ov = [f"job/num_domains={nlev}"] + dom(1, (8, 8, n3))
+        lo, hi = 0, n3                      # extent of the previous level in its own zones
+        ok = True
+        for l in range(1, nlev):
+            # a child strictly inside its parent (or flush with the root boundary), even sizes/displacements
+            a = rng.randrange(lo // 1 + 2, (lo + hi) // 2, 2) if rng.random() < 0.8 or lo != 0 else 0
+            b = rng.randrange((lo + hi) // 2 + 2, hi - 1, 2)
+            if b - a < 4:
+                ok = False; break
+            ov += dom(l + 1, (8, 8, 2 * (b - a)), (4 * (2 ** (l - 1)) if l == 1 else 0, 0, 2 * a))
+            lo, hi = 2 * a, 2 * b
+        if not ok:
+            continue
+        # x1/x2: level l covers 8 zones of its own => displaced so that it is nested: keep x1,x2 trivial (full width
+        # is not allowed for a child unless it touches the root boundary, which periodic roots forbid) -> use outflow
+        ov = [o for o in ov if not o.startswith("domain") or "Disp" not in o or o.split("/")[1][0] == "k"] + \
+             ["domain1/bc_ix1=2", "domain1/bc_ox1=2", "domain1/bc_ix2=2", "domain1/bc_ox2=2", "domain1/bc_ix3=2", "domain1/bc_ox3=2"]
+        for l in range(1, nlev):
+            ov += [f"domain{l + 1}/iDisp=0", f"domain{l + 1}/jDisp=0", f"domain{l + 1}/Nx1={8 * 2 ** l}", f"domain{l + 1}/Nx2={8 * 2 ** l}"]
+        try:
+            par = aa.athinput.ParTable.from_file(os.path.join(orc.DECKS, "athinput.blast")).cmdline(ov)
+            run = aa.config.from_par(par, "blast")
+            levs = aa.config.levels(par, run)
+        except aa.athinput.ParError:
+            continue
+        nranks = rng.choice([2, 3, 4])
+        cuts = None
+        if rng.random() < 0.5:                       # put cuts exactly on the first refined level's boundaries
+            g1 = levs[1]
+            cand = sorted({0, g1.disp[2] // 2, (g1.disp[2] + g1.Nx[2]) // 2, n3})
+            if all(b - a >= 4 for a, b in zip(cand, cand[1:])):
+                cuts, nranks = tuple(cand), len(cand) - 1
+        try:
+            cfgs = [aa.config.mesh_slabs(par, run, r, nranks, cuts) for r in range(nranks)]
+        except aa.athinput.ParError:
+            continue                                 # some slab thinner than nghost: legitimately refused
+        tried += 1
+        for l, g in enumerate(levs):
+            spans = sorted(c.table[c.rank][l] for c in cfgs if c.table[c.rank][l] is not None)
+            d3 = g.disp[2] if l else 0
+            assert spans[0][0] == d3 and spans[-1][1] == d3 + g.Nx[2]
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:])), "slabs of a level must tile it"
+        sent, received = [], []
+        for c in cfgs:
+            for l, L in enumerate(c.links):
+                P, C = c.levels[l], c.levels[l + 1]
+                assert 0 <= L.cs[2] - 4 and L.cs[2] - 4 + L.n[2] <= P.Nx[2] and 2 * L.n[2] == C.Nx[2]
+                g = levs[l + 1]
+                assert L.prol[4] == int(C.disp[2] == g.disp[2] and g.disp[2] != 0)
+                assert L.prol[5] == int(C.disp[2] + C.Nx[2] == g.disp[2] + g.Nx[2] and (g.disp[2] + g.Nx[2]) // 2 ** (l + 1) != run.rootNx[2])
+                for side in (0, 1):
+                    assert not (L.corr[4 + side] and L.corr_to[side] >= 0)
+                    if L.prol[4 + side]:
+                        assert L.corr[4 + side] or L.corr_to[side] >= 0, "a level boundary must be corrected somewhere"
+                    if L.corr_to[side] >= 0:
+                        sent.append((c.rank, L.corr_to[side], l, side))
+            for (lp, side, src, i0, j0, n1, n2) in c.corr_in:
+                received.append((src, c.rank, lp, side))
+        assert sorted(sent) == sorted(received)
