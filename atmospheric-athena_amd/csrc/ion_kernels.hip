@@ -207,12 +207,14 @@ k_ray_sweep(DevGrid g, IonPar p, Real flux0, int from_edgeflux)
     if (alive && tid < nrays) {                               // one lane per ray: serial product
       const int r = tid;
       Real flux = s_flux[r]; int dead = s_dead[r];
+      // flux/(f0 + 1e-12) < MINFLUXFRAC (:299-300) as flux < MINFLUXFRAC*(f0 + 1e-12): no division in the
+      // serial chain (a ray whose ratio rounds exactly onto the threshold may be cut one zone apart)
+      const Real cut = MINFLUXFRAC*(s_f0[r] + 1e-12);
       for (int cc = 0; cc < ncol; cc++) {
         if (dead) { s_fin[r][cc] = 0.0; continue; }
         s_fin[r][cc] = flux;                                  // EdgeFlux[..][i-s] = flux  (:279)
         flux *= s_etau[r][cc];                                // :298
-        const Real flux_frac = flux / (s_f0[r] + 1e-12);      // :299
-        if (flux_frac < MINFLUXFRAC) { dead = 1; flux = 0.0; atomicSub(&s_nalive, 1); }   // :300-306
+        if (flux < cut) { dead = 1; flux = 0.0; atomicSub(&s_nalive, 1); }   // :300-306
       }
       s_flux[r] = flux; s_dead[r] = dead;
     }
