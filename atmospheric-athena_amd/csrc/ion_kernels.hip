@@ -62,10 +62,12 @@ AA_DEV IonQ ion_q(const Cell &c, const IonPar &p, Real Gamma_1)
 AA_DEV Real neutral_lim(Real d, const IonPar &p)   // ionrad_3d.c:147-148
 { Real d_nlim = d*IONFRACFLOOR; return d_nlim < p.d_nlo ? d_nlim : p.d_nlo; }
 
-// apply_temp_floor (:70-131) then apply_neutral_floor (:140-156) on one cell
-AA_DEV void floors(Cell &c, const IonPar &p, Real Gamma_1)
+// apply_temp_floor (:70-131) then apply_neutral_floor (:140-156) on one cell; `q` returns the derived
+// quantities of the cell as it entered, `changed` whether E or s was touched (then q is stale)
+AA_DEV void floors(Cell &c, const IonPar &p, Real Gamma_1, IonQ &q, bool &changed)
 {
-  IonQ q = ion_q(c, p, Gamma_1);
+  const Real E0 = c.E, s0 = c.s;
+  q = ion_q(c, p, Gamma_1);
   if (q.T < p.tfloor) {
     Real e_sp = p.tfloor * p.k_B / (q.muq * Gamma_1);
     c.E = c.ke + e_sp * c.d;
@@ -76,7 +78,9 @@ AA_DEV void floors(Cell &c, const IonPar &p, Real Gamma_1)
   }
   Real d_nlim = neutral_lim(c.d, p);
   if (c.s < d_nlim) c.s = d_nlim; else if (c.s > c.d) c.s = c.d;
+  changed = (c.E != E0) || (c.s != s0);
 }
+AA_DEV void floors(Cell &c, const IonPar &p, Real Gamma_1) { IonQ q; bool ch; floors(c, p, Gamma_1, q, ch); }
 
 // Undamped rate of change of the neutral density (compute_chem_rates, ionrad_3d.c:334-341).
 // recomb_rate_coef = 2.59e-13 (T/1e4)^-0.7 and recomb_cool_rate_coef = 6.11e-10 T^-0.89 k_B T
@@ -127,10 +131,11 @@ k_ion_begin(DevGrid g, IonPar p)
   const Real di = 1.0/d;
   Cell c; c.d = d; c.ke = 0.5 * (M1*M1 + M2*M2 + M3*M3) * di; c.E = Uq(g,4)[m]; c.s = Uq(g,5)[m];
   const Real E0 = c.E, s0 = c.s;
-  floors(c, p, g.Gamma_1);
+  IonQ q; bool floored;
+  floors(c, p, g.Gamma_1, q, floored);
   if (c.E != E0) Uq(g,4)[m] = c.E;
   if (c.s != s0) Uq(g,5)[m] = c.s;
-  IonQ q = ion_q(c, p, g.Gamma_1);
+  if (floored) q = ion_q(c, p, g.Gamma_1);
   g.e_init[m] = c.E;
   g.x_init[m] = q.x;
   g.sign[m] = make_int2(0, 0);
@@ -347,10 +352,11 @@ k_ion_update(DevGrid g, IonPar p, Real dt_arg, DevScalars *sc, int dt_from_sc)
         c.s += nHdot * dt * p.m_H;
       }
     }
-    floors(c, p, g.Gamma_1);
+    IonQ q; bool floored;
+    floors(c, p, g.Gamma_1, q, floored);
     if (c.E != E0) Uq(g,4)[m] = c.E;
     if (c.s != s0) Uq(g,5)[m] = c.s;
-    const IonQ q = ion_q(c, p, g.Gamma_1);
+    if (floored) q = ion_q(c, p, g.Gamma_1);               // otherwise what floors() derived still holds
     // check_range :223-264.  a/b >= L is tested as a >= L*b when both are positive (the common
     // case; ratios sit near 1, limits at 11), by division otherwise.
     {
