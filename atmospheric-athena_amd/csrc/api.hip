@@ -64,6 +64,7 @@ int aa_create(const aa_params *p, aa_grid **out)
   d.sJ = d.N1; d.sK = (long)d.N1*d.N2; d.nc = d.sK*d.N3;
   if (p->level < 0 || p->level > 7) { delete g; return fail(-1, "[aa_create]: level %d out of range", p->level); }
   g->level = p->level;
+  { const char *e = getenv("AA_FUSED_UPDATE"); g->fused_update = e ? atoi(e) != 0 : false; }
   Real rootdx[3];
   for (int a = 0; a < 3; a++) {
     rootdx[a] = (p->xmax[a] - p->xmin[a])/(Real)(p->rootNx[a]);   // init_mesh.c:225
@@ -321,10 +322,14 @@ int aa_integrate_3d_ctu(aa_grid *g)
   { Scope s(g, "sweep_correct_x1"); launch_sweep_correct_x1(d, ns, dt, g->grav, g->st); }
   { Scope s(g, "correct_x2"); launch_correct(d, ns, 1, dt, g->grav, g->st); }
   { Scope s(g, "correct_x3"); launch_correct(d, ns, 2, dt, g->grav, g->st); }
-  { Scope s(g, "flux2_x1"); launch_flux2(d, ns, 0, g->st); }
-  { Scope s(g, "flux2_x2"); launch_flux2(d, ns, 1, g->st); }
-  { Scope s(g, "flux2_x3"); launch_flux2(d, ns, 2, g->st); }
-  { Scope s(g, "update");   launch_update(d, ns, d.dhalf, dt, g->grav, g->st); }
+  if (g->fused_update && !g->keep_flux) {
+    Scope s(g, "flux2_update"); launch_flux2_update(d, ns, dt, g->grav, g->st);
+  } else {
+    { Scope s(g, "flux2_x1"); launch_flux2(d, ns, 0, g->st); }
+    { Scope s(g, "flux2_x2"); launch_flux2(d, ns, 1, g->st); }
+    { Scope s(g, "flux2_x3"); launch_flux2(d, ns, 2, g->st); }
+    { Scope s(g, "update");   launch_update(d, ns, d.dhalf, dt, g->grav, g->st); }
+  }
   HIPCHK(hipGetLastError());
   return 0;
 }

@@ -74,6 +74,7 @@ void launch_correct(const DevGrid &g, int nscal, int dir, Real dt, bool grav, hi
 void launch_sweep_correct_x1(const DevGrid &g, int nscal, Real dt, bool grav, hipStream_t st);
 void launch_flux2(const DevGrid &g, int nscal, int dir, hipStream_t st);
 void launch_update(const DevGrid &g, int nscal, const Real *dhalf, Real dt, bool grav, hipStream_t st);
+void launch_flux2_update(const DevGrid &g, int nscal, Real dt, bool grav, hipStream_t st);   // flux2 x3 + update fused
 void launch_vl_flux1(const DevGrid &g, int nscal, int dir, hipStream_t st);
 void launch_vl_uhalf(const DevGrid &g, int nscal, Real dt, bool grav, hipStream_t st);
 void launch_vl_flux2(const DevGrid &g, int nscal, int dir, Real dt, hipStream_t st);

@@ -469,6 +469,135 @@ k_update(DevGrid g, const Real *dhalf, Real dt, Order ord)
   for (int v = 0; v < NV; v++) Uf(g, v)[m] = u[v];
 }
 
+// ---- steps 9b-d + 11a + 12 in one marching kernel --------------------------------------------
+// The second-pass fluxes never go to HBM: a thread owns one (i,j) column and marches along x3; at every
+// zone it solves the Riemann problems of the zone's LOWER x1 and x2 faces and of its UPPER x3 face.
+// The upper x1 (x2) face is the lower face of the next lane (row) and arrives by a wavefront shuffle
+// (through LDS); the lower x3 face is the upper one of the previous step and stays in registers.  Lane 63
+// and row FU_TJ-1 of a block only provide fluxes (63 x 7 zones per 64 x 8 threads: 16 % more Riemann
+// solves than faces), and a chunk of `kchunk` zones starts with one extra x3 solve.  Against
+// k_flux2 x3 + k_update this drops 18 stores and ~20 loads of doubles per zone.  Expressions and their
+// order per zone are those of k_flux2 / k_update, so results are bit-identical to the unfused chain.
+// Not used for levels of a Mesh: RestrictCorrect reads the second-pass fluxes at the level boundaries.
+#define FU_TJ 8
+template <int NS, int D>
+AA_DEV void face_flux2(const DevGrid &g, long m, Real f[6])
+{
+  const long sD = stride<D>(g), ml = m - sD;
+  constexpr int E1 = (D == 0) ? 1 : 0, E2 = (D == 2) ? 1 : 2;
+  const long s1 = stride<E1>(g), s2 = stride<E2>(g);
+  const Real *e1 = Ef(g, E1), *e2 = Ef(g, E2);
+  Real etah = rmax(e1[ml], e1[m]);
+  etah = rmax(etah, e1[ml + s1]);
+  etah = rmax(etah, e1[m + s1]);
+  etah = rmax(etah, e2[ml]);
+  etah = rmax(etah, e2[m]);
+  etah = rmax(etah, e2[ml + s2]);
+  etah = rmax(etah, e2[m + s2]);
+  etah = rmax(etah, Ef(g, D)[m]);
+  Real ul[6], ur[6], wl[6], wr[6];
+  load_sweep<D, NS>(LRf(g, D, 0, 0), g.nc, m, ul);
+  load_sweep<D, NS>(LRf(g, D, 1, 0), g.nc, m, ur);
+  cons_to_prim<NS>(ul, wl, g.Gamma_1);
+  cons_to_prim<NS>(ur, wr, g.Gamma_1);
+  flux_roe<NS>(ul, ur, wl, wr, etah, g.Gamma, g.Gamma_1, f);
+}
+
+template <int NS, bool GRAV>
+__global__ void __launch_bounds__(64*FU_TJ)
+k_flux2_update(DevGrid g, const Real *dhalf, Real dt, int kchunk)
+{
+  __shared__ Real s_f2[FU_TJ][6][64];
+  const int lane = threadIdx.x, row = threadIdx.y;
+  const int i = g.is + blockIdx.x*63 + lane, j = g.js + blockIdx.y*(FU_TJ - 1) + row;
+  const int k0 = g.ks + blockIdx.z*kchunk;
+  int k1 = k0 + kchunk - 1; if (k1 > g.ke) k1 = g.ke;
+  constexpr int NV = 5 + NS;
+  const bool cell = (lane < 63) && (row < FU_TJ - 1) && (i <= g.ie) && (j <= g.je);
+  const bool need1 = (row < FU_TJ - 1) && (j <= g.je) && (i <= g.ie + 1);      // lower x1 face of (i,j)
+  const bool need2 = (lane < 63) && (i <= g.ie) && (j <= g.je + 1);            // lower x2 face of (i,j)
+  // clamp the column of idle threads into the Grid so that shuffles / barriers stay uniform
+  const int ic = (i <= g.ie + 1) ? i : g.ie + 1, jc = (j <= g.je + 1) ? j : g.je + 1;
+  const long mcol = (long)jc*g.sJ + ic;
+  Real dtodx[3];
+#pragma unroll
+  for (int d = 0; d < 3; d++) dtodx[d] = dt/g.dx[d];
+  // per direction: flux differences (hi - lo) of all components + the two mass fluxes (gravity)
+  Real f3lo[6], d1[6], d2[6], d3[6], m1lo = 0.0, m1hi = 0.0, m2lo = 0.0, m2hi = 0.0, m3hi = 0.0;
+#pragma unroll
+  for (int n = 0; n < 6; n++) f3lo[n] = 0.0;
+  if (cell) face_flux2<NS, 2>(g, (long)k0*g.sK + mcol, f3lo);                   // face k0
+  for (int k = k0; k <= k1; k++) {
+    // (opaque to the optimiser: otherwise every one of the ~60 field pointers becomes its own
+    //  strength-reduced 64-bit induction variable and the kernel spills)
+    long m = (long)k*g.sK + mcol;
+    asm volatile("" : "+v"(m));
+    __builtin_amdgcn_sched_barrier(0);
+    {
+      Real f[6];
+#pragma unroll
+      for (int n = 0; n < 6; n++) f[n] = 0.0;
+      if (need1) face_flux2<NS, 0>(g, m, f);
+#pragma unroll
+      for (int n = 0; n < NV; n++) d1[n] = __shfl_down(f[n], 1) - f[n];
+      m1lo = f[0]; m1hi = __shfl_down(f[0], 1);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    {
+      Real f[6];
+#pragma unroll
+      for (int n = 0; n < 6; n++) f[n] = 0.0;
+      if (need2) face_flux2<NS, 1>(g, m, f);
+#pragma unroll
+      for (int n = 0; n < NV; n++) s_f2[row][n][lane] = f[n];
+      __syncthreads();
+      if (row < FU_TJ - 1) {
+#pragma unroll
+        for (int n = 0; n < NV; n++) d2[n] = s_f2[row + 1][n][lane] - f[n];
+        m2hi = s_f2[row + 1][0][lane];
+      }
+      m2lo = f[0];
+      __syncthreads();
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (cell) {
+      Real f[6];
+      face_flux2<NS, 2>(g, m + g.sK, f);
+#pragma unroll
+      for (int n = 0; n < NV; n++) d3[n] = f[n] - f3lo[n];
+      m3hi = f[0];
+      const Real m3lo = f3lo[0];
+#pragma unroll
+      for (int n = 0; n < NV; n++) f3lo[n] = f[n];
+      __builtin_amdgcn_sched_barrier(0);
+      Real u[6];
+#pragma unroll
+      for (int v = 0; v < NV; v++) u[v] = Uf(g, v)[m];
+      if (GRAV) {   // :2741-2782, with the mass fluxes (sweep component 0) of the faces just solved
+        const Real phic = Pf(g, 0)[m], dh = dhalf[m];
+        { const Real phir = Pf(g, 1)[m + 1], phil = Pf(g, 1)[m];
+          u[1] -= dtodx[0]*(phir - phil)*dh;
+          u[4] -= dtodx[0]*(m1lo*(phic - phil) + m1hi*(phir - phic)); }
+        { const Real phir = Pf(g, 2)[m + g.sJ], phil = Pf(g, 2)[m];
+          u[2] -= dtodx[1]*(phir - phil)*dh;
+          u[4] -= dtodx[1]*(m2lo*(phic - phil) + m2hi*(phir - phic)); }
+        { const Real phir = Pf(g, 3)[m + g.sK], phil = Pf(g, 3)[m];
+          u[3] -= dtodx[2]*(phir - phil)*dh;
+          u[4] -= dtodx[2]*(m3lo*(phic - phil) + m3hi*(phir - phic)); }
+      }
+      // :2981-3050, x1 then x2 then x3; sweep component n of direction D is global variable gv<D>(n)
+#pragma unroll
+      for (int n = 0; n < NV; n++) u[gv<0>(n)] -= dtodx[0]*d1[n];
+#pragma unroll
+      for (int n = 0; n < NV; n++) u[gv<1>(n)] -= dtodx[1]*d2[n];
+#pragma unroll
+      for (int n = 0; n < NV; n++) u[gv<2>(n)] -= dtodx[2]*d3[n];
+#pragma unroll
+      for (int v = 0; v < NV; v++) Uf(g, v)[m] = u[v];
+    }
+  }
+}
+
 // ---- van Leer integrator (integrators/integrate_3d_vl.c, NO_H_CORRECTION) --------------------
 // steps 1-3: first-order (donor-cell) fluxes, Wl = W[c-1], Wr = W[c], over the whole ghost range
 template <int NS, int D>
@@ -841,6 +970,19 @@ static void flux2_impl(const DevGrid &g, int dir, hipStream_t st)
 }
 void launch_flux2(const DevGrid &g, int nscal, int dir, hipStream_t st)
 { if (nscal) flux2_impl<1>(g, dir, st); else flux2_impl<0>(g, dir, st); }
+
+// fused second-pass fluxes + update (CTU, Grids that are not levels of a Mesh)
+void launch_flux2_update(const DevGrid &g, int nscal, Real dt, bool grav, hipStream_t st)
+{
+  const int ni = g.ie - g.is + 1, nj = g.je - g.js + 1, nk = g.ke - g.ks + 1;
+  int kc = 32;
+  while (kc > 4 && (long)nblk(ni, 63)*nblk(nj, FU_TJ - 1)*((nk + kc - 1)/kc) < 1024) kc >>= 1;
+  dim3 grid(nblk(ni, 63), nblk(nj, FU_TJ - 1), (nk + kc - 1)/kc), blk(64, FU_TJ);
+  if (nscal) { if (grav) hipLaunchKernelGGL((k_flux2_update<1, true>), grid, blk, 0, st, g, g.dhalf, dt, kc);
+               else      hipLaunchKernelGGL((k_flux2_update<1, false>), grid, blk, 0, st, g, g.dhalf, dt, kc); }
+  else       { if (grav) hipLaunchKernelGGL((k_flux2_update<0, true>), grid, blk, 0, st, g, g.dhalf, dt, kc);
+               else      hipLaunchKernelGGL((k_flux2_update<0, false>), grid, blk, 0, st, g, g.dhalf, dt, kc); }
+}
 
 void launch_update(const DevGrid &g, int nscal, const Real *dhalf, Real dt, bool grav, hipStream_t st)
 {

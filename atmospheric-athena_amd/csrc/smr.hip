@@ -275,6 +275,7 @@ static aa_mesh *mesh_alloc(int nlevels, aa_grid **levels)
     if (!g || g->level != l) { delete m; aa_fail(-1, "[aa_mesh_create]: levels[%d] was not created with level=%d", l, l); return nullptr; }
     if (g->p.device != levels[0]->p.device) { delete m; aa_fail(-1, "[aa_mesh_create]: all levels must live on one device"); return nullptr; }
     m->lev[l] = g; m->box[l] = nullptr;
+    g->keep_flux = true;
   }
   return m;
 }
