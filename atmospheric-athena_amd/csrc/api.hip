@@ -64,7 +64,7 @@ int aa_create(const aa_params *p, aa_grid **out)
   d.sJ = d.N1; d.sK = (long)d.N1*d.N2; d.nc = d.sK*d.N3;
   if (p->level < 0 || p->level > 7) { delete g; return fail(-1, "[aa_create]: level %d out of range", p->level); }
   g->level = p->level;
-  { const char *e = getenv("AA_FUSED_UPDATE"); g->fused_update = e ? atoi(e) != 0 : false; }
+  { const char *e = getenv("AA_FUSED_UPDATE"); g->fused_update = e ? atoi(e) != 0 : true; }
   Real rootdx[3];
   for (int a = 0; a < 3; a++) {
     rootdx[a] = (p->xmax[a] - p->xmin[a])/(Real)(p->rootNx[a]);   // init_mesh.c:225

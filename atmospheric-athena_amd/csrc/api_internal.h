@@ -27,7 +27,7 @@ struct aa_grid {
   bool grav = false;
   int rad_dir = 0, nradplane = 0; aa::Real flux_i = 0;
   int level = 0;                       // DomainS.Level: > 0 only as a level of an aa_mesh
-  bool fused_update = false;           // AA_FUSED_UPDATE at aa_create: second-pass fluxes + update in one kernel
+  bool fused_update = false;           // second-pass fluxes + update in one kernel (AA_FUSED_UPDATE=0 at aa_create: the unfused chain)
   bool keep_flux = false;              // a level of an aa_mesh: RestrictCorrect reads the second-pass fluxes
   double time = 0, dt = 0; int nstep = 0;
   long long bytes = 0;
