@@ -322,8 +322,8 @@ int aa_integrate_3d_ctu(aa_grid *g)
   { Scope s(g, "sweep_correct_x1"); launch_sweep_correct_x1(d, ns, dt, g->grav, g->st); }
   { Scope s(g, "correct_x2"); launch_correct(d, ns, 1, dt, g->grav, g->st); }
   { Scope s(g, "correct_x3"); launch_correct(d, ns, 2, dt, g->grav, g->st); }
-  if (g->fused_update && !g->keep_flux) {
-    Scope s(g, "flux2_update"); launch_flux2_update(d, ns, dt, g->grav, g->st);
+  if (g->fused_update) {
+    Scope s(g, "flux2_update"); launch_flux2_update(d, ns, dt, g->grav, g->keep_flux ? &g->keep : nullptr, g->st);
   } else {
     { Scope s(g, "flux2_x1"); launch_flux2(d, ns, 0, g->st); }
     { Scope s(g, "flux2_x2"); launch_flux2(d, ns, 1, g->st); }

@@ -28,7 +28,8 @@ struct aa_grid {
   int rad_dir = 0, nradplane = 0; aa::Real flux_i = 0;
   int level = 0;                       // DomainS.Level: > 0 only as a level of an aa_mesh
   bool fused_update = false;           // second-pass fluxes + update in one kernel (AA_FUSED_UPDATE=0 at aa_create: the unfused chain)
-  bool keep_flux = false;              // a level of an aa_mesh: RestrictCorrect reads the second-pass fluxes
+  bool keep_flux = false;              // a level of an aa_mesh: RestrictCorrect reads the second-pass fluxes ...
+  aa::KeepPlanes keep = {0, {{0}}};        // ... on these face planes (own boundaries + the child's outline)
   double time = 0, dt = 0; int nstep = 0;
   long long bytes = 0;
   bool prof = false;

@@ -74,7 +74,10 @@ void launch_correct(const DevGrid &g, int nscal, int dir, Real dt, bool grav, hi
 void launch_sweep_correct_x1(const DevGrid &g, int nscal, Real dt, bool grav, hipStream_t st);
 void launch_flux2(const DevGrid &g, int nscal, int dir, hipStream_t st);
 void launch_update(const DevGrid &g, int nscal, const Real *dhalf, Real dt, bool grav, hipStream_t st);
-void launch_flux2_update(const DevGrid &g, int nscal, Real dt, bool grav, hipStream_t st);   // flux2 x3 + update fused
+// face planes (index along the normal, incl. ghost offset) whose second-pass fluxes the fused kernel also
+// stores: the level boundaries static mesh refinement reads back (smr.hip)
+struct KeepPlanes { int n; int p[3][4]; };
+void launch_flux2_update(const DevGrid &g, int nscal, Real dt, bool grav, const KeepPlanes *keep, hipStream_t st);   // flux2 x3 + update fused
 void launch_vl_flux1(const DevGrid &g, int nscal, int dir, hipStream_t st);
 void launch_vl_uhalf(const DevGrid &g, int nscal, Real dt, bool grav, hipStream_t st);
 void launch_vl_flux2(const DevGrid &g, int nscal, int dir, Real dt, hipStream_t st);

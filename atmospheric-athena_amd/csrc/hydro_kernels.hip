@@ -478,7 +478,8 @@ k_update(DevGrid g, const Real *dhalf, Real dt, Order ord)
 // solves than faces), and a chunk of `kchunk` zones starts with one extra x3 solve.  Against
 // k_flux2 x3 + k_update this drops 18 stores and ~20 loads of doubles per zone.  Expressions and their
 // order per zone are those of k_flux2 / k_update, so results are bit-identical to the unfused chain.
-// Not used for levels of a Mesh: RestrictCorrect reads the second-pass fluxes at the level boundaries.
+// Levels of a Mesh (KEEP): RestrictCorrect reads the second-pass fluxes on the level boundaries, so the
+// faces on those planes (KeepPlanes: a few planes per direction) are stored as well.
 #define FU_TJ 8
 template <int NS, int D>
 AA_DEV void face_flux2(const DevGrid &g, long m, Real f[6])
@@ -503,9 +504,14 @@ AA_DEV void face_flux2(const DevGrid &g, long m, Real f[6])
   flux_roe<NS>(ul, ur, wl, wr, etah, g.Gamma, g.Gamma_1, f);
 }
 
-template <int NS, bool GRAV>
+AA_DEV bool on_plane(const KeepPlanes &kp, int d, int x)
+{
+  return x == kp.p[d][0] || x == kp.p[d][1] || x == kp.p[d][2] || x == kp.p[d][3];
+}
+
+template <int NS, bool GRAV, bool KEEP>
 __global__ void __launch_bounds__(64*FU_TJ)
-k_flux2_update(DevGrid g, const Real *dhalf, Real dt, int kchunk)
+k_flux2_update(DevGrid g, const Real *dhalf, Real dt, int kchunk, KeepPlanes kp)
 {
   __shared__ Real s_f2[FU_TJ][6][64];
   const int lane = threadIdx.x, row = threadIdx.y;
@@ -526,7 +532,11 @@ k_flux2_update(DevGrid g, const Real *dhalf, Real dt, int kchunk)
   Real f3lo[6], d1[6], d2[6], d3[6], m1lo = 0.0, m1hi = 0.0, m2lo = 0.0, m2hi = 0.0, m3hi = 0.0;
 #pragma unroll
   for (int n = 0; n < 6; n++) f3lo[n] = 0.0;
-  if (cell) face_flux2<NS, 2>(g, (long)k0*g.sK + mcol, f3lo);                   // face k0
+  const bool keep1 = KEEP && need1 && on_plane(kp, 0, i), keep2 = KEEP && need2 && on_plane(kp, 1, j);
+  if (cell) {                                                                   // face k0
+    face_flux2<NS, 2>(g, (long)k0*g.sK + mcol, f3lo);
+    if (KEEP && on_plane(kp, 2, k0)) store_sweep<2, NS>(Ff(g, 2, 0), g.nc, (long)k0*g.sK + mcol, f3lo);
+  }
   for (int k = k0; k <= k1; k++) {
     // (opaque to the optimiser: otherwise every one of the ~60 field pointers becomes its own
     //  strength-reduced 64-bit induction variable and the kernel spills)
@@ -538,6 +548,7 @@ k_flux2_update(DevGrid g, const Real *dhalf, Real dt, int kchunk)
 #pragma unroll
       for (int n = 0; n < 6; n++) f[n] = 0.0;
       if (need1) face_flux2<NS, 0>(g, m, f);
+      if (keep1) store_sweep<0, NS>(Ff(g, 0, 0), g.nc, m, f);
 #pragma unroll
       for (int n = 0; n < NV; n++) d1[n] = __shfl_down(f[n], 1) - f[n];
       m1lo = f[0]; m1hi = __shfl_down(f[0], 1);
@@ -548,6 +559,7 @@ k_flux2_update(DevGrid g, const Real *dhalf, Real dt, int kchunk)
 #pragma unroll
       for (int n = 0; n < 6; n++) f[n] = 0.0;
       if (need2) face_flux2<NS, 1>(g, m, f);
+      if (keep2) store_sweep<1, NS>(Ff(g, 1, 0), g.nc, m, f);
 #pragma unroll
       for (int n = 0; n < NV; n++) s_f2[row][n][lane] = f[n];
       __syncthreads();
@@ -563,6 +575,7 @@ k_flux2_update(DevGrid g, const Real *dhalf, Real dt, int kchunk)
     if (cell) {
       Real f[6];
       face_flux2<NS, 2>(g, m + g.sK, f);
+      if (KEEP && on_plane(kp, 2, k + 1)) store_sweep<2, NS>(Ff(g, 2, 0), g.nc, m + g.sK, f);
 #pragma unroll
       for (int n = 0; n < NV; n++) d3[n] = f[n] - f3lo[n];
       m3hi = f[0];
@@ -971,17 +984,22 @@ static void flux2_impl(const DevGrid &g, int dir, hipStream_t st)
 void launch_flux2(const DevGrid &g, int nscal, int dir, hipStream_t st)
 { if (nscal) flux2_impl<1>(g, dir, st); else flux2_impl<0>(g, dir, st); }
 
-// fused second-pass fluxes + update (CTU, Grids that are not levels of a Mesh)
-void launch_flux2_update(const DevGrid &g, int nscal, Real dt, bool grav, hipStream_t st)
+// fused second-pass fluxes + update (CTU); `keep`: the face planes whose fluxes are stored as well
+template <int NS, bool GRAV>
+static void launch_fu(const DevGrid &g, Real dt, int kc, dim3 grid, dim3 blk, const KeepPlanes *keep, hipStream_t st)
+{
+  KeepPlanes none = {0, {{0}}};
+  if (keep && keep->n) hipLaunchKernelGGL((k_flux2_update<NS, GRAV, true>), grid, blk, 0, st, g, g.dhalf, dt, kc, *keep);
+  else                 hipLaunchKernelGGL((k_flux2_update<NS, GRAV, false>), grid, blk, 0, st, g, g.dhalf, dt, kc, none);
+}
+void launch_flux2_update(const DevGrid &g, int nscal, Real dt, bool grav, const KeepPlanes *keep, hipStream_t st)
 {
   const int ni = g.ie - g.is + 1, nj = g.je - g.js + 1, nk = g.ke - g.ks + 1;
   int kc = 32;
   while (kc > 4 && (long)nblk(ni, 63)*nblk(nj, FU_TJ - 1)*((nk + kc - 1)/kc) < 1024) kc >>= 1;
   dim3 grid(nblk(ni, 63), nblk(nj, FU_TJ - 1), (nk + kc - 1)/kc), blk(64, FU_TJ);
-  if (nscal) { if (grav) hipLaunchKernelGGL((k_flux2_update<1, true>), grid, blk, 0, st, g, g.dhalf, dt, kc);
-               else      hipLaunchKernelGGL((k_flux2_update<1, false>), grid, blk, 0, st, g, g.dhalf, dt, kc); }
-  else       { if (grav) hipLaunchKernelGGL((k_flux2_update<0, true>), grid, blk, 0, st, g, g.dhalf, dt, kc);
-               else      hipLaunchKernelGGL((k_flux2_update<0, false>), grid, blk, 0, st, g, g.dhalf, dt, kc); }
+  if (nscal) { if (grav) launch_fu<1, true>(g, dt, kc, grid, blk, keep, st); else launch_fu<1, false>(g, dt, kc, grid, blk, keep, st); }
+  else       { if (grav) launch_fu<0, true>(g, dt, kc, grid, blk, keep, st); else launch_fu<0, false>(g, dt, kc, grid, blk, keep, st); }
 }
 
 void launch_update(const DevGrid &g, int nscal, const Real *dhalf, Real dt, bool grav, hipStream_t st)

@@ -261,6 +261,18 @@ static int mesh_finish(aa_mesh *m, aa_grid **levels, aa_mesh **out)
     const size_t nb = (size_t)(L.n[0] + 6)*(L.n[1] + 6)*(L.n[2] + 6)*6;
     if (hipMalloc(&m->box[l], nb*sizeof(Real)) != hipSuccess) return aa_fail(-2, "[aa_mesh_create]: hipMalloc box");
   }
+  // the face planes whose second-pass fluxes k_flux_correct / k_flux_x3_export / k_flux_x3_apply read:
+  // a level's own boundary faces and the outline of its child
+  for (int l = 0; l < m->nl; l++) {
+    aa_grid *g = m->lev[l];
+    const int lo[3] = {g->d.is, g->d.js, g->d.ks}, hi[3] = {g->d.ie, g->d.je, g->d.ke};
+    g->keep.n = 4;
+    for (int d = 0; d < 3; d++) {
+      g->keep.p[d][0] = lo[d]; g->keep.p[d][1] = hi[d] + 1;
+      g->keep.p[d][2] = (l + 1 < m->nl) ? m->link[l].cs[d] : lo[d];
+      g->keep.p[d][3] = (l + 1 < m->nl) ? m->link[l].ce[d] + 1 : lo[d];
+    }
+  }
   *out = m;
   return 0;
 }
