@@ -250,11 +250,13 @@ k_sweep_march(DevGrid g, const Real *src, Real dt, int chunk)
   for (int n = 0; n < 6; n++) wl_cur[n] = 0.0;
 #pragma nounroll
   for (int f = f0 - 1; f <= f1; f++) {
+    long mf = base + (long)f*s;
+    asm volatile("" : "+v"(mf));     // one index for all fields instead of a strength-reduced pointer per field
 #pragma unroll
     for (int n = 0; n < 6; n++) { wm[n] = w[n]; w[n] = wp[n]; }
-    load_sweep<D, NS>(src, g.nc, base + (long)(f + 1)*s, u); cons_to_prim<NS>(u, wp, g.Gamma_1);
-    recon_cell<NS, MODE != MODE_VL, ORD, D>(g, base + (long)f*s, wm, w, wp, dtodx, wl_next, wr);  // cell f -> Wl[f+1], Wr[f]
-    if (f >= f0) face_work<NS, D, GRAV, MODE>(g, base + (long)f*s, i, D == 1 ? f : t, D == 1 ? t : f, dt, wl_cur, wr);
+    load_sweep<D, NS>(src, g.nc, mf + s, u); cons_to_prim<NS>(u, wp, g.Gamma_1);
+    recon_cell<NS, MODE != MODE_VL, ORD, D>(g, mf, wm, w, wp, dtodx, wl_next, wr);  // cell f -> Wl[f+1], Wr[f]
+    if (f >= f0) face_work<NS, D, GRAV, MODE>(g, mf, i, D == 1 ? f : t, D == 1 ? t : f, dt, wl_cur, wr);
 #pragma unroll
     for (int n = 0; n < 6; n++) wl_cur[n] = wl_next[n];
   }
