@@ -64,6 +64,10 @@ int aa_create(const aa_params *p, aa_grid **out)
   d.sJ = d.N1; d.sK = (long)d.N1*d.N2; d.nc = d.sK*d.N3;
   if (p->level < 0 || p->level > 7) { delete g; return fail(-1, "[aa_create]: level %d out of range", p->level); }
   g->level = p->level;
+  // the one-kernel correct pass wins on big Grids (-4 % of a 512^3 step), the tile kernels on small ones
+  // (80^3: +7 %): same results bit for bit, so the choice follows the size unless AA_CORRECT_ALL forces it
+  { const char *e = getenv("AA_CORRECT_ALL");
+    g->correct_all = e ? atoi(e) != 0 : ((long long)p->Nx[0]*p->Nx[1]*p->Nx[2] >= (1LL << 21)); }
   { const char *e = getenv("AA_FUSED_UPDATE"); g->fused_update = e ? atoi(e) != 0 : true; }
   Real rootdx[3];
   for (int a = 0; a < 3; a++) {
@@ -319,9 +323,14 @@ int aa_integrate_3d_ctu(aa_grid *g)
   // x2 and x3 first, so that the x1 sweep can do its first pass and its correct pass in one go
   { Scope s(g, "sweep_x2"); launch_sweep(d, ns, 1, dt, g->grav, g->st); }
   { Scope s(g, "sweep_x3"); launch_sweep(d, ns, 2, dt, g->grav, g->st); }
-  { Scope s(g, "sweep_correct_x1"); launch_sweep_correct_x1(d, ns, dt, g->grav, g->st); }
-  { Scope s(g, "correct_x2"); launch_correct(d, ns, 1, dt, g->grav, g->st); }
-  { Scope s(g, "correct_x3"); launch_correct(d, ns, 2, dt, g->grav, g->st); }
+  if (g->correct_all) {
+    { Scope s(g, "sweep_x1"); launch_sweep(d, ns, 0, dt, g->grav, g->st); }
+    { Scope s(g, "correct_all"); launch_correct_all(d, ns, dt, g->grav, g->st); }
+  } else {
+    { Scope s(g, "sweep_correct_x1"); launch_sweep_correct_x1(d, ns, dt, g->grav, g->st); }
+    { Scope s(g, "correct_x2"); launch_correct(d, ns, 1, dt, g->grav, g->st); }
+    { Scope s(g, "correct_x3"); launch_correct(d, ns, 2, dt, g->grav, g->st); }
+  }
   if (g->fused_update) {
     Scope s(g, "flux2_update"); launch_flux2_update(d, ns, dt, g->grav, g->keep_flux ? &g->keep : nullptr, g->st);
   } else {

@@ -398,6 +398,219 @@ k_sweep_x1(DevGrid g, const Real *src, Real dt)
   }
 }
 
+// ---- steps 5-8a, 9a for all three directions in one marching kernel ---------------------------------
+// Per CELL instead of per face: the two face states a cell's reconstruction along D produces (left
+// state of its upper face, right state of its lower face) take the SAME transverse correction, the
+// first-pass flux differences across that cell (integrate_3d_ctu.c:978-1158, :1282-1452, :1691-1863),
+// so a thread that owns a zone loads its six first-pass fluxes per variable once and corrects all six
+// face states with them.  A thread owns one (i,j) column and marches along x3 with the primitive
+// variables of three planes in registers (the x3 stencil) and the upper x3 flux carried over as the next
+// zone's lower one; the x1 neighbours come by wavefront shuffle, the x2 neighbours through LDS.  Only
+// eta couples neighbouring zones: eta of a face = 0.5 |lambda_r(right state) - lambda_l(left state)|
+// needs one scalar from the zone below (shuffle / LDS / carried).  Against the three separate correct
+// passes U and the first-pass fluxes are read once instead of three / two times and no flux plane is
+// re-read; lane 0 and row 0 of a block repeat the last lane / row of the block before as providers.
+// Every expression is face_correct's, in the same order: bit-identical under -ffp-contract=off.
+#define CA_TJ 4
+// Primitive variables of one zone for all three sweeps.  cons_to_prim sums the squared momenta in the
+// order of the sweep frame, (Mx^2 + My^2) + Mz^2 with x = D, so the pressure differs in the last bit
+// between the frames: w (global frame d, V1, V2, V3, P, r) carries the pressure of the x3 sweep, p0 and
+// p1 are the pressures the x1 and x2 sweeps see.
+template <int NS>
+AA_DEV void load_prim3(const DevGrid &g, long m, Real w[6], Real &p0, Real &p1)
+{
+  Real u[6];
+#pragma unroll
+  for (int v = 0; v < 5 + NS; v++) u[v] = Uf(g, v)[m];
+  if (!NS) u[5] = 0.0;
+  const Real di = 1.0/u[0];
+  w[0] = u[0]; w[1] = u[1]*di; w[2] = u[2]*di; w[3] = u[3]*di;
+  Real pa = u[4] - 0.5*(sqr(u[1]) + sqr(u[2]) + sqr(u[3]))*di;
+  Real pb = u[4] - 0.5*(sqr(u[2]) + sqr(u[3]) + sqr(u[1]))*di;
+  Real pc = u[4] - 0.5*(sqr(u[3]) + sqr(u[1]) + sqr(u[2]))*di;
+  pa *= g.Gamma_1; pb *= g.Gamma_1; pc *= g.Gamma_1;
+  p0 = rmax(pa, AA_TINY); p1 = rmax(pb, AA_TINY); w[4] = rmax(pc, AA_TINY);
+  w[5] = NS ? u[5]*di : 0.0;
+}
+// sweep-frame primitives of a halo zone, exactly as the sweeps load them
+template <int NS, int D>
+AA_DEV void load_prim_sweep(const DevGrid &g, long m, Real w[6])
+{
+  Real u[6];
+  load_sweep<D, NS>(g.U, g.nc, m, u);
+  cons_to_prim<NS>(u, w, g.Gamma_1);
+}
+// global frame (d, V1, V2, V3, ., r) with the pressure of frame D -> sweep frame of D
+template <int D> AA_DEV void to_sweep(const Real wg[6], Real p, Real ws[6])
+{
+#pragma unroll
+  for (int n = 0; n < 6; n++) ws[n] = wg[gv<D>(n)];
+  ws[4] = p;
+}
+
+struct CellFlux {            // first-pass fluxes across one zone
+  Real dF[3][6];             // F_e(upper face) - F_e(lower face), global frame
+  Real gm[3], ge[3];         // gravity: q_e (phi_r - phi_l) d   and   q_e (F_lo (phi_c - phi_l) + F_hi (phi_r - phi_c))
+};
+
+// one zone along D: reconstruction, gravity kick, conversion, transverse correction, face states stored;
+// returns the wave speeds eta needs: lam_l of the left state it gave to its UPPER face, lam_r of the
+// right state it gave to its LOWER face
+template <int NS, int D, bool GRAV, int ORD>
+AA_DEV void cell_states(const DevGrid &g, long m, Real dt, const Real q[3], const CellFlux &cf, const Real wm[6], const Real w[6],
+                        const Real wp[6], bool store, Real &lam_l, Real &lam_r)
+{
+  constexpr int NV = 5 + NS;
+  const Real dtodx = dt/g.dx[D];
+  const long sD = stride<D>(g);
+  Real wl[6], wr[6];
+  recon_cell<NS, true, ORD, D>(g, m, wm, w, wp, dtodx, wl, wr);
+  if (GRAV) {   // face_work: the left state belongs to the upper face, the right state to the lower one
+    const Real phic = Pf(g, 0)[m], phi_up = Pf(g, 1 + D)[m + sD], phi_lo = Pf(g, 1 + D)[m];
+    wl[1] -= dtodx*(phi_up - phic);
+    wr[1] -= dtodx*(phic - phi_lo);
+  }
+  Real sl[6], sr[6], ul[6], ur[6];
+  prim_to_cons<NS>(wl, sl, g.Gamma_1);
+  prim_to_cons<NS>(wr, sr, g.Gamma_1);
+#pragma unroll
+  for (int n = 0; n < 6; n++) { ul[gv<D>(n)] = sl[n]; ur[gv<D>(n)] = sr[n]; }   // to the global frame
+#pragma unroll
+  for (int e = 0; e < 3; e++) {
+    if (e == D) continue;
+#pragma unroll
+    for (int v = 0; v < NV; v++) { ul[v] -= q[e]*cf.dF[e][v]; ur[v] -= q[e]*cf.dF[e][v]; }
+  }
+  if (GRAV) {
+#pragma unroll
+    for (int e = 0; e < 3; e++) {
+      if (e == D) continue;
+      ur[1 + e] -= cf.gm[e]; ur[4] -= cf.ge[e];
+      ul[1 + e] -= cf.gm[e]; ul[4] -= cf.ge[e];
+    }
+  }
+  if (store) {
+#pragma unroll
+    for (int v = 0; v < NV; v++) { LRf(g, D, 0, v)[m + sD] = ul[v]; LRf(g, D, 1, v)[m] = ur[v]; }
+  }
+#pragma unroll
+  for (int n = 0; n < 6; n++) { sl[n] = ul[gv<D>(n)]; sr[n] = ur[gv<D>(n)]; }
+  const Real cfr = cfast(sr, g.Gamma, g.Gamma_1), cfl = cfast(sl, g.Gamma, g.Gamma_1);
+  lam_r = sr[1]/sr[0] + cfr;
+  lam_l = sl[1]/sl[0] - cfl;
+}
+
+template <int NS, bool GRAV, int ORD>
+__global__ void __launch_bounds__(64*CA_TJ)
+k_correct_all(DevGrid g, Real dt, int kchunk)
+{
+  __shared__ Real s_w[CA_TJ][6][64];
+  __shared__ Real s_l[CA_TJ][64];
+  constexpr int NV = 5 + NS;
+  const int lane = threadIdx.x, row = threadIdx.y;
+  // zones s-1 .. e+1 in every direction get their face states; a block's lane 0 / row 0 is the zone of
+  // the previous block's lane 63 / row CA_TJ-1
+  const int i = g.is - 1 + blockIdx.x*63 + lane, j = g.js - 1 + blockIdx.y*(CA_TJ - 1) + row;
+  const int k0 = g.ks - 1 + blockIdx.z*kchunk;
+  int k1 = k0 + kchunk - 1; if (k1 > g.ke + 1) k1 = g.ke + 1;
+  const int kstart = (blockIdx.z == 0) ? k0 : k0 - 1;          // one provider plane below a later chunk
+  // idle threads beyond the Grid keep valid addresses (their neighbours may read what they load)
+  const int ic = (i <= g.ie + 2) ? i : g.ie + 2, jc = (j <= g.je + 2) ? j : g.je + 2;
+  const long mcol = (long)jc*g.sJ + ic;
+  const bool in = (i <= g.ie + 1) && (j <= g.je + 1);
+  const bool full_lane = (lane > 0) || (blockIdx.x == 0), full_row = (row > 0) || (blockIdx.y == 0);
+  const bool do1 = in && full_row, do2 = in && full_lane, do3 = in && full_lane && full_row;
+  Real q[3];
+#pragma unroll
+  for (int d = 0; d < 3; d++) q[d] = 0.5*(dt/g.dx[d]);
+
+  Real wm3[6], wc[6], wn[6], pc0, pc1, pn0, pn1, f3[6], lam3 = 0.0;
+  load_prim3<NS>(g, (long)(kstart - 1)*g.sK + mcol, wc, pn0, pn1);
+  load_prim3<NS>(g, (long)kstart*g.sK + mcol, wn, pn0, pn1);
+#pragma unroll
+  for (int v = 0; v < 6; v++) f3[v] = (v < NV) ? Ff(g, 2, v)[(long)kstart*g.sK + mcol] : 0.0;
+#pragma nounroll
+  for (int k = kstart; k <= k1; k++) {
+    long m = (long)k*g.sK + mcol;
+    asm volatile("" : "+v"(m));                   // one index for all fields (see k_flux2_update)
+    const bool full = (k >= k0);                  // block-uniform; the provider plane does x3 only
+#pragma unroll
+    for (int n = 0; n < 6; n++) { wm3[n] = wc[n]; wc[n] = wn[n]; }
+    pc0 = pn0; pc1 = pn1;
+    load_prim3<NS>(g, m + g.sK, wn, pn0, pn1);
+    // first-pass fluxes across the zone
+    CellFlux cf;
+#pragma unroll
+    for (int v = 0; v < 6; v++) { cf.dF[0][v] = 0.0; cf.dF[1][v] = 0.0; cf.dF[2][v] = 0.0; }
+    Real mlo[3], mhi[3];
+#pragma unroll
+    for (int v = 0; v < NV; v++) {
+      const Real a0 = Ff(g, 0, v)[m], a1 = Ff(g, 0, v)[m + 1], b0 = Ff(g, 1, v)[m], b1 = Ff(g, 1, v)[m + g.sJ];
+      const Real c0 = f3[v], c1 = Ff(g, 2, v)[m + g.sK];
+      cf.dF[0][v] = a1 - a0; cf.dF[1][v] = b1 - b0; cf.dF[2][v] = c1 - c0;
+      if (v == 0) { mlo[0] = a0; mhi[0] = a1; mlo[1] = b0; mhi[1] = b1; mlo[2] = c0; mhi[2] = c1; }
+      f3[v] = c1;
+    }
+    if (GRAV) {
+      const Real dc = wc[0], phic = Pf(g, 0)[m];
+#pragma unroll
+      for (int e = 0; e < 3; e++) {
+        const Real phir = Pf(g, 1 + e)[m + stride_rt(g, e)], phil = Pf(g, 1 + e)[m];
+        cf.gm[e] = q[e]*(phir - phil)*dc;
+        cf.ge[e] = q[e]*(mlo[e]*(phic - phil) + mhi[e]*(phir - phic));
+      }
+    }
+    if (full) {
+      __builtin_amdgcn_sched_barrier(0);
+      {   // ---- x1: neighbours by shuffle ----
+        Real wm[6], wp[6], ws[6], ll = 0.0, lr = 0.0;
+        to_sweep<0>(wc, pc0, ws);
+#pragma unroll
+        for (int n = 0; n < 6; n++) { wm[n] = __shfl_up(ws[n], 1); wp[n] = __shfl_down(ws[n], 1); }
+        if (lane == 0)  load_prim_sweep<NS, 0>(g, m - 1, wm);
+        if (lane == 63) load_prim_sweep<NS, 0>(g, m + 1, wp);
+        if (do1) cell_states<NS, 0, GRAV, ORD>(g, m, dt, q, cf, wm, ws, wp, true, ll, lr);
+        const Real lprev = __shfl_up(ll, 1);
+        if (do1 && lane > 0) Ef(g, 0)[m] = 0.5*fabs(lr - lprev);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      {   // ---- x2: neighbours through LDS ----
+        Real wm[6], wp[6], ws[6], ll = 0.0, lr = 0.0;
+        to_sweep<1>(wc, pc1, ws);
+#pragma unroll
+        for (int n = 0; n < NV; n++) s_w[row][n][lane] = ws[n];
+        __syncthreads();
+        if (row == 0) load_prim_sweep<NS, 1>(g, m - g.sJ, wm);
+        else {
+#pragma unroll
+          for (int n = 0; n < NV; n++) wm[n] = s_w[row - 1][n][lane];
+          if (!NS) wm[5] = 0.0;
+        }
+        if (row == CA_TJ - 1) load_prim_sweep<NS, 1>(g, m + g.sJ, wp);
+        else {
+#pragma unroll
+          for (int n = 0; n < NV; n++) wp[n] = s_w[row + 1][n][lane];
+          if (!NS) wp[5] = 0.0;
+        }
+        if (do2) cell_states<NS, 1, GRAV, ORD>(g, m, dt, q, cf, wm, ws, wp, true, ll, lr);
+        s_l[row][lane] = ll;
+        __syncthreads();
+        if (do2 && row > 0) Ef(g, 1)[m] = 0.5*fabs(lr - s_l[row - 1][lane]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (do3) {   // ---- x3: the register window; lam3 = lambda_l the zone below gave to this zone's lower face ----
+      Real wm[6], ws[6], wp[6], ll, lr;
+      to_sweep<2>(wm3, wm3[4], wm); to_sweep<2>(wc, wc[4], ws); to_sweep<2>(wn, wn[4], wp);
+      cell_states<NS, 2, GRAV, ORD>(g, m, dt, q, cf, wm, ws, wp, full, ll, lr);
+      if (full && k > g.ks - 1) Ef(g, 2)[m] = 0.5*fabs(lr - lam3);
+      lam3 = ll;
+      if (GRAV && full)   // d^{n+1/2}, :2104-2125
+        g.dhalf[m] = wc[0] - q[0]*cf.dF[0][0] - q[1]*cf.dF[1][0] - q[2]*cf.dF[2][0];
+    }
+  }
+}
+
 // ---- steps 9b-d: second-pass fluxes with the H-correction -----------------------------------
 template <int NS, int D>
 __global__ void __launch_bounds__(256)
@@ -928,6 +1141,23 @@ static void slopes_impl(const DevGrid &g, int dir, hipStream_t st)
   else if (dir == 1) hipLaunchKernelGGL((k_slopes<NS, 1>), grid, blk, 0, st, g);
   else hipLaunchKernelGGL((k_slopes<NS, 2>), grid, blk, 0, st, g);
 }
+// the correct passes of all three directions in one kernel (after the three first passes)
+template <int NS, bool GRAV>
+static void correct_all_impl(const DevGrid &g, Real dt, hipStream_t st)
+{
+  const int ni = g.ie - g.is + 3, nj = g.je - g.js + 3, nk = g.ke - g.ks + 3;    // zones s-1 .. e+1
+  int kc = 32;
+  while (kc > 4 && (long)nblk(ni - 1, 63)*nblk(nj - 1, CA_TJ - 1)*((nk + kc - 1)/kc) < 1024) kc >>= 1;
+  dim3 grid(nblk(ni - 1, 63), nblk(nj - 1, CA_TJ - 1), (nk + kc - 1)/kc), blk(64, CA_TJ);
+  if (g.slope) hipLaunchKernelGGL((k_correct_all<NS, GRAV, 3>), grid, blk, 0, st, g, dt, kc);
+  else         hipLaunchKernelGGL((k_correct_all<NS, GRAV, 2>), grid, blk, 0, st, g, dt, kc);
+}
+void launch_correct_all(const DevGrid &g, int nscal, Real dt, bool grav, hipStream_t st)
+{
+  if (nscal) { if (grav) correct_all_impl<1, true>(g, dt, st); else correct_all_impl<1, false>(g, dt, st); }
+  else       { if (grav) correct_all_impl<0, true>(g, dt, st); else correct_all_impl<0, false>(g, dt, st); }
+}
+
 void launch_slopes(const DevGrid &g, int nscal, int dir, hipStream_t st)
 { if (nscal) slopes_impl<1>(g, dir, st); else slopes_impl<0>(g, dir, st); }
 
