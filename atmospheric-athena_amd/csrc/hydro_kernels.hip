@@ -2,13 +2,16 @@
 // for gfx950 (HYDRO / ADIABATIC / CARTESIAN / PLM-characteristic / Roe + H-correction).
 //
 // Kernel chain of one integrate_3d_ctu() call (reference steps in brackets):
-//   sweep<x1>, sweep<x2>, sweep<x3>   [1-3]  prim conversion + PLM/tracing + gravity kick +
+//   sweep<x2>, sweep<x3>, sweep<x1>   [1-3]  prim conversion + PLM/tracing + gravity kick +
 //                                            first-pass Roe flux; writes only F of that direction
-//   correct<x1>, <x2>, <x3>           [5-8a,9a] same sweep, L/R states re-derived instead of read
+//   correct_all                       [5-8a,9a] per cell: L/R states re-derived instead of read
 //                                            back, transverse flux-gradient corrections, stores the
-//                                            corrected Ul,Ur and eta of the faces (x1 also d^{n+1/2})
-//   flux2<x1>, flux2<x2>, flux2<x3>   [9b-d] etah = max of 9 etas, second-pass Roe flux
-//   update                            [11a,12] gravity source + conservative update of U
+//                                            corrected Ul,Ur, eta of the faces and d^{n+1/2}
+//                                            (small Grids: one tile kernel per direction, x1 fused with
+//                                            its first pass)
+//   flux2_update                      [9b-d,11a,12] etah = max of 9 etas, second-pass Roe fluxes (kept in
+//                                            registers / LDS), gravity source + conservative update of U
+//                                            (AA_FUSED_UPDATE=0: flux2<x1..x3> + update through HBM)
 // All arrays are struct-of-arrays with i fastest (grid.h); every global access of a wavefront
 // is to consecutive i.  The x1 sweep exchanges neighbour cells through LDS; the x2/x3 sweeps
 // march a register sliding window along the sweep direction so no cell is converted or
