@@ -33,10 +33,24 @@ REHEARSAL = bool(os.environ.get("AA_BENCH_REHEARSAL"))
 
 def init_pg(dist, torch, rank, world, local):
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29511")
-    if REHEARSAL:
-        dist.init_process_group("gloo", rank=rank, world_size=world)
-    else:
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+    # RCCL prints its version banner on stdout when the first communicator is created: keep stdout for the
+    # ONE JSON line by pointing fd 1 at stderr until the communicator exists
+    sys.stdout.flush()
+    keep = os.dup(1)
+    os.dup2(2, 1)
+    try:
+        if REHEARSAL:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        t = torch.zeros(1, device="cpu" if REHEARSAL else torch.device("cuda", local))
+        dist.all_reduce(t)
+        if not REHEARSAL:
+            torch.cuda.synchronize()
+    finally:
+        sys.stdout.flush()
+        os.dup2(keep, 1)
+        os.close(keep)
 
 
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/s measured copy)
