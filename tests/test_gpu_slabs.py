@@ -32,9 +32,13 @@ def _worker(rank, world, port, problem, overrides, nsteps, q):
     dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("correct_all", ["0", "1"])
 @pytest.mark.parametrize("problem,nx,nsteps", [("blast", (24, 16, 32), 3), ("ifront", (16, 8, 16), 3),
                                                ("ioniz_sphere", (24, 24, 24), 2)])
-def test_two_slabs_equal_one(problem, nx, nsteps):
+def test_two_slabs_equal_one(problem, nx, nsteps, correct_all, monkeypatch):
+    """correct_all: the tile kernels of the correct passes / the one marching kernel big Grids use (its
+    chunks start at the slab's first plane, so the default build must not depend on where a chunk starts)"""
+    monkeypatch.setenv("AA_CORRECT_ALL", correct_all)      # inherited by the spawned ranks
     import torch.multiprocessing as mp
     aa = importlib.import_module("atmospheric-athena_amd")
     driver = importlib.import_module("atmospheric-athena_amd.driver")
