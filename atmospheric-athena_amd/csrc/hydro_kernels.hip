@@ -572,7 +572,7 @@ k_correct_all(DevGrid g, Real dt, int kchunk)
         for (int n = 0; n < 6; n++) { wm[n] = __shfl_up(ws[n], 1); wp[n] = __shfl_down(ws[n], 1); }
         if (lane == 0)  load_prim_sweep<NS, 0>(g, m - 1, wm);
         if (lane == 63) load_prim_sweep<NS, 0>(g, m + 1, wp);
-        if (do1) cell_states<NS, 0, GRAV, ORD>(g, m, dt, q, cf, wm, ws, wp, true, ll, lr);
+        if (do1) cell_states<NS, 0, GRAV, ORD>(g, m, dt, q, cf, wm, ws, wp, full_lane, ll, lr);   // a provider lane's states were stored by the block before
         const Real lprev = __shfl_up(ll, 1);
         if (do1 && lane > 0) Ef(g, 0)[m] = 0.5*fabs(lr - lprev);
       }
@@ -595,7 +595,7 @@ k_correct_all(DevGrid g, Real dt, int kchunk)
           for (int n = 0; n < NV; n++) wp[n] = s_w[row + 1][n][lane];
           if (!NS) wp[5] = 0.0;
         }
-        if (do2) cell_states<NS, 1, GRAV, ORD>(g, m, dt, q, cf, wm, ws, wp, true, ll, lr);
+        if (do2) cell_states<NS, 1, GRAV, ORD>(g, m, dt, q, cf, wm, ws, wp, full_row, ll, lr);    // ... likewise a provider row's
         s_l[row][lane] = ll;
         __syncthreads();
         if (do2 && row > 0) Ef(g, 1)[m] = 0.5*fabs(lr - s_l[row - 1][lane]);
