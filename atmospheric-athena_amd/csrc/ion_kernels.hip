@@ -253,13 +253,21 @@ k_ion_rates(DevGrid g, IonPar p, DevScalars *sc)
   __shared__ Real red[256];
   long m;
   Real dt_chem_min = DBL_MAX, dt_therm_min = DBL_MAX;
-  for (long lin = (long)blockIdx.x*blockDim.x + threadIdx.x; active_cell(g, lin, m); lin += (long)gridDim.x*blockDim.x) {
-    Cell c; c.d = Uq(g,0)[m]; c.ke = g.kin[m]; c.E = Uq(g,4)[m]; c.s = Uq(g,5)[m];
-    const Real ph = g.ph_rate[m];
+  // software-pipelined like k_ion_update: the next zone's operands are in flight during this zone's rates
+  const long stride = (long)gridDim.x*blockDim.x;
+  long lin = (long)blockIdx.x*blockDim.x + threadIdx.x, m_n = 0;
+  bool have = active_cell(g, lin, m);
+  Real n_d = 0, n_ke = 0, n_E = 0, n_s = 0, n_ph = 0; int2 n_sg = make_int2(0, 0);
+  if (have) { n_d = Uq(g,0)[m]; n_ke = g.kin[m]; n_E = Uq(g,4)[m]; n_s = Uq(g,5)[m]; n_ph = g.ph_rate[m]; n_sg = g.sign[m]; }
+  for (; have; lin += stride, m = m_n) {
+    Cell c; c.d = n_d; c.ke = n_ke; c.E = n_E; c.s = n_s;
+    const Real ph = n_ph;
+    int2 sg = n_sg;
+    have = active_cell(g, lin + stride, m_n);
+    if (have) { n_d = Uq(g,0)[m_n]; n_ke = g.kin[m_n]; n_E = Uq(g,4)[m_n]; n_s = Uq(g,5)[m_n]; n_ph = g.ph_rate[m_n]; n_sg = g.sign[m_n]; }
     const IonQ iq = ion_q(c, p, g.Gamma_1);
     Real lnT; bool cold;
     Real nHdot = chem_rate(iq, ph, p, lnT, cold);
-    int2 sg = g.sign[m];
     const int2 sg0 = sg;
     if (nHdot < 0.0) {
       if (sg.x == 1) sg.y++; else if (sg.y > 0) sg.y--;
@@ -336,14 +344,24 @@ k_ion_update(DevGrid g, IonPar p, Real dt_arg, DevScalars *sc, int dt_from_sc)
   const Real *ke_f = g.kin, *vmx_f = g.vmax;
   // grid-stride: a capped grid keeps the number of same-address atomics at 2 per block (one
   // word sustains only ~90 atomics/us on MI355X)
-  for (long lin = (long)blockIdx.x*blockDim.x + threadIdx.x; active_cell(g, lin, m); lin += (long)gridDim.x*blockDim.x) {
-    Cell c; c.d = Uq(g,0)[m]; c.ke = ke_f[m]; c.E = Uq(g,4)[m]; c.s = Uq(g,5)[m];
+  // software-pipelined: the next zone's operands are in flight while this zone's rates are evaluated
+  // (a log and three exp between the loads and the stores otherwise leave the memory pipe idle)
+  const long stride = (long)gridDim.x*blockDim.x;
+  long lin = (long)blockIdx.x*blockDim.x + threadIdx.x, m_n = 0;
+  bool have = active_cell(g, lin, m);
+  Real n_d = 0, n_ke = 0, n_E = 0, n_s = 0, n_ph = 0, n_e0 = 0; int n_sy = 0;
+  if (have) { n_d = Uq(g,0)[m]; n_ke = ke_f[m]; n_E = Uq(g,4)[m]; n_s = Uq(g,5)[m]; n_ph = g.ph_rate[m]; n_sy = g.sign[m].y; n_e0 = g.e_init[m]; }
+  for (; have; lin += stride, m = m_n) {
+    Cell c; c.d = n_d; c.ke = n_ke; c.E = n_E; c.s = n_s;
     const Real E0 = c.E, s0 = c.s;
-    const Real ph = g.ph_rate[m];
+    const Real ph = n_ph, e_init0 = n_e0;
+    const int sign_y = n_sy;
+    have = active_cell(g, lin + stride, m_n);
+    if (have) { n_d = Uq(g,0)[m_n]; n_ke = ke_f[m_n]; n_E = Uq(g,4)[m_n]; n_s = Uq(g,5)[m_n]; n_ph = g.ph_rate[m_n]; n_sy = g.sign[m_n].y; n_e0 = g.e_init[m_n]; }
     {   // the rates ion_rates derived its time-step limits from, re-evaluated (same code path)
       const IonQ q0 = ion_q(c, p, g.Gamma_1);
       Real lnT; bool cold;
-      const Real nHdot = damp(chem_rate(q0, ph, p, lnT, cold), g.sign[m].y);
+      const Real nHdot = damp(chem_rate(q0, ph, p, lnT, cold), sign_y);
       const Real d_nlim = neutral_lim(c.d, p);
       const bool skip = cold || ((nHdot < 0) && (c.s < 1.0001*d_nlim));
       const Real edot = skip ? 0.0 : therm_rate(q0, ph, lnT, p);
@@ -364,7 +382,7 @@ k_ion_update(DevGrid g, IonPar p, Real dt_arg, DevScalars *sc, int dt_from_sc)
       const bool dtype = (q.n_H > 0.0) ? (ph > 2.0*CION*p.min_area*q.n_H) : (ph / (p.min_area * q.n_H) > 2.0*CION);
       if (!dtype) {
         // e_th_init (ionrad_3d.c:176) = e_init - ke with ke frozen over the ion step: not stored
-        const Real e0 = g.e_init[m], eth0 = e0 - c.ke;
+        const Real e0 = e_init0, eth0 = e0 - c.ke;
         const Real L1 = 1 + p.max_de_therm_step, L2 = 1 + p.max_de_step, L3 = 1 + p.max_dx_step;
         if (ratio_ge(q.e_th, eth0, L1) || ratio_ge(eth0, q.e_th, L1)) counted = true;
         else if ((p.max_de_step > 0) && (ratio_ge(c.E, e0, L2) || ratio_ge(e0, c.E, L2))) counted = true;
