@@ -188,6 +188,16 @@ k_ray_sweep(DevGrid g, IonPar p, Real flux0, int from_edgeflux)
   }
   if (tid == 0) s_nalive = nrays;
   __syncthreads();
+  // the neutral densities of a tile are loaded one tile ahead (during the serial product of the tile
+  // before), so the chain: loads -> exp -> barrier -> serial product -> barrier -> stores does not leave the
+  // memory pipe idle
+  Real sv[RS_PASS];
+#pragma unroll
+  for (int q = 0; q < RS_PASS; q++) {
+    const int r = rsub + RSTEP*q;
+    sv[q] = 0.0;
+    if (g.is + col <= g.ie && r < nrays) sv[q] = Uq(g,5)[(long)k*g.sK + (long)(j0 + r)*g.sJ + g.is + col];
+  }
   for (int c0 = g.is; c0 <= g.ie; c0 += RS_CH) {
     const int i = c0 + col;
     const bool incol = (i <= g.ie);
@@ -200,12 +210,18 @@ k_ray_sweep(DevGrid g, IonPar p, Real flux0, int from_edgeflux)
         const int r = rsub + RSTEP*q;
         nH[q] = 1.0;
         if (incol && r < nrays) {
-          const long m = (long)k*g.sK + (long)(j0 + r)*g.sJ + i;
-          const Real n_H = Uq(g,5)[m] * p.inv_mH;              // ionradplane_3d.c:281
+          const Real n_H = sv[q] * p.inv_mH;                   // ionradplane_3d.c:281
           const Real tau = p.sigma_ph * n_H * g.dx[0];        // :294
           nH[q] = n_H;
           s_etau[r][col] = exp(-tau);
         }
+      }
+    }
+    if (alive && c0 + RS_CH <= g.ie) {                        // next tile (wasted once if every ray dies in this one)
+#pragma unroll
+      for (int q = 0; q < RS_PASS; q++) {
+        const int r = rsub + RSTEP*q;
+        if (i + RS_CH <= g.ie && r < nrays) sv[q] = Uq(g,5)[(long)k*g.sK + (long)(j0 + r)*g.sJ + i + RS_CH];
       }
     }
     __syncthreads();
