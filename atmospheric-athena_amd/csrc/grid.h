@@ -103,6 +103,7 @@ void launch_test_lr_ppm(int nscal, Real gamma, int n, const Real *W, Real dt, Re
 // ---- launch wrappers (ion_kernels.hip) ---------------------------------------------
 void launch_ion_begin(const DevGrid &g, const IonPar &p, hipStream_t st);
 void launch_ray_sweep(const DevGrid &g, const IonPar &p, Real flux0, bool from_edgeflux, hipStream_t st);
+void launch_ray_sweep_rates(const DevGrid &g, const IonPar &p, Real flux0, bool from_edgeflux, DevScalars *sc, hipStream_t st);
 void launch_ion_rates(const DevGrid &g, const IonPar &p, DevScalars *sc, hipStream_t st);
 void launch_ion_update(const DevGrid &g, const IonPar &p, Real dt, DevScalars *sc, hipStream_t st);
 void launch_ion_pick(DevScalars *sc, Real dt_done, Real dt_limit, hipStream_t st);      // ionrad_3d.c:941-963 on the device

@@ -158,14 +158,71 @@ AA_DEV void block_min_to(unsigned long long *addr, Real v, Real *red)
   __syncthreads();
 }
 
+// compute_chem_rates :334-394 + compute_therm_rates :460-557 of one zone: the sign bookkeeping `sg`
+// (last_sign, sign_count) is updated in place, the two time-step limits of the zone are returned.  The
+// rates themselves are not stored (k_ion_update re-evaluates them).
+AA_DEV void rates_cell(const Cell &c, Real ph, int2 &sg, const IonPar &p, Real Gamma_1, DevScalars *sc, Real &dt_chem, Real &dt_therm)
+{
+  const IonQ iq = ion_q(c, p, Gamma_1);
+  Real lnT; bool cold;
+  Real nHdot = chem_rate(iq, ph, p, lnT, cold);
+  if (nHdot < 0.0) {
+    if (sg.x == 1) sg.y++; else if (sg.y > 0) sg.y--;
+    sg.x = -1;
+  } else if (nHdot > 0.0) {
+    if (sg.x == -1) sg.y++; else if (sg.y > 0) sg.y--;
+    sg.x = 1;
+  } else { sg.x = 0; sg.y = 0; }
+  nHdot = damp(nHdot, sg.y);
+  const Real d_nlim = neutral_lim(c.d, p);
+  const Real inv_n = 1.0/nHdot;
+  Real dt1, dt2;
+  if (nHdot == 0.0) { dt1 = dt2 = DBL_MAX; }
+  else if (nHdot > 0.0) {
+    dt1 = p.cx1 * iq.n_e * inv_n;               // max_dx_iter/(1+max_dx_iter) * n_e / nHdot
+    dt2 = p.max_dx_iter * iq.n_H * inv_n;
+  } else if (c.s > 1.0001*d_nlim) {
+    dt1 = -p.max_dx_iter * iq.n_e * inv_n;
+    dt2 = -p.cx1 * iq.n_H * inv_n;
+  } else { dt1 = dt2 = DBL_MAX; }
+  dt_chem = (dt1 < dt2) ? dt1 : dt2;
+  if (dt_chem < 0) { atomicExch(&sc->neg_dt_chem, 1); dt_chem = DBL_MAX; }
+  dt_therm = DBL_MAX;
+  const bool skip = cold || ((nHdot < 0) && (c.s < 1.0001*d_nlim));
+  if (!skip) {
+    const Real edot = therm_rate(iq, ph, lnT, p);
+    Real t1, t2; bool have = true;
+    const Real inv_e = 1.0/edot;
+    if (edot == 0.0) { t1 = t2 = DBL_MAX; }
+    else if (edot > 0.0) {
+      t1 = p.max_de_iter * c.E * inv_e;
+      t2 = p.max_de_therm_iter * iq.e_th * inv_e;
+    } else {
+      const Real e_sp_min = p.tfloor * p.k_B / (iq.muq * Gamma_1);
+      const Real e_th_min = e_sp_min * c.d;
+      const Real e_min = c.ke + e_th_min;
+      if ((iq.e_th*p.ie1 < e_th_min) && (c.E*p.ie2 < e_min)) have = false;   // e/(1+max_de*_iter)
+      t1 = -p.ce2 * c.E * inv_e;
+      t2 = -p.ce1 * iq.e_th * inv_e;
+    }
+    if (have) dt_therm = (t1 < t2) ? t1 : t2;
+    if (!(dt_therm == dt_therm) || dt_therm < 0) dt_therm = DBL_MAX;
+  }
+}
+
 // ---- ray sweep --------------------------------------------------------------------------------
 #ifndef RS_CH
 #define RS_CH 32
 #endif
 #define RS_RAYS 64
 #define RS_PASS (RS_RAYS*RS_CH/256)      /* cells per thread per tile */
-__global__ void __launch_bounds__(256)
-k_ray_sweep(DevGrid g, IonPar p, Real flux0, int from_edgeflux)
+// RATES: the chemistry / thermal rates of every zone (compute_chem_rates + compute_therm_rates) are
+// evaluated right where its ph_rate is produced, and the two time-step limits reduced here: the separate
+// k_ion_rates pass (which re-reads s0 and ph_rate and is bound by its log + 3 exp per zone) then overlaps
+// with the loads / barriers / serial product this kernel is bound by.
+template <bool RATES>
+__global__ void __launch_bounds__(256, RATES ? 3 : 4)
+k_ray_sweep(DevGrid g, IonPar p, Real flux0, int from_edgeflux, DevScalars *sc)
 {
   __shared__ Real s_etau[RS_RAYS][RS_CH + 1];
   __shared__ Real s_fin[RS_RAYS][RS_CH + 1];
@@ -173,6 +230,7 @@ k_ray_sweep(DevGrid g, IonPar p, Real flux0, int from_edgeflux)
   __shared__ Real s_f0[RS_RAYS];                              // flux entering the ray (denominator of :299)
   __shared__ int  s_dead[RS_RAYS];
   __shared__ int  s_nalive;
+  __shared__ Real red[RATES ? 256 : 1];
   const int tid = threadIdx.x;
   const int j0 = g.js + blockIdx.x*RS_RAYS;                 // rays: 64 consecutive j at one k
   const int k = g.ks + blockIdx.y;
@@ -180,6 +238,7 @@ k_ray_sweep(DevGrid g, IonPar p, Real flux0, int from_edgeflux)
   const int col = tid % RS_CH, rsub = tid / RS_CH;           // 256/RS_CH ray-rows per pass
   constexpr int RSTEP = 256/RS_CH;
   const long efp = (long)(g.Nx1 + 1), efrow = (long)(g.Nx2 + 1)*efp;
+  Real dt_chem_min = DBL_MAX, dt_therm_min = DBL_MAX;
   if (tid < RS_RAYS) {
     Real f0 = flux0;
     if (from_edgeflux && tid < nrays)                          // :271 refined level: the parent's flux
@@ -191,11 +250,11 @@ k_ray_sweep(DevGrid g, IonPar p, Real flux0, int from_edgeflux)
   // the neutral densities of a tile are loaded one tile ahead (during the serial product of the tile
   // before), so the chain: loads -> exp -> barrier -> serial product -> barrier -> stores does not leave the
   // memory pipe idle
-  Real sv[RS_PASS];
+  Real sv[RS_PASS], sn[RS_PASS];
 #pragma unroll
   for (int q = 0; q < RS_PASS; q++) {
     const int r = rsub + RSTEP*q;
-    sv[q] = 0.0;
+    sv[q] = 0.0; sn[q] = 0.0;
     if (g.is + col <= g.ie && r < nrays) sv[q] = Uq(g,5)[(long)k*g.sK + (long)(j0 + r)*g.sJ + g.is + col];
   }
   for (int c0 = g.is; c0 <= g.ie; c0 += RS_CH) {
@@ -217,11 +276,11 @@ k_ray_sweep(DevGrid g, IonPar p, Real flux0, int from_edgeflux)
         }
       }
     }
-    if (alive && c0 + RS_CH <= g.ie) {                        // next tile (wasted once if every ray dies in this one)
+    if ((alive || RATES) && c0 + RS_CH <= g.ie) {             // next tile (without RATES wasted once, when every ray dies in this one)
 #pragma unroll
       for (int q = 0; q < RS_PASS; q++) {
         const int r = rsub + RSTEP*q;
-        if (i + RS_CH <= g.ie && r < nrays) sv[q] = Uq(g,5)[(long)k*g.sK + (long)(j0 + r)*g.sJ + i + RS_CH];
+        if (i + RS_CH <= g.ie && r < nrays) sn[q] = Uq(g,5)[(long)k*g.sK + (long)(j0 + r)*g.sJ + i + RS_CH];
       }
     }
     __syncthreads();
@@ -252,12 +311,28 @@ k_ray_sweep(DevGrid g, IonPar p, Real flux0, int from_edgeflux)
         }
         g.ph_rate[m] = kph;                                   // ph_rate_init + "+=" (:55, :297)
         g.edgeflux[(long)(k - g.ks)*efrow + (long)(j0 + r - g.js)*efp + (i - g.is)] = fin;
+        if (RATES) {
+          Cell c; c.d = Uq(g,0)[m]; c.ke = g.kin[m]; c.E = Uq(g,4)[m]; c.s = sv[q];
+          int2 sg = g.sign[m];
+          const int2 sg0 = sg;
+          Real dt_chem, dt_therm;
+          rates_cell(c, kph, sg, p, g.Gamma_1, sc, dt_chem, dt_therm);
+          if (sg.x != sg0.x || sg.y != sg0.y) g.sign[m] = sg;
+          dt_chem_min = rmin(dt_chem_min, dt_chem);
+          dt_therm_min = rmin(dt_therm_min, dt_therm);
+        }
       }
     }
+#pragma unroll
+    for (int q = 0; q < RS_PASS; q++) sv[q] = sn[q];
     __syncthreads();
   }
   if (tid < nrays)                                            // :308
     g.edgeflux[(long)(k - g.ks)*efrow + (long)(j0 + tid - g.js)*efp + g.Nx1] = s_dead[tid] ? 0.0 : s_flux[tid];
+  if (RATES) {
+    block_min_to(&sc->dt_chem, dt_chem_min, red);
+    block_min_to(&sc->dt_therm, dt_therm_min, red);
+  }
 }
 
 // ---- rates: compute_chem_rates :334-394 + compute_therm_rates :460-557.  Streams d, ke, E, s0,
@@ -281,53 +356,10 @@ k_ion_rates(DevGrid g, IonPar p, DevScalars *sc)
     int2 sg = n_sg;
     have = active_cell(g, lin + stride, m_n);
     if (have) { n_d = Uq(g,0)[m_n]; n_ke = g.kin[m_n]; n_E = Uq(g,4)[m_n]; n_s = Uq(g,5)[m_n]; n_ph = g.ph_rate[m_n]; n_sg = g.sign[m_n]; }
-    const IonQ iq = ion_q(c, p, g.Gamma_1);
-    Real lnT; bool cold;
-    Real nHdot = chem_rate(iq, ph, p, lnT, cold);
     const int2 sg0 = sg;
-    if (nHdot < 0.0) {
-      if (sg.x == 1) sg.y++; else if (sg.y > 0) sg.y--;
-      sg.x = -1;
-    } else if (nHdot > 0.0) {
-      if (sg.x == -1) sg.y++; else if (sg.y > 0) sg.y--;
-      sg.x = 1;
-    } else { sg.x = 0; sg.y = 0; }
+    Real dt_chem, dt_therm;
+    rates_cell(c, ph, sg, p, g.Gamma_1, sc, dt_chem, dt_therm);
     if (sg.x != sg0.x || sg.y != sg0.y) g.sign[m] = sg;
-    nHdot = damp(nHdot, sg.y);
-    const Real d_nlim = neutral_lim(c.d, p);
-    const Real inv_n = 1.0/nHdot;
-    Real dt1, dt2;
-    if (nHdot == 0.0) { dt1 = dt2 = DBL_MAX; }
-    else if (nHdot > 0.0) {
-      dt1 = p.cx1 * iq.n_e * inv_n;               // max_dx_iter/(1+max_dx_iter) * n_e / nHdot
-      dt2 = p.max_dx_iter * iq.n_H * inv_n;
-    } else if (c.s > 1.0001*d_nlim) {
-      dt1 = -p.max_dx_iter * iq.n_e * inv_n;
-      dt2 = -p.cx1 * iq.n_H * inv_n;
-    } else { dt1 = dt2 = DBL_MAX; }
-    Real dt_chem = (dt1 < dt2) ? dt1 : dt2;
-    if (dt_chem < 0) { atomicExch(&sc->neg_dt_chem, 1); dt_chem = DBL_MAX; }
-    Real dt_therm = DBL_MAX;
-    const bool skip = cold || ((nHdot < 0) && (c.s < 1.0001*d_nlim));
-    if (!skip) {
-      const Real edot = therm_rate(iq, ph, lnT, p);
-      Real t1, t2; bool have = true;
-      const Real inv_e = 1.0/edot;
-      if (edot == 0.0) { t1 = t2 = DBL_MAX; }
-      else if (edot > 0.0) {
-        t1 = p.max_de_iter * c.E * inv_e;
-        t2 = p.max_de_therm_iter * iq.e_th * inv_e;
-      } else {
-        const Real e_sp_min = p.tfloor * p.k_B / (iq.muq * g.Gamma_1);
-        const Real e_th_min = e_sp_min * c.d;
-        const Real e_min = c.ke + e_th_min;
-        if ((iq.e_th*p.ie1 < e_th_min) && (c.E*p.ie2 < e_min)) have = false;   // e/(1+max_de*_iter)
-        t1 = -p.ce2 * c.E * inv_e;
-        t2 = -p.ce1 * iq.e_th * inv_e;
-      }
-      if (have) dt_therm = (t1 < t2) ? t1 : t2;
-      if (!(dt_therm == dt_therm) || dt_therm < 0) dt_therm = DBL_MAX;
-    }
     dt_chem_min = rmin(dt_chem_min, dt_chem);
     dt_therm_min = rmin(dt_therm_min, dt_therm);
   }
@@ -441,7 +473,10 @@ static inline unsigned nblk(long n, int b) { return (unsigned)((n + b - 1)/b); }
 void launch_ion_begin(const DevGrid &g, const IonPar &p, hipStream_t st)
 { const long n = (long)g.Nx1*g.Nx2*g.Nx3; hipLaunchKernelGGL(k_ion_begin, dim3(nblk(n, 256)), dim3(256), 0, st, g, p); }
 void launch_ray_sweep(const DevGrid &g, const IonPar &p, Real flux0, bool from_edgeflux, hipStream_t st)
-{ hipLaunchKernelGGL(k_ray_sweep, dim3((g.Nx2 + RS_RAYS - 1)/RS_RAYS, g.Nx3), dim3(256), 0, st, g, p, flux0, from_edgeflux ? 1 : 0); }
+{ hipLaunchKernelGGL(k_ray_sweep<false>, dim3((g.Nx2 + RS_RAYS - 1)/RS_RAYS, g.Nx3), dim3(256), 0, st, g, p, flux0, from_edgeflux ? 1 : 0, (DevScalars*)nullptr); }
+// ray sweep + the rates of every zone + the two time-step limits (what launch_ray_sweep + launch_ion_rates do)
+void launch_ray_sweep_rates(const DevGrid &g, const IonPar &p, Real flux0, bool from_edgeflux, DevScalars *sc, hipStream_t st)
+{ hipLaunchKernelGGL(k_ray_sweep<true>, dim3((g.Nx2 + RS_RAYS - 1)/RS_RAYS, g.Nx3), dim3(256), 0, st, g, p, flux0, from_edgeflux ? 1 : 0, sc); }
 void launch_ion_rates(const DevGrid &g, const IonPar &p, DevScalars *sc, hipStream_t st)
 { const long n = (long)g.Nx1*g.Nx2*g.Nx3; const unsigned nb = reduce_blocks(n);
   hipLaunchKernelGGL(k_ion_rates, dim3(nb), dim3(256), 0, st, g, p, sc); }

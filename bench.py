@@ -65,7 +65,7 @@ KERNEL_BYTES = {
     "flux2_x3": 8 * (12 + 3 + 6), "update": 8 * (6 + 18 + 6),
     "correct_all": 8 * (6 + 18 + 4 + 36 + 3 + 1),   # U, first-pass fluxes, phi in; L/R states x3, eta x3, d^{n+1/2} out
     "flux2_update": 8 * (36 + 3 + 6 + 5 + 6),     # L/R states of 3 directions, eta x3, U in, phi x4 + d^{n+1/2}, U out
-    "ray_sweep": 8 * (1 + 2), "ion_rates": 8 * (5 + 1), "ion_update": 8 * (5 + 1 + 2 + 0.5 + 2),
+    "ray_sweep": 8 * (1 + 2), "ray_sweep_rates": 8 * (1 + 2) + 8 * (3 + 1),   # + d, ke, E and the int2 sign word "ion_rates": 8 * (5 + 1), "ion_update": 8 * (5 + 1 + 2 + 0.5 + 2),
     "ion_begin": 8 * (6 + 6), "bvals_mhd": 0, "new_dt": 8 * 5, "pinned_cells": 0, "ppm_slopes": 3 * 8 * (6 + 6),
 }
 

@@ -42,7 +42,7 @@ for r in csv.DictReader(open(one(trace, "*_kernel_stats.csv"))):
 if len(sys.argv) > 5:
     import json
     import re
-    alias = [(r"k_ion_update", "ion_update"), (r"k_ion_rates", "ion_rates"), (r"k_ray_sweep", "ray_sweep"),
+    alias = [(r"k_ion_update", "ion_update"), (r"k_ion_rates", "ion_rates"), (r"k_ray_sweep<true>", "ray_sweep_rates"), (r"k_ray_sweep<false>", "ray_sweep"),
              (r"k_ion_begin", "ion_begin"), (r"k_cfl", "new_dt"), (r"k_update<", "update"),
              (r"k_flux2_update<", "flux2_update"), (r"k_correct_all<", "correct_all"),
              (r"k_sweep_tile<1, 1, true, 1", "correct_x2"), (r"k_sweep_tile<1, 2, true, 1", "correct_x3"),

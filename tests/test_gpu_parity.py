@@ -207,7 +207,14 @@ def test_ifront_vs_oracle(aa, lib, nx, nsteps, strict):
     g.close()
 
 
-def test_ifront_golden_fixture(aa, lib):
+@pytest.fixture(params=["0", "1"])
+def fused_rates(request, monkeypatch):
+    """AA_FUSED_RATES: the rates in their own pass (small Grids' default) / inside the ray sweep (big Grids')"""
+    monkeypatch.setenv("AA_FUSED_RATES", request.param)
+    return request.param
+
+
+def test_ifront_golden_fixture(aa, lib, fused_rates):
     gz = np.load(os.path.join(GOLD, "ifront_16x8x8_n6.npz"))
     o, g, nv, trace = run_pair(aa, lib, "ifront", (16, 8, 8), 6, False)
     assert [t[1] for t in trace] == [int(x) for x in gz["niter"]]
@@ -221,7 +228,7 @@ def test_ifront_golden_fixture(aa, lib):
 
 @pytest.mark.parametrize("strict", [True, False])
 @pytest.mark.parametrize("nx,nsteps", [((20, 20, 20), 1), ((24, 16, 12), 2), ((40, 40, 40), 2)])
-def test_ioniz_sphere_vs_oracle(aa, lib, nx, nsteps, strict):
+def test_ioniz_sphere_vs_oracle(aa, lib, nx, nsteps, strict, fused_rates):
     """Hydro + static gravity (potential tables) + ion radiation + per-step core reset."""
     o, g, nv, trace = run_pair(aa, lib, "ioniz_sphere", nx, nsteps, strict)
     assert [t[0] for t in trace] == [t[1] for t in trace], trace
