@@ -74,3 +74,25 @@ def test_fused_fast_build_within_rounding(problem, ov, nstep, mode, monkeypatch)
             assert np.all(b[..., c] == 0)
         else:
             assert np.nanmax(np.abs(a[..., c] - b[..., c])) <= 1e-12 * scale     # fused multiply-adds only
+
+
+@pytest.mark.parametrize("problem,n,nstep", [("ioniz_sphere", 48, 10), ("ifront", 32, 8), ("blast", 40, 10)])
+def test_every_fused_kernel_on_against_every_one_off_strict(problem, n, nstep, monkeypatch):
+    """Big-Grid defaults (k_correct_all, k_flux2_update, rates inside the ray sweep) forced on at a small
+    size, against the chain with none of them, over enough steps for the radiation to sub-cycle a few dozen
+    times: same sub-cycle counts, time, dt, state and EdgeFlux, bit for bit."""
+    aa = importlib.import_module("atmospheric-athena_amd")
+    lib = importlib.import_module("atmospheric-athena_amd.lib")
+    out = []
+    for on in ("0", "1"):
+        for k in ("AA_FUSED_UPDATE", "AA_CORRECT_ALL", "AA_FUSED_RATES"):
+            monkeypatch.setenv(k, on)
+        run = aa.config.load(os.path.join(DECKS, "athinput." + problem), [f"domain1/Nx{d}={n}" for d in (1, 2, 3)], problem)
+        g = lib.setup_problem(aa.config.slab(run), 0, True)
+        g.start()
+        its = [g.step() for _ in range(nstep)]
+        out.append((g.download(), g.download_edgeflux() if run.ion else np.zeros(1), its, g.mesh_state()))
+        g.close()
+    a, b = out
+    assert a[2] == b[2] and a[3] == b[3]
+    assert np.array_equal(a[0], b[0], equal_nan=True) and np.array_equal(a[1], b[1], equal_nan=True)
