@@ -171,11 +171,23 @@ def bench_smr(a, aa, torch, rank, world, local):
                           "subcycle_trace_per_level": trace, "final_dt": m.dt,
                           "hbm_resident_GB_rank0": sum(g.device_bytes() for g in grids) / 1e9, "setup_s": t_setup}}
         if not a.no_kernel_times:
-            prof = {}
+            prof, dom = {}, None
             for l, g in enumerate(grids):
                 for k, (ms, n) in g.profile().items():
                     prof[f"L{l}.{k}"] = ms / a.steps
+                    if n and KERNEL_BYTES.get(k, 0) > 0 and (dom is None or ms > dom[2]):   # boundary / inter-level kernels have no per-zone figure
+                        dom = (l, k, ms, n)
             out["kernel_ms_per_step_rank0"] = dict(sorted(prof.items(), key=lambda kv: -kv[1]))
+            if dom:
+                # the dominant kernel (of whichever level): compulsory bytes of one launch on that level's slab /
+                # its mean duration
+                l, k, ms, n = dom
+                cfg = grids[l].cfg if hasattr(grids[l], "cfg") else lv[l]
+                ncell = cfg.Nx[0] * cfg.Nx[1] * cfg.Nx[2]
+                bpl = KERNEL_BYTES.get(k, 0) * ncell
+                ach = bpl / (ms / n * 1e-3) / 1e9
+                out["roofline"] = {"bound": "hbm", "kernel": f"L{l}.{k}", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                   "frac": ach / HBM_PEAK_GBS, "traffic": None, "bytes_per_launch": bpl, "avg_launch_ms": ms / n}
         print(json.dumps(out))
     if multi:
         dist.barrier()
@@ -296,7 +308,7 @@ def main():
         # roofline of the dominant kernel: compulsory bytes of one launch / its mean duration
         # (hipEvent pairs recorded on the launch stream inside the timed region)
         if prof:
-            dom = max(prof, key=lambda k: prof[k][0])
+            dom = max(prof, key=lambda k: prof[k][0] if KERNEL_BYTES.get(k, 0) > 0 else -1.0)   # (boundary kernels have no per-zone figure)
             ms, n = prof[dom]
             ncell = nx ** 3
             bpl = KERNEL_BYTES.get(dom, 0) * ncell * ((5 + run.nscal) / 6.0 if not dom.startswith("ion") and dom != "ray_sweep" else 1.0)
