@@ -39,6 +39,7 @@ def test_two_slabs_equal_one(problem, nx, nsteps, correct_all, monkeypatch):
     """correct_all: the tile kernels of the correct passes / the one marching kernel big Grids use (its
     chunks start at the slab's first plane, so the default build must not depend on where a chunk starts)"""
     monkeypatch.setenv("AA_CORRECT_ALL", correct_all)      # inherited by the spawned ranks
+    monkeypatch.setenv("AA_FUSED_RATES", correct_all)      # likewise the rates inside / after the ray sweep
     import torch.multiprocessing as mp
     aa = importlib.import_module("atmospheric-athena_amd")
     driver = importlib.import_module("atmospheric-athena_amd.driver")
