@@ -699,27 +699,38 @@ k_update(DevGrid g, const Real *dhalf, Real dt, Order ord)
 // Levels of a Mesh (KEEP): RestrictCorrect reads the second-pass fluxes on the level boundaries, so the
 // faces on those planes (KeepPlanes: a few planes per direction) are stored as well.
 #define FU_TJ 8
+// operands of one second-pass Riemann problem: the corrected face states (sweep frame) and the 9 etas
+struct FaceIn { Real ul[6], ur[6], eta[9]; };
 template <int NS, int D>
-AA_DEV void face_flux2(const DevGrid &g, long m, Real f[6])
+AA_DEV void face_load(const DevGrid &g, long m, FaceIn &in)
 {
   const long sD = stride<D>(g), ml = m - sD;
   constexpr int E1 = (D == 0) ? 1 : 0, E2 = (D == 2) ? 1 : 2;
   const long s1 = stride<E1>(g), s2 = stride<E2>(g);
   const Real *e1 = Ef(g, E1), *e2 = Ef(g, E2);
-  Real etah = rmax(e1[ml], e1[m]);
-  etah = rmax(etah, e1[ml + s1]);
-  etah = rmax(etah, e1[m + s1]);
-  etah = rmax(etah, e2[ml]);
-  etah = rmax(etah, e2[m]);
-  etah = rmax(etah, e2[ml + s2]);
-  etah = rmax(etah, e2[m + s2]);
-  etah = rmax(etah, Ef(g, D)[m]);
-  Real ul[6], ur[6], wl[6], wr[6];
-  load_sweep<D, NS>(LRf(g, D, 0, 0), g.nc, m, ul);
-  load_sweep<D, NS>(LRf(g, D, 1, 0), g.nc, m, ur);
-  cons_to_prim<NS>(ul, wl, g.Gamma_1);
-  cons_to_prim<NS>(ur, wr, g.Gamma_1);
-  flux_roe<NS>(ul, ur, wl, wr, etah, g.Gamma, g.Gamma_1, f);
+  in.eta[0] = e1[ml]; in.eta[1] = e1[m]; in.eta[2] = e1[ml + s1]; in.eta[3] = e1[m + s1];
+  in.eta[4] = e2[ml]; in.eta[5] = e2[m]; in.eta[6] = e2[ml + s2]; in.eta[7] = e2[m + s2];
+  in.eta[8] = Ef(g, D)[m];
+  load_sweep<D, NS>(LRf(g, D, 0, 0), g.nc, m, in.ul);
+  load_sweep<D, NS>(LRf(g, D, 1, 0), g.nc, m, in.ur);
+}
+template <int NS>
+AA_DEV void face_solve(const DevGrid &g, const FaceIn &in, Real f[6])
+{
+  Real etah = rmax(in.eta[0], in.eta[1]);
+#pragma unroll
+  for (int n = 2; n < 9; n++) etah = rmax(etah, in.eta[n]);
+  Real wl[6], wr[6];
+  cons_to_prim<NS>(in.ul, wl, g.Gamma_1);
+  cons_to_prim<NS>(in.ur, wr, g.Gamma_1);
+  flux_roe<NS>(in.ul, in.ur, wl, wr, etah, g.Gamma, g.Gamma_1, f);
+}
+template <int NS, int D>
+AA_DEV void face_flux2(const DevGrid &g, long m, Real f[6])
+{
+  FaceIn in;
+  face_load<NS, D>(g, m, in);
+  face_solve<NS>(g, in, f);
 }
 
 AA_DEV bool on_plane(const KeepPlanes &kp, int d, int x)
@@ -755,28 +766,40 @@ k_flux2_update(DevGrid g, const Real *dhalf, Real dt, int kchunk, KeepPlanes kp)
     face_flux2<NS, 2>(g, (long)k0*g.sK + mcol, f3lo);
     if (KEEP && on_plane(kp, 2, k0)) store_sweep<2, NS>(Ff(g, 2, 0), g.nc, (long)k0*g.sK + mcol, f3lo);
   }
+  // Software pipeline: the operands of the NEXT Riemann problem are requested before the current one is
+  // solved (x2's during the x1 solve, x3's during x2's, the next zone's x1's during x3's), so that with two
+  // wavefronts per SIMD the memory pipe is not idle while a wavefront computes.
+  FaceIn in1, in2;
+  {
+    long m0 = (long)k0*g.sK + mcol;
+    asm volatile("" : "+v"(m0));
+    if (need1) face_load<NS, 0>(g, m0, in1);
+  }
   for (int k = k0; k <= k1; k++) {
     // (opaque to the optimiser: otherwise every one of the ~60 field pointers becomes its own
     //  strength-reduced 64-bit induction variable and the kernel spills)
     long m = (long)k*g.sK + mcol;
     asm volatile("" : "+v"(m));
+    if (need2) face_load<NS, 1>(g, m, in2);
     __builtin_amdgcn_sched_barrier(0);
     {
       Real f[6];
 #pragma unroll
       for (int n = 0; n < 6; n++) f[n] = 0.0;
-      if (need1) face_flux2<NS, 0>(g, m, f);
+      if (need1) face_solve<NS>(g, in1, f);
       if (keep1) store_sweep<0, NS>(Ff(g, 0, 0), g.nc, m, f);
 #pragma unroll
       for (int n = 0; n < NV; n++) d1[n] = __shfl_down(f[n], 1) - f[n];
       m1lo = f[0]; m1hi = __shfl_down(f[0], 1);
     }
     __builtin_amdgcn_sched_barrier(0);
+    if (cell) face_load<NS, 2>(g, m + g.sK, in1);           // (in1 is free: reused for the x3 face)
+    __builtin_amdgcn_sched_barrier(0);
     {
       Real f[6];
 #pragma unroll
       for (int n = 0; n < 6; n++) f[n] = 0.0;
-      if (need2) face_flux2<NS, 1>(g, m, f);
+      if (need2) face_solve<NS>(g, in2, f);
       if (keep2) store_sweep<1, NS>(Ff(g, 1, 0), g.nc, m, f);
 #pragma unroll
       for (int n = 0; n < NV; n++) s_f2[row][n][lane] = f[n];
@@ -790,17 +813,21 @@ k_flux2_update(DevGrid g, const Real *dhalf, Real dt, int kchunk, KeepPlanes kp)
       __syncthreads();
     }
     __builtin_amdgcn_sched_barrier(0);
-    if (cell) {
-      Real f[6];
-      face_flux2<NS, 2>(g, m + g.sK, f);
-      if (KEEP && on_plane(kp, 2, k + 1)) store_sweep<2, NS>(Ff(g, 2, 0), g.nc, m + g.sK, f);
+    Real f3[6];
 #pragma unroll
-      for (int n = 0; n < NV; n++) d3[n] = f[n] - f3lo[n];
-      m3hi = f[0];
+    for (int n = 0; n < 6; n++) f3[n] = 0.0;
+    if (cell) face_solve<NS>(g, in1, f3);
+    __builtin_amdgcn_sched_barrier(0);
+    if (need1 && k < k1) face_load<NS, 0>(g, m + g.sK, in1);  // the next zone's x1 face
+    __builtin_amdgcn_sched_barrier(0);
+    if (cell) {
+      if (KEEP && on_plane(kp, 2, k + 1)) store_sweep<2, NS>(Ff(g, 2, 0), g.nc, m + g.sK, f3);
+#pragma unroll
+      for (int n = 0; n < NV; n++) d3[n] = f3[n] - f3lo[n];
+      m3hi = f3[0];
       const Real m3lo = f3lo[0];
 #pragma unroll
-      for (int n = 0; n < NV; n++) f3lo[n] = f[n];
-      __builtin_amdgcn_sched_barrier(0);
+      for (int n = 0; n < NV; n++) f3lo[n] = f3[n];
       Real u[6];
 #pragma unroll
       for (int v = 0; v < NV; v++) u[v] = Uf(g, v)[m];
