@@ -30,6 +30,7 @@ struct aa_grid {
   bool fused_update = false;           // second-pass fluxes + update in one kernel (AA_FUSED_UPDATE=0 at aa_create: the unfused chain)
   bool correct_all = false;            // the three correct passes in one kernel (k_correct_all): Grids of 2^21 zones or more, or AA_CORRECT_ALL
   bool fused_rates = false;            // rates evaluated inside the ray sweep (k_ray_sweep<true>): 2^17 rays or more, or AA_FUSED_RATES
+  bool vl_predict = false;             // van Leer predictor as one kernel (k_vl_predict): 2^18 zones or more, or AA_VL_PREDICT
   bool keep_flux = false;              // a level of an aa_mesh: RestrictCorrect reads the second-pass fluxes ...
   aa::KeepPlanes keep = {0, {{0}}};        // ... on these face planes (own boundaries + the child's outline)
   double time = 0, dt = 0; int nstep = 0;

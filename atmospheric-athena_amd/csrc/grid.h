@@ -81,6 +81,7 @@ struct KeepPlanes { int n; int p[3][4]; };
 void launch_flux2_update(const DevGrid &g, int nscal, Real dt, bool grav, const KeepPlanes *keep, hipStream_t st);   // flux2 x3 + update fused
 void launch_vl_flux1(const DevGrid &g, int nscal, int dir, hipStream_t st);
 void launch_vl_uhalf(const DevGrid &g, int nscal, Real dt, bool grav, hipStream_t st);
+void launch_vl_predict(const DevGrid &g, int nscal, Real dt, bool grav, hipStream_t st);   // vl_flux1 x3 + vl_uhalf fused
 void launch_vl_flux2(const DevGrid &g, int nscal, int dir, Real dt, hipStream_t st);
 void launch_bc(const DevGrid &g, int nscal, int dir, int side, int flag, hipStream_t st);
 void launch_bc_dir(const DevGrid &g, int nscal, int dir, int flag_in, int flag_out, hipStream_t st);   // both sides, one launch

@@ -884,6 +884,158 @@ k_vl_flux1(DevGrid g)
 
 // steps 5-6: U^{n+1/2} over [s-3, e+3]^3 (x1, x2, x3 flux differences in that order, then the
 // gravity predictor); stored in the first six face-state arrays
+// ---- van Leer predictor in one marching kernel: donor-cell fluxes + U^{n+1/2} (integrate_3d_vl.c:153-510) --
+// The first-order fluxes only feed U^{n+1/2}, so they never go to HBM: thread = (i,j) column marching along
+// x3 as in k_flux2_update.  The state of a zone is converted once for all three sweeps: d, V and r are the
+// same in every frame, the pressure (cons_to_prim) and the round-tripped energy (prim_to_cons, the reference
+// converts W back to U, :166-169) sum the squared velocities in sweep-frame order, so both come in three
+// variants.  The lower x1 face takes its left state from the previous lane (shuffle), the lower x2 face
+// from the row below (loaded), the lower x3 face from the previous step (registers); the upper fluxes come
+// from the next lane / row / step.  Lane 63 and row VP_TJ-1 only provide fluxes.
+#define VP_TJ 8
+struct VlState { Real w[6], p[3], e[3]; };       // w: d, V1, V2, V3, (unused), r;  p, e per sweep frame
+template <int NS>
+AA_DEV void vl_state(const DevGrid &g, long m, VlState &q)
+{
+  Real u[6];
+#pragma unroll
+  for (int v = 0; v < 5 + NS; v++) u[v] = Uf(g, v)[m];
+  if (!NS) u[5] = 0.0;
+#pragma unroll
+  for (int D = 0; D < 3; D++) {
+    // exactly cons_to_prim / prim_to_cons on the state rotated into the frame of D
+    Real us[6], ws[6], ub[6];
+    us[0] = u[0]; us[1] = u[1 + D]; us[2] = u[1 + (D + 1) % 3]; us[3] = u[1 + (D + 2) % 3]; us[4] = u[4]; us[5] = u[5];
+    cons_to_prim<NS>(us, ws, g.Gamma_1);
+    prim_to_cons<NS>(ws, ub, g.Gamma_1);
+    q.p[D] = ws[4]; q.e[D] = ub[4];
+    if (D == 0) { q.w[0] = ws[0]; q.w[1] = ws[1]; q.w[2] = ws[2]; q.w[3] = ws[3]; q.w[4] = 0.0; q.w[5] = ws[5]; }
+  }
+}
+// sweep-frame primitive and (round-tripped) conserved state of direction D
+template <int NS, int D>
+AA_DEV void vl_rotate(const VlState &q, Real w[6], Real u[6])
+{
+  w[0] = q.w[0]; w[1] = q.w[1 + D]; w[2] = q.w[1 + (D + 1) % 3]; w[3] = q.w[1 + (D + 2) % 3]; w[4] = q.p[D]; w[5] = q.w[5];
+  u[0] = w[0]; u[1] = w[0]*w[1]; u[2] = w[0]*w[2]; u[3] = w[0]*w[3]; u[4] = q.e[D]; u[5] = NS ? w[5]*w[0] : 0.0;
+}
+template <int NS, int D>
+AA_DEV void vl_face(const DevGrid &g, const VlState &lo, const VlState &hi, Real f[6])
+{
+  Real wl[6], wr[6], ul[6], ur[6];
+  vl_rotate<NS, D>(lo, wl, ul);
+  vl_rotate<NS, D>(hi, wr, ur);
+  flux_roe<NS>(ul, ur, wl, wr, 0.0, g.Gamma, g.Gamma_1, f);
+}
+
+template <int NS, bool GRAV>
+__global__ void __launch_bounds__(64*VP_TJ)
+k_vl_predict(DevGrid g, Real dt, int kchunk)
+{
+  __shared__ Real s_f2[VP_TJ][6][64];
+  constexpr int NV = 5 + NS;
+  const int lane = threadIdx.x, row = threadIdx.y;
+  const int lo[3] = {g.is - 3, g.js - 3, g.ks - 3}, hi[3] = {g.ie + 3, g.je + 3, g.ke + 3};   // zones that get U^{n+1/2}
+  const int i = lo[0] + blockIdx.x*63 + lane, j = lo[1] + blockIdx.y*(VP_TJ - 1) + row;
+  const int k0 = lo[2] + blockIdx.z*kchunk;
+  int k1 = k0 + kchunk - 1; if (k1 > hi[2]) k1 = hi[2];
+  const bool cell = (lane < 63) && (row < VP_TJ - 1) && (i <= hi[0]) && (j <= hi[1]);
+  const bool need1 = (row < VP_TJ - 1) && (j <= hi[1]) && (i <= hi[0] + 1);      // lower x1 face of (i,j)
+  const bool need2 = (lane < 63) && (i <= hi[0]) && (j <= hi[1] + 1);            // lower x2 face of (i,j)
+  const int ic = (i <= hi[0] + 1) ? i : hi[0] + 1, jc = (j <= hi[1] + 1) ? j : hi[1] + 1;
+  const long mcol = (long)jc*g.sJ + ic;
+  Real q[3];
+#pragma unroll
+  for (int d = 0; d < 3; d++) q[d] = 0.5*(dt/g.dx[d]);
+  VlState below, here;
+  Real f3lo[6];
+#pragma unroll
+  for (int n = 0; n < 6; n++) f3lo[n] = 0.0;
+  vl_state<NS>(g, (long)(k0 - 1)*g.sK + mcol, below);
+  vl_state<NS>(g, (long)k0*g.sK + mcol, here);
+  if (cell) vl_face<NS, 2>(g, below, here, f3lo);                                // face k0
+  for (int k = k0; k <= k1; k++) {
+    long m = (long)k*g.sK + mcol;
+    asm volatile("" : "+v"(m));                   // one index for all fields (see k_flux2_update)
+    VlState above;
+    vl_state<NS>(g, m + g.sK, above);
+    Real d1[6], d2[6], d3[6], m1lo, m1hi, m2lo, m2hi = 0.0, m3lo, m3hi;
+#pragma unroll
+    for (int n = 0; n < 6; n++) d2[n] = 0.0;
+    __builtin_amdgcn_sched_barrier(0);
+    {   // ---- x1: left state from the previous lane ----
+      VlState left;
+#pragma unroll
+      for (int n = 0; n < 6; n++) left.w[n] = __shfl_up(here.w[n], 1);
+      left.p[0] = __shfl_up(here.p[0], 1); left.e[0] = __shfl_up(here.e[0], 1);
+      left.p[1] = left.p[2] = left.e[1] = left.e[2] = 0.0;
+      if (lane == 0) vl_state<NS>(g, m - 1, left);
+      Real f[6];
+#pragma unroll
+      for (int n = 0; n < 6; n++) f[n] = 0.0;
+      if (need1) vl_face<NS, 0>(g, left, here, f);
+#pragma unroll
+      for (int n = 0; n < NV; n++) d1[n] = __shfl_down(f[n], 1) - f[n];
+      m1lo = f[0]; m1hi = __shfl_down(f[0], 1);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    {   // ---- x2: left state = the zone of the row below (converted here: it is in L1/L2) ----
+      VlState left;
+      vl_state<NS>(g, m - g.sJ, left);
+      Real f[6];
+#pragma unroll
+      for (int n = 0; n < 6; n++) f[n] = 0.0;
+      if (need2) vl_face<NS, 1>(g, left, here, f);
+#pragma unroll
+      for (int n = 0; n < NV; n++) s_f2[row][n][lane] = f[n];
+      __syncthreads();
+      if (row < VP_TJ - 1) {
+#pragma unroll
+        for (int n = 0; n < NV; n++) d2[n] = s_f2[row + 1][n][lane] - f[n];
+        m2hi = s_f2[row + 1][0][lane];
+      }
+      m2lo = f[0];
+      __syncthreads();
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (cell) {
+      Real f[6];
+      vl_face<NS, 2>(g, here, above, f);                                         // face k+1
+#pragma unroll
+      for (int n = 0; n < NV; n++) d3[n] = f[n] - f3lo[n];
+      m3lo = f3lo[0]; m3hi = f[0];
+#pragma unroll
+      for (int n = 0; n < NV; n++) f3lo[n] = f[n];
+      Real u[6];
+#pragma unroll
+      for (int v = 0; v < NV; v++) u[v] = Uf(g, v)[m];
+      const Real d0 = u[0];
+      // :436-478 flux differences x1, x2, x3; sweep component n of direction D is global variable gv<D>(n)
+#pragma unroll
+      for (int n = 0; n < NV; n++) u[gv<0>(n)] -= q[0]*d1[n];
+#pragma unroll
+      for (int n = 0; n < NV; n++) u[gv<1>(n)] -= q[1]*d2[n];
+#pragma unroll
+      for (int n = 0; n < NV; n++) u[gv<2>(n)] -= q[2]*d3[n];
+      if (GRAV) {   // :480-510
+        const Real phic = Pf(g, 0)[m];
+        { const Real phir = Pf(g, 1)[m + 1], phil = Pf(g, 1)[m];
+          u[1] -= q[0]*(phir - phil)*d0;
+          u[4] -= q[0]*(m1lo*(phic - phil) + m1hi*(phir - phic)); }
+        { const Real phir = Pf(g, 2)[m + g.sJ], phil = Pf(g, 2)[m];
+          u[2] -= q[1]*(phir - phil)*d0;
+          u[4] -= q[1]*(m2lo*(phic - phil) + m2hi*(phir - phic)); }
+        { const Real phir = Pf(g, 3)[m + g.sK], phil = Pf(g, 3)[m];
+          u[3] -= q[2]*(phir - phil)*d0;
+          u[4] -= q[2]*(m3lo*(phic - phil) + m3hi*(phir - phic)); }
+      }
+#pragma unroll
+      for (int v = 0; v < NV; v++) LRf(g, 0, 0, v)[m] = u[v];
+    }
+    below = here; here = above;
+  }
+}
+
 template <int NS, bool GRAV>
 __global__ void __launch_bounds__(256)
 k_vl_uhalf(DevGrid g, Real dt)
@@ -1224,6 +1376,18 @@ static void vl_flux1_impl(const DevGrid &g, int dir, hipStream_t st)
 }
 void launch_vl_flux1(const DevGrid &g, int nscal, int dir, hipStream_t st)
 { if (nscal) vl_flux1_impl<1>(g, dir, st); else vl_flux1_impl<0>(g, dir, st); }
+// donor-cell fluxes + U^{n+1/2} in one kernel (what launch_vl_flux1 x3 + launch_vl_uhalf do)
+void launch_vl_predict(const DevGrid &g, int nscal, Real dt, bool grav, hipStream_t st)
+{
+  const int ni = g.ie - g.is + 7, nj = g.je - g.js + 7, nk = g.ke - g.ks + 7;
+  int kc = 32;
+  while (kc > 4 && (long)nblk(ni, 63)*nblk(nj, VP_TJ - 1)*((nk + kc - 1)/kc) < 1024) kc >>= 1;
+  dim3 grid(nblk(ni, 63), nblk(nj, VP_TJ - 1), (nk + kc - 1)/kc), blk(64, VP_TJ);
+  if (nscal) { if (grav) hipLaunchKernelGGL((k_vl_predict<1, true>), grid, blk, 0, st, g, dt, kc);
+               else      hipLaunchKernelGGL((k_vl_predict<1, false>), grid, blk, 0, st, g, dt, kc); }
+  else       { if (grav) hipLaunchKernelGGL((k_vl_predict<0, true>), grid, blk, 0, st, g, dt, kc);
+               else      hipLaunchKernelGGL((k_vl_predict<0, false>), grid, blk, 0, st, g, dt, kc); }
+}
 void launch_vl_uhalf(const DevGrid &g, int nscal, Real dt, bool grav, hipStream_t st)
 {
   const long n = (long)(g.ie - g.is + 7)*(g.je - g.js + 7)*(g.ke - g.ks + 7);

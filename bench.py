@@ -60,6 +60,7 @@ HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/s mea
 KERNEL_BYTES = {
     "sweep_x1": 8 * (6 + 6), "sweep_x2": 8 * (6 + 6), "sweep_x3": 8 * (6 + 6),
     "sweep_correct_x1": 8 * (6 + 12 + 6 + 12 + 1), "correct_x1": 8 * (6 + 12 + 12 + 1), "correct_x2": 8 * (6 + 12 + 12 + 1), "correct_x3": 8 * (6 + 12 + 12 + 1),
+    "vl_predict": 8 * (6 + 6 + 4),                   # U in, U^{n+1/2} out, phi x4
     "vl_flux1": 8 * (6 + 18), "vl_uhalf": 8 * (6 + 18 + 6), "vl_flux2_x1": 8 * 12, "vl_flux2_x2": 8 * 12,
     "vl_flux2_x3": 8 * 12, "flux2_x1": 8 * (12 + 3 + 6), "flux2_x2": 8 * (12 + 3 + 6),
     "flux2_x3": 8 * (12 + 3 + 6), "update": 8 * (6 + 18 + 6),

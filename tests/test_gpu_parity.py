@@ -208,6 +208,13 @@ def test_ifront_vs_oracle(aa, lib, nx, nsteps, strict):
 
 
 @pytest.fixture(params=["0", "1"])
+def vl_predict(request, monkeypatch):
+    """AA_VL_PREDICT: the van Leer predictor as four kernels (small Grids' default) / as one (big Grids')"""
+    monkeypatch.setenv("AA_VL_PREDICT", request.param)
+    return request.param
+
+
+@pytest.fixture(params=["0", "1"])
 def fused_rates(request, monkeypatch):
     """AA_FUSED_RATES: the rates in their own pass (small Grids' default) / inside the ray sweep (big Grids')"""
     monkeypatch.setenv("AA_FUSED_RATES", request.param)
@@ -247,7 +254,7 @@ def test_ioniz_sphere_vs_oracle(aa, lib, nx, nsteps, strict, fused_rates):
 
 
 @pytest.mark.parametrize("nx,nsteps", [((16, 12, 20), 4), ((40, 24, 32), 3)])
-def test_vl_blast_bitwise_strict(aa, lib, nx, nsteps):
+def test_vl_blast_bitwise_strict(aa, lib, nx, nsteps, vl_predict):
     """van Leer integrator (integrate_3d_vl.c, NO_H_CORRECTION), hydro only: bit for bit."""
     o, g, nv, trace = run_pair(aa, lib, "blast", nx, nsteps, True, "vl")
     for (_, _, dto, dtg, to, tg) in trace:
@@ -257,7 +264,7 @@ def test_vl_blast_bitwise_strict(aa, lib, nx, nsteps):
     g.close()
 
 
-def test_vl_golden_fixtures(aa, lib):
+def test_vl_golden_fixtures(aa, lib, vl_predict):
     gz = np.load(os.path.join(GOLD, "vl_blast_16x12x20_n4.npz"))
     o, g, nv, trace = run_pair(aa, lib, "blast", (16, 12, 20), 4, True, "vl")
     assert np.array_equal(g.download()[4:-4, 4:-4, 4:-4, :nv], gz["U"][..., :nv]) and g.dt == float(gz["dt"])
@@ -270,7 +277,7 @@ def test_vl_golden_fixtures(aa, lib):
 
 
 @pytest.mark.parametrize("problem,nx,nsteps", [("ifront", (16, 8, 8), 3), ("ioniz_sphere", (32, 32, 32), 2)])
-def test_vl_ion_problems_vs_oracle(aa, lib, problem, nx, nsteps):
+def test_vl_ion_problems_vs_oracle(aa, lib, problem, nx, nsteps, vl_predict):
     o, g, nv, trace = run_pair(aa, lib, problem, nx, nsteps, False, "vl")
     assert [t[0] for t in trace] == [t[1] for t in trace], trace
     err = relerr(g.download()[4:-4, 4:-4, 4:-4, :nv], o.active[..., :nv])
