@@ -857,6 +857,7 @@ k_flux2_update(DevGrid g, const Real *dhalf, Real dt, int kchunk, KeepPlanes kp)
 }
 
 // ---- van Leer integrator (integrators/integrate_3d_vl.c, NO_H_CORRECTION) --------------------
+// Predictor on small Grids: k_vl_flux1 x3 + k_vl_uhalf below; on big ones k_vl_predict further down does both.
 // steps 1-3: first-order (donor-cell) fluxes, Wl = W[c-1], Wr = W[c], over the whole ghost range
 template <int NS, int D>
 __global__ void __launch_bounds__(256)
