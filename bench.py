@@ -5,15 +5,29 @@ One "step" = one pass of the reference's main loop (main.c:519-669) on synthetic
 resident in HBM: ion-radiation step with its sub-cycles (ionrad_3d.c:862) + ghost zones +
 3-D CTU hydro step (integrate_3d_ctu.c:110) + per-step core reset + new_dt + ghost zones.
 Workload at N=1: BASELINE.json configs[3] on one GPU, tst/massloss/athinput.ioniz_sphere_hires
-keys at 512^3 single level (hydro + static gravity + ion radiation).  With N>1 the box is cut
-into x3 slabs of 512x512x512 each (weak scaling: 512 x 512 x 512*N zones, same dx), halo
-exchange and scalar reductions over RCCL.
+keys at 512^3 single level (hydro + static gravity + ion radiation).
+
+Regime.  The deck starts with dt = 4.7e-6 s, which new_dt lets double once per step; around step 19
+(512^3) dt reaches the chemical time scale and the ion step takes 30-80 sub-cycles for a few dozen
+steps; from about step 60 on dt sits at the CFL limit (5.4-6.5 s) and the ion step needs ONE
+sub-cycle per step, for as long as the run can be followed (profiles/r02_regime_512.txt).  The timed
+region therefore starts after an untimed SPIN-UP that runs until that stationary state is reached
+(--spinup auto: dt no longer doubling and the sub-cycle count unchanged over 12 consecutive steps,
+at most 200 steps; --spinup N: exactly N steps, e.g. 19 to land in the burst of sub-cycles).
+`value` is what the timed region gives; `phases` breaks it into the hydro chain, one radiation
+sub-cycle and the rest, each with its roofline on SURVEY 8(d)'s algorithmic bytes (96 B per
+cell-update, 64 B per cell and sub-cycle), so the number can be re-derived for any sub-cycle count.
+
+N>1: one rank per GPU, x3 slabs, halo exchange and scalar reductions over RCCL.  Default = weak
+scaling (every GPU holds nx^3 zones, the box grows along x3 at the same dx); --strong cuts ONE
+nx^3 box into N slabs (BASELINE configs[3]: 512^3 on 8 GPUs = 64-plane slabs).
 
 Prints ONE JSON line (rank 0).  `value` = active zones advanced per second by the whole job.
 """
 import argparse
 import importlib
 import json
+import math
 import os
 import re
 import shutil
@@ -54,51 +68,129 @@ def init_pg(dist, torch, rank, world, local):
 
 
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/s measured copy)
+FP64_PEAK_TFLOPS = 78.6  # vector FP64, public spec; hydro is bound by this, not by HBM
+HYDRO_FLOP_PER_CELL = 5.0e3   # SURVEY 8(d) hand count for one CTU cell-update (+2e3 with an analytic potential: tabulated here)
 
 # Compulsory bytes per cell of each kernel = distinct doubles it must read + write per zone
-# (NVAR=6): the figures are derived in DESIGN.md section 4.
+# (NVAR=6): the figures are derived in DESIGN.md section 3.
 KERNEL_BYTES = {
     "sweep_x1": 8 * (6 + 6), "sweep_x2": 8 * (6 + 6), "sweep_x3": 8 * (6 + 6),
-    "sweep_correct_x1": 8 * (6 + 12 + 6 + 12 + 1), "correct_x1": 8 * (6 + 12 + 12 + 1), "correct_x2": 8 * (6 + 12 + 12 + 1), "correct_x3": 8 * (6 + 12 + 12 + 1),
+    "sweep_correct_x1": 8 * (6 + 12 + 6 + 12 + 1), "correct_x1": 8 * (6 + 12 + 12 + 1), "correct_x2": 8 * (6 + 12 + 12 + 1),
+    "correct_x3": 8 * (6 + 12 + 12 + 1),
     "vl_predict": 8 * (6 + 6 + 4),                   # U in, U^{n+1/2} out, phi x4
     "vl_flux1": 8 * (6 + 18), "vl_uhalf": 8 * (6 + 18 + 6), "vl_flux2_x1": 8 * 12, "vl_flux2_x2": 8 * 12,
     "vl_flux2_x3": 8 * 12, "flux2_x1": 8 * (12 + 3 + 6), "flux2_x2": 8 * (12 + 3 + 6),
     "flux2_x3": 8 * (12 + 3 + 6), "update": 8 * (6 + 18 + 6),
     "correct_all": 8 * (6 + 18 + 4 + 36 + 3 + 1),   # U, first-pass fluxes, phi in; L/R states x3, eta x3, d^{n+1/2} out
     "flux2_update": 8 * (36 + 3 + 6 + 5 + 6),     # L/R states of 3 directions, eta x3, U in, phi x4 + d^{n+1/2}, U out
-    "ray_sweep": 8 * (1 + 2), "ray_sweep_rates": 8 * (1 + 2) + 8 * (3 + 1),   # + d, ke, E and the int2 sign word "ion_rates": 8 * (5 + 1), "ion_update": 8 * (5 + 1 + 2 + 0.5 + 2),
-    "ion_begin": 8 * (6 + 6), "bvals_mhd": 0, "new_dt": 8 * 5, "pinned_cells": 0, "ppm_slopes": 3 * 8 * (6 + 6),
+    "ray_sweep": 8 * (1 + 2),
+    "ray_sweep_rates": 8 * (1 + 2) + 8 * (3 + 1),   # + d, ke, E and the int2 sign word
+    "ion_rates": 8 * (5 + 1),
+    "ion_update": 8 * (5 + 1 + 2 + 0.5 + 2),
+    # the one-kernel sub-cycle: d, ke, E, s0, incoming flux of the previous sweep, e_init, vmax in;
+    # E, s0, incoming flux out; 2-byte sign word in + out
+    "ion_pass": 8 * (7 + 3) + 4,
+    "ion_pass_first": 8 * (4 + 1) + 4, "ion_pass_last": 8 * (7 + 2) + 2,
+    "ion_begin": 8 * (6 + 6), "ion_finish": 8 * 2,
+    "bvals_mhd": 0, "new_dt": 8 * 5, "pinned_cells": 0, "ppm_slopes": 3 * 8 * (6 + 6),
 }
+HYDRO_KERNELS = ("sweep_", "sweep_correct_x1", "correct_", "flux2_", "update", "vl_", "ppm_slopes")
+SUBCYCLE_KERNELS = ("ray_sweep", "ray_sweep_rates", "ion_rates", "ion_update", "ion_pass", "ion_pass_first", "ion_pass_last", "ion_pick")
 
 
-def cpu_baseline(nx=64, nlim=40):
-    """The REAL reference (oracle/_ref, built from /root/reference by oracle/Makefile.ref) timed
-    on one host core on a bounded sample of the same deck; falls back to the CPU restatement."""
-    exe = os.path.join(ROOT, "oracle", "_ref", "athena_ioniz_sphere")
-    deck = os.path.join(ROOT, PKG, "decks", "athinput.ioniz_sphere")
-    if os.path.exists(exe):
-        tmp = tempfile.mkdtemp(prefix="cpu_baseline_")
-        try:
-            t0 = time.time()
-            pr = subprocess.run([exe, "-i", deck, "-d", os.path.join(tmp, "run"),
-                                 f"domain1/Nx1={nx}", f"domain1/Nx2={nx}", f"domain1/Nx3={nx}", f"time/nlim={nlim}"],
-                                stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, cwd=tmp, timeout=600)
-            wall = time.time() - t0
-            m = re.search(r"zone-cycles/wall-second = ([0-9.eE+-]+)", pr.stdout)
-            its = [int(x) for x in re.findall(r"Radiation done in (\d+) iterations", pr.stderr)]
-            if pr.returncode == 0 and m:
-                return {"value": float(m.group(1)), "unit": "cell-updates/s", "cores": 1, "kind": "reference",
-                        "sample": f"ioniz_sphere {nx}^3, {nlim} steps, sub-cycles/step {its}, {wall:.1f} s wall"}
-        except Exception:
-            pass
-        finally:
-            shutil.rmtree(tmp, ignore_errors=True)
+def kernel_class(name):
+    if name in SUBCYCLE_KERNELS:
+        return "subcycle"
+    if name.startswith("ion_"):
+        return "ion_step"
+    for h in HYDRO_KERNELS:
+        if name == h or (h.endswith("_") and name.startswith(h)):
+            return "hydro"
+    return "other"
+
+
+def dominant_kernel(prof):
+    """argmax of total time over the kernels that have a per-zone byte figure (boundary kernels have none)."""
+    cand = {k: v[0] for k, v in prof.items() if KERNEL_BYTES.get(k, 0) > 0 and v[1] > 0}
+    return max(cand, key=cand.get) if cand else None
+
+
+# ---- CPU baseline: the REAL reference, MPI build, on the host cores of this box ------------------------------
+MPIEXEC = "/opt/conda/bin/mpiexec"   # MPICH 3.3.2 of the image (off PATH; SURVEY 8c)
+
+
+def _rank_grid(cores, nx):
+    """x2 x x3 split (never x1: the rays travel along x1), as many ranks as cores allow."""
+    best = (1, 1)
+    for p2 in range(1, cores + 1):
+        for p3 in range(p2, cores + 1):
+            if p2 * p3 <= cores and nx % p2 == 0 and nx % p3 == 0 and (p2 * p3, p2) > (best[0] * best[1], best[0]):
+                best = (p2, p3)
+    return best
+
+
+def _run_ref(exe, deck, tmp, tag, nx, nlim, ranks):
+    args = [exe, "-i", deck, "-d", os.path.join(tmp, tag), f"domain1/Nx1={nx}", f"domain1/Nx2={nx}", f"domain1/Nx3={nx}",
+            f"time/nlim={nlim}"]
+    if ranks > 1:
+        args = [MPIEXEC, "-n", str(ranks)] + args
+    t0 = time.time()
+    pr = subprocess.run(args, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, cwd=tmp, timeout=900)
+    wall = time.time() - t0
+    if pr.returncode != 0:
+        raise RuntimeError(f"{os.path.basename(exe)} rc={pr.returncode}: {pr.stderr[-300:]}")
+    m = re.findall(r"zone-cycles/wall-second = ([0-9.eE+-]+)", pr.stdout)
+    its = [int(x) for x in re.findall(r"Radiation done in (\d+) iterations", pr.stderr)][::max(1, ranks)]
+    return float(m[-1]), its, wall     # the last line is the total over ranks (main.c:735)
+
+
+def cpu_baseline(nx=128, nlim=12):
+    """The reference's own MPI CPU path (oracle/_ref/athena_*_mpi: the unmodified sources built with
+    MPI_PARALLEL by oracle/Makefile.ref) on the host cores of this box, on a bounded sample of the same
+    deck: the coupled run, and the same deck without ion radiation, so that the cost of a hydro step and
+    of a radiation sub-cycle can be stated separately (ns per zone), like the GPU's `phases`."""
+    ref = os.path.join(ROOT, "oracle", "_ref")
+    deck0 = os.path.join(ROOT, PKG, "decks", "athinput.ioniz_sphere")
+    cores = min(len(os.sched_getaffinity(0)), 16)      # a one-GPU box's CPU share
+    tmp = tempfile.mkdtemp(prefix="cpu_baseline_")
+    try:
+        if os.path.exists(os.path.join(ref, "athena_ioniz_sphere_mpi")) and os.path.exists(MPIEXEC):
+            try:
+                p2, p3 = _rank_grid(cores, nx)
+                deck = os.path.join(tmp, "athinput")
+                txt = open(deck0).read().replace("<domain1>", f"<domain1>\nNGrid_x1 = 1\nNGrid_x2 = {p2}\nNGrid_x3 = {p3}", 1)
+                open(deck, "w").write(txt)
+                zc, its, wall = _run_ref(os.path.join(ref, "athena_ioniz_sphere_mpi"), deck, tmp, "ion", nx, nlim, p2 * p3)
+                out = {"value": zc, "unit": "cell-updates/s", "cores": p2 * p3, "kind": "reference-mpi",
+                       "sample": f"ioniz_sphere {nx}^3, {nlim} steps, NGrid 1x{p2}x{p3} (mpiexec -n {p2 * p3}), sub-cycles/step {its}, {wall:.1f} s wall"}
+                nsub = sum(its) / max(1, len(its))
+                ns_step = 1e9 / zc
+                out["nsub_mean"] = nsub
+                if os.path.exists(os.path.join(ref, "athena_sphere_hydro_mpi")):
+                    zh, _, wh = _run_ref(os.path.join(ref, "athena_sphere_hydro_mpi"), deck, tmp, "hyd", nx, nlim, p2 * p3)
+                    out["per_hydro_step_ns_per_zone"] = 1e9 / zh
+                    out["per_subcycle_ns_per_zone"] = max(0.0, ns_step - 1e9 / zh) / max(nsub, 1e-30)
+                    out["sample"] += f"; same deck without ion radiation {zh:.3e} zone-cycles/s ({wh:.1f} s wall)"
+                return out
+            except Exception as e:      # e.g. hydra cannot start on this host: fall back to one core
+                sys.stderr.write(f"[bench] MPI reference baseline failed ({e}); falling back to one core\n")
+        exe = os.path.join(ref, "athena_ioniz_sphere")
+        if os.path.exists(exe):
+            try:
+                zc, its, wall = _run_ref(exe, deck0, tmp, "ser", 64, 40, 1)
+                return {"value": zc, "unit": "cell-updates/s", "cores": 1, "kind": "reference",
+                        "sample": f"ioniz_sphere 64^3, 40 steps, sub-cycles/step {its}, {wall:.1f} s wall",
+                        "nsub_mean": sum(its) / max(1, len(its))}
+            except Exception as e:
+                sys.stderr.write(f"[bench] serial reference baseline failed ({e}); falling back to the CPU restatement\n")
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import orc
-    s = orc.make_sim("ioniz_sphere", [f"domain1/Nx{d}={nx}" for d in (1, 2, 3)]).start()
-    t0 = time.time(); its = [s.step() for _ in range(nlim)]; wall = time.time() - t0
-    return {"value": nx ** 3 * nlim / wall, "unit": "cell-updates/s", "cores": 1, "kind": "port",
-            "sample": f"ioniz_sphere {nx}^3, {nlim} steps, sub-cycles/step {its}, {wall:.1f} s wall"}
+    s = orc.make_sim("ioniz_sphere", [f"domain1/Nx{d}=64" for d in (1, 2, 3)]).start()
+    t0 = time.time(); its = [s.step() for _ in range(40)]; wall = time.time() - t0
+    return {"value": 64 ** 3 * 40 / wall, "unit": "cell-updates/s", "cores": 1, "kind": "port",
+            "sample": f"ioniz_sphere 64^3, 40 steps, sub-cycles/step {its}, {wall:.1f} s wall", "nsub_mean": sum(its) / 40.0}
 
 
 def bench_smr(a, aa, torch, rank, world, local):
@@ -197,15 +289,35 @@ def bench_smr(a, aa, torch, rank, world, local):
         m.close()
 
 
+def spin_up(drv, mode, log):
+    """Untimed steps that carry the deck from its initial state into the stationary regime (module docstring)."""
+    if mode != "auto":
+        for _ in range(int(mode)):
+            log.append(drv.step())
+        return
+    quiet = 0
+    while len(log) < 200 and quiet < 12:
+        dt0 = drv.dt
+        n = drv.step()
+        log.append(n)
+        steady = drv.dt < 1.5 * dt0 and len(log) >= 2 and n == log[-2]
+        quiet = quiet + 1 if steady else 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--nx", type=int, default=512, help="zones per direction per GPU (default: the 512^3 workload)")
     ap.add_argument("--problem", default="ioniz_sphere", choices=["ioniz_sphere", "ifront", "blast"])
     ap.add_argument("--integrator", default="ctu", choices=["ctu", "vl"])
     ap.add_argument("--order", type=int, default=2, choices=[2, 3], help="reconstruction: 2 PLM (default), 3 PPM (--with-order=3)")
+    ap.add_argument("--spinup", default="auto",
+                    help="untimed steps before the warm-up: 'auto' (until dt has stopped doubling and the sub-cycle count is "
+                         "stationary, at most 200) or a number (0: the start-up transient; 19 at 512^3: the burst of sub-cycles)")
+    ap.add_argument("--strong", action="store_true", help="N>1: cut ONE nx^3 box into N x3 slabs (default: weak scaling, nx^3 per GPU)")
+    ap.add_argument("--strict", action="store_true", help="time libathena_amd_strict.so (-ffp-contract=off: the bit-exact hydro build)")
     ap.add_argument("--smr", action="store_true",
                     help="BASELINE.json configs[4]: 2-level static mesh refinement, per GPU a root slab of nx^3 zones plus "
                          "nx^3 level-1 zones over the central half of the box (not the headline line)")
@@ -236,22 +348,25 @@ def main():
     if a.smr:
         return bench_smr(a, aa, torch, rank, world, local)
     force = bool(os.environ.get("AA_FORCE_DISTRIBUTED"))
-    if world > 1 or force:
+    multi = world > 1 or force
+    if multi:
         import torch.distributed as dist
         init_pg(dist, torch, rank, world, local)
 
-    # weak scaling: every GPU holds nx^3 zones; the box grows along x3 with the same dx
     nx = a.nx
+    nx3 = nx if a.strong else nx * world
     deck = os.path.join(ROOT, PKG, "decks", "athinput." + a.problem)
     par = aa.athinput.ParTable.from_file(deck)
     x3min, x3max = par.getd("domain1", "x3min"), par.getd("domain1", "x3max")
-    par.cmdline([f"domain1/Nx1={nx}", f"domain1/Nx2={nx}", f"domain1/Nx3={nx * world}",
-                 f"domain1/x3max={x3min + (x3max - x3min) * world!r}"])
+    ov = [f"domain1/Nx1={nx}", f"domain1/Nx2={nx}", f"domain1/Nx3={nx3}"]
+    if not a.strong:      # weak scaling: the box grows along x3 with the same dx
+        ov.append(f"domain1/x3max={x3min + (x3max - x3min) * world!r}")
+    par.cmdline(ov)
     run = aa.config.from_par(par, a.problem)
     run.integrator = a.integrator
     run.order = a.order
     t_setup = time.time()
-    drv = driver.Driver(run, None, rank, world, local)
+    drv = driver.Driver(run, None, rank, world, local, strict=True if a.strict else None)
     if a.ionized_slab:
         if not run.ion:
             sys.exit("--ionized-slab needs a problem with ion radiation")
@@ -264,16 +379,24 @@ def main():
     t_setup = time.time() - t_setup
 
     def barrier():
-        if world > 1 or force:
+        if multi:
             dist.barrier()
         torch.cuda.synchronize()
 
+    spin_log = []
+    t_spin = time.time()
+    spin_up(drv, a.spinup if run.ion else "0", spin_log)
+    torch.cuda.synchronize()
+    t_spin = time.time() - t_spin
     for _ in range(a.warmup):
         drv.step()
+    hist0 = drv.history()
     eng.g.profile_reset()
     if not a.no_kernel_times:
         eng.g.profile_enable(True)
     drv.niter_trace.clear()
+    if hasattr(drv, "host_syncs"):
+        drv.host_syncs = 0
     barrier()
     t0 = time.perf_counter()
     for _ in range(a.steps):
@@ -283,60 +406,111 @@ def main():
     prof = eng.g.profile() if not a.no_kernel_times else {}
     eng.g.profile_enable(False)
     elapsed = t1 - t0
-    if world > 1 or force:
+    if multi:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    hist1 = drv.history()      # volume integrals (dump_history.c): a NaN or Inf anywhere in the state shows up here
 
     if rank == 0:
-        zones = nx * nx * nx * world
-        nsub = sum(drv.niter_trace) / max(1, len(drv.niter_trace))
+        zones_gpu = run.rootNx[0] * run.rootNx[1] * run.rootNx[2] // world if a.strong else nx ** 3
+        zones = nx * nx * nx3
+        nsub_tot = sum(drv.niter_trace)
+        nsub = nsub_tot / max(1, len(drv.niter_trace))
         value = zones * a.steps / elapsed
+        nvar = 5 + run.nscal
         out = {
             "metric": "cell-updates/sec (hydro+ion-rad step)", "value": value, "unit": "cell-updates/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * elapsed / a.steps,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+            "higher_is_better": True, "scaling": "strong" if a.strong else "weak", "vs_baseline": None, "dtype": "f64",
             "data": "synthetic (deck values on a uniform grid, generated in place"
                     + ("; neutral fraction reset to 1e-4 everywhere: fully ionized slab" if a.ionized_slab else "") + ")",
-            "config": {"workload": f"{a.problem} {nx}x{nx}x{nx * world} single level, "
+            "config": {"workload": f"{a.problem} {nx}x{nx}x{nx3} single level, "
                                    + ((f"CTU+{'PPM' if a.order == 3 else 'PLM'}+Roe+H-correction") if a.integrator == "ctu" else "VL+PLM+Roe")
                                    + (" + static gravity + plane-parallel ion radiation" if a.problem == "ioniz_sphere"
-                                      else (" + plane-parallel ion radiation" if a.problem == "ifront" else "")),
-                       "zones_per_gpu": nx ** 3, "partition": f"x3 slabs x{world}", "nvar": 5 + run.nscal,
+                                      else (" + plane-parallel ion radiation" if a.problem == "ifront" else ""))
+                                   + (f"; timed after {len(spin_log)} spin-up steps"
+                                      + (" (stationary regime: dt at the CFL limit, sub-cycle count constant)" if a.spinup == "auto" else "")
+                                      if run.ion else ""),
+                       "build": "libathena_amd_strict.so (-ffp-contract=off)" if a.strict else "libathena_amd.so",
+                       "zones_per_gpu": zones_gpu, "partition": f"x3 slabs x{world}" + (" of one box (strong scaling)" if a.strong else ""),
+                       "nvar": nvar, "spinup_steps": len(spin_log), "spinup_subcycle_trace": spin_log, "spinup_s": t_spin,
                        "radiation_subcycles_per_step": nsub, "subcycle_trace": drv.niter_trace,
-                       "final_dt": drv.dt, "hbm_resident_GB": eng.g.device_bytes() / 1e9, "setup_s": t_setup},
+                       "final_dt": drv.dt, "final_time": drv.time, "hbm_resident_GB": eng.g.device_bytes() / 1e9, "setup_s": t_setup},
         }
-        # roofline of the dominant kernel: compulsory bytes of one launch / its mean duration
-        # (hipEvent pairs recorded on the launch stream inside the timed region)
+        # the state that was timed: finite everywhere, mass and energy of the box before / after (outflow
+        # boundaries: not conserved to round-off), no sub-cycle loop at its iteration limit
+        fin = all(math.isfinite(float(x)) for x in hist1)
+        out["state_check"] = {"finite": fin, "mass_before": float(hist0[0]), "mass_after": float(hist1[0]),
+                              "mass_rel_change": float(hist1[0] / hist0[0] - 1.0) if hist0[0] else None,
+                              "energy_rel_change": float(hist1[1] / hist0[1] - 1.0) if hist0[1] else None,
+                              "max_subcycles": max(drv.niter_trace) if drv.niter_trace else 0, "maxiter": run.maxiter,
+                              "ok": bool(fin and (not run.ion or max(drv.niter_trace) < run.maxiter))}
+        if hasattr(drv, "host_syncs"):
+            out["host_syncs_per_step"] = drv.host_syncs / a.steps
         if prof:
-            dom = max(prof, key=lambda k: prof[k][0] if KERNEL_BYTES.get(k, 0) > 0 else -1.0)   # (boundary kernels have no per-zone figure)
-            ms, n = prof[dom]
-            ncell = nx ** 3
-            bpl = KERNEL_BYTES.get(dom, 0) * ncell * ((5 + run.nscal) / 6.0 if not dom.startswith("ion") and dom != "ray_sweep" else 1.0)
-            ach = bpl / (ms / n * 1e-3) / 1e9 if n else 0.0
-            # measured HBM bytes per launch of that kernel: from the committed rocprofv3 PMC passes of
-            # this same command (profiles/r01_traffic.json); only valid for the workload it was taken on
-            traffic = None
-            try:
-                tj = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
-                if tj.get("workload") == f"{a.problem} {nx}x{nx}x{nx}" and a.integrator == "ctu":
-                    traffic = tj["kernels"].get(dom)
-            except Exception:
-                pass
-            out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                               "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "bytes_per_launch": bpl,
-                               "avg_launch_ms": ms / n if n else None}
-            out["kernel_ms_per_step"] = {k: v[0] / a.steps for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])}
+            ms_step = {k: v[0] / a.steps for k, v in prof.items()}
+            cls = {"hydro": 0.0, "subcycle": 0.0, "ion_step": 0.0, "other": 0.0}
+            for k, v in ms_step.items():
+                cls[kernel_class(k)] += v
+            # 1. the dominant kernel: compulsory bytes of one launch / its mean duration (hipEvent pairs
+            #    recorded on the launch stream inside the timed region)
+            dom = dominant_kernel(prof)
+            if dom:
+                ms, n = prof[dom]
+                scale = (nvar / 6.0) if kernel_class(dom) == "hydro" else 1.0
+                bpl = KERNEL_BYTES[dom] * zones_gpu * scale
+                ach = bpl / (ms / n * 1e-3) / 1e9
+                # measured HBM bytes per launch of that kernel: from the committed rocprofv3 PMC passes of
+                # this same command (profiles/r02_traffic.json); only valid for the workload it was taken on
+                traffic = None
+                try:
+                    tj = json.load(open(os.path.join(ROOT, "profiles", "r02_traffic.json")))
+                    if tj.get("workload") == f"{a.problem} {nx}x{nx}x{nx3}" and a.integrator == "ctu" and world == 1:
+                        traffic = tj["kernels"].get(dom)
+                except Exception:
+                    pass
+                out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                   "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "bytes_per_launch": bpl,
+                                   "bytes_basis": f"{KERNEL_BYTES[dom] * scale:g} B/zone: the distinct doubles this kernel must read + write (DESIGN.md section 3)",
+                                   "avg_launch_ms": ms / n}
+            # 2. the phases of the step on SURVEY 8(d)'s algorithmic bytes: hydro chain 2*NVAR*8 B per
+            #    cell-update, radiation 64 B per cell and sub-cycle
+            ph = {}
+            b_h = 2 * 8 * nvar
+            if cls["hydro"] > 0:
+                a_h = b_h * zones_gpu / (cls["hydro"] * 1e-3) / 1e9
+                tf = HYDRO_FLOP_PER_CELL * zones_gpu / (cls["hydro"] * 1e-3) / 1e12
+                ph["hydro"] = {"ms_per_step": cls["hydro"], "bytes_per_cell": b_h, "achieved_GBs": a_h, "frac_hbm": a_h / HBM_PEAK_GBS,
+                               "ns_per_zone": 1e6 * cls["hydro"] / zones_gpu,
+                               "fp64_TFLOPs_est": tf, "frac_fp64_peak_est": tf / FP64_PEAK_TFLOPS}
+            if nsub_tot > 0 and cls["subcycle"] > 0:
+                ms_sub = cls["subcycle"] * a.steps / nsub_tot
+                a_s = 64 * zones_gpu / (ms_sub * 1e-3) / 1e9
+                ph["subcycle"] = {"ms_per_subcycle": ms_sub, "bytes_per_cell": 64, "achieved_GBs": a_s, "frac_hbm": a_s / HBM_PEAK_GBS,
+                                  "ns_per_zone": 1e6 * ms_sub / zones_gpu, "subcycles_timed": nsub_tot}
+            ph["ion_step_overhead_ms"] = cls["ion_step"]
+            ph["other_ms"] = cls["other"]
+            ph["unattributed_ms"] = 1e3 * elapsed / a.steps - sum(cls.values())
+            out["phases"] = ph
+            out["kernel_ms_per_step"] = dict(sorted(ms_step.items(), key=lambda kv: -kv[1]))
             out["kernel_launches_per_step"] = {k: v[1] / a.steps for k, v in prof.items()}
-        # the survey's whole-step definition: (96 + 64*<N_sub>) B per cell-update
-        bstep = (2 * 8 * (5 + run.nscal)) + (64 * nsub if run.ion else 0)
+        # 3. the whole step, the survey's definition: (2*NVAR*8 + 64*<N_sub>) B per cell-update
+        bstep = (2 * 8 * nvar) + (64 * nsub if run.ion else 0)
         out["step_roofline"] = {"bytes_per_cell_update": bstep, "achieved": value / world * bstep / 1e9,
                                 "peak": HBM_PEAK_GBS, "unit": "GB/s per GPU",
                                 "frac": value / world * bstep / 1e9 / HBM_PEAK_GBS}
         if not a.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline()
+            cb = cpu_baseline()
+            out["cpu_baseline"] = cb
+            if "phases" in out and "per_hydro_step_ns_per_zone" in cb:
+                ph = out["phases"]
+                out["gpu_vs_cpu"] = {"hydro_step": cb["per_hydro_step_ns_per_zone"] / ph["hydro"]["ns_per_zone"] if "hydro" in ph else None,
+                                     "subcycle": (cb["per_subcycle_ns_per_zone"] / ph["subcycle"]["ns_per_zone"]
+                                                  if "subcycle" in ph and cb["per_subcycle_ns_per_zone"] > 0 else None),
+                                     "note": f"one MI355X against {cb['cores']} host cores, per zone and per hydro step / sub-cycle"}
         print(json.dumps(out))
-    if world > 1 or force:
+    if multi:
         dist.barrier()
         dist.destroy_process_group()
 
