@@ -36,6 +36,30 @@ static void prof_drain(aa_grid *g)
   }
 }
 
+void aa_eval_grav_tables(const aa_params &p, const double dx[3], int N1, int N2, int N3, aa_gravpot_fn fn, std::vector<double> t[4])
+{
+  for (int w = 0; w < 4; w++) t[w].resize((size_t)N1*N2*N3);
+  // the callback is a pure function of position (as in the reference, which calls it ~52 times
+  // per cell per step): evaluate k-planes on all host cores
+  unsigned nth = std::thread::hardware_concurrency(); if (nth < 1) nth = 1; if (nth > 64) nth = 64;
+  if ((int)nth > N3) nth = N3;
+  std::vector<std::thread> pool;
+  for (unsigned w = 0; w < nth; w++) pool.emplace_back([&, w]() {
+    for (int k = (int)w; k < N3; k += (int)nth) for (int j = 0; j < N2; j++) for (int i = 0; i < N1; i++) {
+      // cc_pos.c:36-43
+      const double x1 = p.MinX[0] + ((double)(i - AA_NGHOST) + 0.5)*dx[0];
+      const double x2 = p.MinX[1] + ((double)(j - AA_NGHOST) + 0.5)*dx[1];
+      const double x3 = p.MinX[2] + ((double)(k - AA_NGHOST) + 0.5)*dx[2];
+      const size_t m = ((size_t)k*N2 + j)*N1 + i;
+      t[0][m] = fn(x1, x2, x3);
+      t[1][m] = fn(x1 - 0.5*dx[0], x2, x3);
+      t[2][m] = fn(x1, x2 - 0.5*dx[1], x3);
+      t[3][m] = fn(x1, x2, x3 - 0.5*dx[2]);
+    }
+  });
+  for (auto &th : pool) th.join();
+}
+
 extern "C" {
 
 const char *aa_last_error(void) { return g_err; }
@@ -49,6 +73,11 @@ int aa_create(const aa_params *p, aa_grid **out)
     return fail(-1, "<time>cour_no was set to %g: must be <= 0.5 with 3D integrator", p->cour_no);
   if (p->ion && p->nscal != 1) return fail(-1, "[aa_create]: ion radiation needs NSCALARS=1");
   if (p->nscal != 0 && p->nscal != 1) return fail(-1, "[aa_create]: NSCALARS must be 0 or 1");
+  { // one Grid of the caller on several GPUs: aa_params.nslab, or AA_NGPU in the environment (drop-in executables)
+    int ns = p->nslab;
+    if (ns == 0) { const char *e = getenv("AA_NGPU"); if (e) ns = atoi(e); }
+    if (ns > 1) return slabs_create(p, ns, out);
+  }
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
     return fail(-3, "[aa_create]: no HIP device visible -- this library has no CPU path");
@@ -88,7 +117,12 @@ int aa_create(const aa_params *p, aa_grid **out)
   const size_t nc = (size_t)d.nc;
   const size_t nef = (size_t)(d.Nx1 + 1)*(d.Nx2 + 1)*(d.Nx3 + 1);
   size_t n = nc*(6 + 36 + 18 + 3 + 1 + 4);
+  // the one-kernel sub-cycle wants whole wavefronts along the rays; AA_ION_FUSED forces either path
+  { const char *e = getenv("AA_ION_FUSED");
+    g->ion_fused = p->ion && (p->ion_path ? p->ion_path == 1 : (e ? atoi(e) != 0 : p->Nx[0] >= 64)); }
+  const size_t nrays = (size_t)d.Nx2*d.Nx3;
   if (p->ion) n += nc*6 + nef;
+  if (g->ion_fused) n += nc + 2*nrays;
   if (p->order != 0 && p->order != 2 && p->order != 3) { delete g; return fail(-1, "[aa_create]: order %d (2: PLM, 3: PPM)", p->order); }
   if (p->order == 3 && p->integrator == 1) { delete g; return fail(-1, "[aa_create]: order 3 is built for the CTU integrator only"); }
   if (p->order == 3) n += nc*18;
@@ -106,6 +140,9 @@ int aa_create(const aa_params *p, aa_grid **out)
     d.ph_rate = q; q += nc; d.kin = q; q += nc; d.vmax = q; q += nc;
     d.e_init = q; q += nc; d.x_init = q; q += nc;
     d.sign = (int2*)q; q += nc; d.edgeflux = q; q += nef;
+    d.sg16 = (unsigned short*)d.sign;                  // the fused path keeps its 2-byte sign words in the same storage
+    d.fin[0] = d.ph_rate; d.fin[1] = d.ph_rate;
+    if (g->ion_fused) { d.fin[1] = q; q += nc; d.raylast = q; q += 2*nrays; }
     IonPar &ip = g->ion;
     ip.sigma_ph = p->sigma_ph; ip.m_H = p->m_H; ip.mu = p->mu; ip.e_gamma = p->e_gamma; ip.alpha_C = p->alpha_C;
     ip.k_B = p->k_B; ip.time_unit = p->time_unit;
@@ -130,6 +167,12 @@ int aa_create(const aa_params *p, aa_grid **out)
   if (hipMalloc(&g->sc, sizeof(DevScalars)) != hipSuccess || hipHostMalloc(&g->sc_host, sizeof(DevScalars)) != hipSuccess) {
     hipFree(g->pool); delete g; return fail(-2, "[aa_create]: scalar buffers");
   }
+  if (g->ion_fused) {
+    if (hipMalloc(&g->ion_part, (size_t)ion_pass_blocks(d)*sizeof(IonPart)) != hipSuccess ||
+        hipMalloc(&g->ion_words, AA_ION_WORDS*sizeof(Real)) != hipSuccess) {
+      hipFree(g->pool); hipFree(g->sc); hipHostFree(g->sc_host); delete g; return fail(-2, "[aa_create]: ion reduction buffers");
+    }
+  }
   hipStreamCreate(&g->st); g->own_stream = true;
   *out = g;
   return 0;
@@ -138,9 +181,12 @@ int aa_create(const aa_params *p, aa_grid **out)
 void aa_destroy(aa_grid *g)
 {
   if (!g) return;
+  if (!g->slab.empty()) { slabs_destroy(g); return; }
   hipStreamSynchronize(g->st);
   prof_drain(g);
   hipFree(g->pool); hipFree(g->sc); hipHostFree(g->sc_host);
+  if (g->ion_part) hipFree(g->ion_part);
+  if (g->ion_words) hipFree(g->ion_words);
   if (g->pin_idx) hipFree(g->pin_idx);
   if (g->pin_val) hipFree(g->pin_val);
   if (g->own_stream) hipStreamDestroy(g->st);
@@ -149,17 +195,19 @@ void aa_destroy(aa_grid *g)
 
 int aa_set_stream(aa_grid *g, void *s)
 {
+  if (!g->slab.empty()) return fail(-1, "[aa_set_stream]: a Grid cut into slabs runs on its slabs' own streams");
   hipStreamSynchronize(g->st);
   if (g->own_stream) { hipStreamDestroy(g->st); g->own_stream = false; }
   g->st = (hipStream_t)s;
   return 0;
 }
-int aa_sync(aa_grid *g) { HIPCHK(hipStreamSynchronize(g->st)); return 0; }
-long long aa_device_bytes(const aa_grid *g) { return g->bytes; }
+int aa_sync(aa_grid *g) { if (!g->slab.empty()) return slabs_sync(g); HIPCHK(hipStreamSynchronize(g->st)); return 0; }
+long long aa_device_bytes(const aa_grid *g) { return g->slab.empty() ? g->bytes : slabs_device_bytes(g); }
 
 // ---- state transfer: staging through the (idle) face-state area ---------------------------
 int aa_upload_cons(aa_grid *g, const double *U)
 {
+  if (!g->slab.empty()) return slabs_upload_cons(g, U);
   const int nvar = 5 + g->p.nscal; const size_t n = (size_t)g->d.N1*g->d.N2*g->d.N3*nvar;
   HIPCHK(hipMemcpyAsync(g->d.LR, U, n*sizeof(Real), hipMemcpyHostToDevice, g->st));
   launch_aos_to_soa(g->d, nvar, g->d.LR, g->st);
@@ -168,14 +216,35 @@ int aa_upload_cons(aa_grid *g, const double *U)
 }
 int aa_download_cons(aa_grid *g, double *U)
 {
+  if (!g->slab.empty()) return slabs_download_cons(g, U);
   const int nvar = 5 + g->p.nscal; const size_t n = (size_t)g->d.N1*g->d.N2*g->d.N3*nvar;
   launch_soa_to_aos(g->d, nvar, g->d.LR, g->st);
   HIPCHK(hipMemcpyAsync(U, g->d.LR, n*sizeof(Real), hipMemcpyDeviceToHost, g->st));
   HIPCHK(hipStreamSynchronize(g->st));
   return 0;
 }
+// planes [k_first, k_first + nplanes) of the host block [N3][N2][N1][nvar]
+int aa_download_cons_planes(aa_grid *g, int k_first, int nplanes, double *dst)
+{
+  if (!g->slab.empty()) return fail(-1, "[aa_download_cons_planes]: one slab at a time");
+  if (k_first < 0 || nplanes < 0 || k_first + nplanes > g->d.N3) return fail(-1, "[aa_download_cons_planes]: planes %d..%d", k_first, k_first + nplanes);
+  const int nvar = 5 + g->p.nscal; const size_t pl = (size_t)g->d.N1*g->d.N2*nvar;
+  launch_soa_to_aos(g->d, nvar, g->d.LR, g->st);
+  HIPCHK(hipMemcpyAsync(dst, g->d.LR + (size_t)k_first*pl, (size_t)nplanes*pl*sizeof(Real), hipMemcpyDeviceToHost, g->st));
+  HIPCHK(hipStreamSynchronize(g->st));
+  return 0;
+}
+int aa_download_edgeflux_planes(aa_grid *g, int nplanes, double *dst)
+{
+  if (!g->p.ion) return fail(-1, "[aa_download_edgeflux]: ion radiation is off");
+  const size_t n = (size_t)(g->d.Nx1 + 1)*(g->d.Nx2 + 1)*(size_t)nplanes;
+  HIPCHK(hipMemcpyAsync(dst, g->d.edgeflux, n*sizeof(Real), hipMemcpyDeviceToHost, g->st));
+  HIPCHK(hipStreamSynchronize(g->st));
+  return 0;
+}
 int aa_upload_edgeflux(aa_grid *g, const double *ef)
 {
+  if (!g->slab.empty()) return slabs_upload_edgeflux(g, ef);
   if (!g->p.ion) return fail(-1, "[aa_upload_edgeflux]: ion radiation is off");
   const size_t n = (size_t)(g->d.Nx1 + 1)*(g->d.Nx2 + 1)*(g->d.Nx3 + 1);
   HIPCHK(hipMemcpyAsync(g->d.edgeflux, ef, n*sizeof(Real), hipMemcpyHostToDevice, g->st));
@@ -184,6 +253,7 @@ int aa_upload_edgeflux(aa_grid *g, const double *ef)
 }
 int aa_download_edgeflux(aa_grid *g, double *ef)
 {
+  if (!g->slab.empty()) return slabs_download_edgeflux(g, ef);
   if (!g->p.ion) return fail(-1, "[aa_download_edgeflux]: ion radiation is off");
   const size_t n = (size_t)(g->d.Nx1 + 1)*(g->d.Nx2 + 1)*(g->d.Nx3 + 1);
   HIPCHK(hipMemcpyAsync(ef, g->d.edgeflux, n*sizeof(Real), hipMemcpyDeviceToHost, g->st));
@@ -193,11 +263,12 @@ int aa_download_edgeflux(aa_grid *g, double *ef)
 int aa_get_mesh_state(const aa_grid *g, double *time, double *dt, int *nstep)
 { if (time) *time = g->time; if (dt) *dt = g->dt; if (nstep) *nstep = g->nstep; return 0; }
 int aa_set_mesh_state(aa_grid *g, double time, double dt, int nstep)
-{ g->time = time; g->dt = dt; g->nstep = nstep; return 0; }
+{ g->time = time; g->dt = dt; g->nstep = nstep; if (!g->slab.empty()) slabs_push_state(g); return 0; }
 
 // ---- hooks --------------------------------------------------------------------------------
 int aa_set_static_grav_tables(aa_grid *g, const double *pc, const double *p1, const double *p2, const double *p3)
 {
+  if (!g->slab.empty()) return slabs_set_grav_tables(g, pc, p1, p2, p3);
   if (!pc) { g->grav = false; return 0; }
   // host tables are dense [N3][N2][N1]; device rows are sJ apart
   const double *src[4] = {pc, p1, p2, p3};
@@ -211,34 +282,20 @@ int aa_set_static_grav_tables(aa_grid *g, const double *pc, const double *p1, co
 
 int aa_set_static_grav_pot(aa_grid *g, aa_gravpot_fn fn)
 {
-  if (!fn) { g->grav = false; return 0; }
-  const DevGrid &d = g->d;
+  if (!fn) return aa_set_static_grav_tables(g, nullptr, nullptr, nullptr, nullptr);
+  // (a Grid cut into slabs evaluates the callback at the positions of the caller's ONE Grid: the slabs then hold
+  //  the very numbers the undivided Grid would)
+  const int N1 = g->p.Nx[0] + 2*AA_NGHOST, N2 = g->p.Nx[1] + 2*AA_NGHOST, N3 = g->p.Nx[2] + 2*AA_NGHOST;
+  double dx[3];
+  for (int a = 0; a < 3; a++) dx[a] = ((g->p.xmax[a] - g->p.xmin[a])/(Real)(g->p.rootNx[a]))/(Real)(1 << g->p.level);
   std::vector<double> t[4];
-  for (int w = 0; w < 4; w++) t[w].resize((size_t)d.N1*d.N2*d.N3);
-  // the callback is a pure function of position (as in the reference, which calls it ~52 times
-  // per cell per step): evaluate k-planes on all host cores
-  unsigned nth = std::thread::hardware_concurrency(); if (nth < 1) nth = 1; if (nth > 64) nth = 64;
-  if ((int)nth > d.N3) nth = d.N3;
-  std::vector<std::thread> pool;
-  for (unsigned w = 0; w < nth; w++) pool.emplace_back([&, w]() {
-    for (int k = (int)w; k < d.N3; k += (int)nth) for (int j = 0; j < d.N2; j++) for (int i = 0; i < d.N1; i++) {
-      // cc_pos.c:36-43
-      const double x1 = g->p.MinX[0] + ((double)(i - d.is) + 0.5)*d.dx[0];
-      const double x2 = g->p.MinX[1] + ((double)(j - d.js) + 0.5)*d.dx[1];
-      const double x3 = g->p.MinX[2] + ((double)(k - d.ks) + 0.5)*d.dx[2];
-      const size_t m = ((size_t)k*d.N2 + j)*d.N1 + i;
-      t[0][m] = fn(x1, x2, x3);
-      t[1][m] = fn(x1 - 0.5*d.dx[0], x2, x3);
-      t[2][m] = fn(x1, x2 - 0.5*d.dx[1], x3);
-      t[3][m] = fn(x1, x2, x3 - 0.5*d.dx[2]);
-    }
-  });
-  for (auto &th : pool) th.join();
+  aa_eval_grav_tables(g->p, dx, N1, N2, N3, fn, t);
   return aa_set_static_grav_tables(g, t[0].data(), t[1].data(), t[2].data(), t[3].data());
 }
 
 int aa_set_pinned_cells(aa_grid *g, long long n, const long long *index, const double *values)
 {
+  if (!g->slab.empty()) return slabs_set_pinned_cells(g, n, index, values);
   if (g->pin_idx) { hipFree(g->pin_idx); g->pin_idx = nullptr; }
   if (g->pin_val) { hipFree(g->pin_val); g->pin_val = nullptr; }
   g->npin = 0;
@@ -253,6 +310,7 @@ int aa_set_pinned_cells(aa_grid *g, long long n, const long long *index, const d
 }
 int aa_apply_pinned_cells(aa_grid *g)
 {
+  if (!g->slab.empty()) return slabs_apply_pinned_cells(g);
   Scope s(g, "pinned_cells");
   launch_pinned(g->d, 5 + g->p.nscal, g->npin, g->pin_idx, g->pin_val, g->st);
   return 0;
@@ -261,7 +319,16 @@ int aa_apply_pinned_cells(aa_grid *g)
 int aa_add_radplane_3d(aa_grid *g, int dir, double flux)
 {
   if (!g->p.ion) return fail(-1, "[add_radplane_3d]: ion radiation is off");
-  if (dir != -1) return fail(-1, "[add_radplane_3d]: only dir=-1 (rays along +x1) is supported, got %d", dir);
+  // Rays along +x1 (dir = -1) and along +x2 (dir = -2).  The reference has no working behaviour for the others:
+  // right-to-left rays (dir > 0) never enter the loop `for (i=s; i<=e; i+=lr)` with s > e (ionradplane_3d.c:275, :335,
+  // :367), and dir = -3 divides by a cell_len that is only assigned in the right-to-left branch (:136-145).
+  if (dir != -1 && dir != -2)
+    return fail(-1, "[add_radplane_3d]: dir=%d: only -1 (rays along +x1) and -2 (along +x2) have defined behaviour in the reference", dir);
+  if (dir == -2) {
+    if (g->p.level > 0) return fail(-1, "[add_radplane_3d]: rays along +x2 on a refined level are not supported");
+    g->ion_fused = false;          // the two-kernel sub-cycle carries this sweep
+  }
+  if (!g->slab.empty()) { int rc = slabs_add_radplane(g, dir, flux); if (rc) return rc; }
   g->rad_dir = dir; g->flux_i = flux; g->nradplane = 1;
   return 0;
 }
@@ -269,6 +336,7 @@ int aa_add_radplane_3d(aa_grid *g, int dir, double flux)
 // ---- per-step call sites ------------------------------------------------------------------
 int aa_bvals_mhd(aa_grid *g)
 {
+  if (!g->slab.empty()) return slabs_bvals_mhd(g);
   Scope s(g, "bvals_mhd");
   for (int d = 0; d < 3; d++)            // x1, x2, x3 so the corners fill (bvals_mhd.c:170)
     launch_bc_dir(g->d, g->p.nscal, d, g->p.bc[2*d], g->p.bc[2*d + 1], g->st);
@@ -278,6 +346,7 @@ int aa_bvals_mhd(aa_grid *g)
 int aa_bvals_mhd_side(aa_grid *g, int dir, int side)
 {
   if (dir < 0 || dir > 2 || side < 0 || side > 1) return fail(-1, "[aa_bvals_mhd_side]: dir=%d side=%d", dir, side);
+  if (!g->slab.empty()) return slabs_bvals_mhd_side(g, dir, side);
   const int flag = g->p.bc[2*dir + side];
   if (flag) { Scope s(g, "bvals_mhd"); launch_bc(g->d, g->p.nscal, dir, side, flag, g->st); }
   return 0;
@@ -285,8 +354,10 @@ int aa_bvals_mhd_side(aa_grid *g, int dir, int side)
 
 int aa_bvals_ionrad(aa_grid *g)
 {
-  if (!g->p.ion || g->rad_dir != -1) return 0;
-  launch_edgeflux_bc(g->d, g->flux_i, g->st);
+  if (!g->slab.empty()) return slabs_bvals_ionrad(g);
+  if (!g->p.ion) return 0;
+  if (g->rad_dir == -1) launch_edgeflux_bc(g->d, g->flux_i, g->st);
+  else if (g->rad_dir == -2) launch_edgeflux_bc_x2(g->d, g->flux_i, g->st);
   return 0;
 }
 
@@ -294,12 +365,14 @@ int aa_fetch_scalars(aa_grid *g)
 {
   HIPCHK(hipMemcpyAsync(g->sc_host, g->sc, sizeof(DevScalars), hipMemcpyDeviceToHost, g->st));
   HIPCHK(hipStreamSynchronize(g->st));
+  g->host_syncs++;
   return 0;
 }
 #define fetch_scalars aa_fetch_scalars
 
 int aa_new_dt_local(aa_grid *g, double *dt_cfl)
 {
+  if (!g->slab.empty()) return slabs_new_dt_local(g, dt_cfl);
   { Scope s(g, "new_dt");
     HIPCHK(hipMemsetAsync(g->sc->max_v, 0, 3*sizeof(unsigned long long), g->st));
     launch_cfl(g->d, g->sc, g->st); }
@@ -312,6 +385,7 @@ int aa_new_dt_local(aa_grid *g, double *dt_cfl)
 
 int aa_cfl_max_v(aa_grid *g, double *v)      // new_dt.c:72-140 of this Grid: max(|v_d| + a) per direction
 {
+  if (!g->slab.empty()) return slabs_cfl_max_v(g, v);
   { Scope s(g, "new_dt");
     HIPCHK(hipMemsetAsync(g->sc->max_v, 0, 3*sizeof(unsigned long long), g->st));
     launch_cfl(g->d, g->sc, g->st); }
@@ -325,11 +399,13 @@ int aa_new_dt(aa_grid *g)
   double dtc; int rc = aa_new_dt_local(g, &dtc); if (rc) return rc;
   if (g->nstep == 0) g->dt = dtc; else g->dt = (2.0*g->dt < dtc) ? 2.0*g->dt : dtc;       // new_dt.c:169-173
   if ((g->time < g->p.tlim) && ((g->p.tlim - g->time) < g->dt)) g->dt = g->p.tlim - g->time;   // :183-185
+  if (!g->slab.empty()) slabs_push_state(g);
   return 0;
 }
 
 int aa_integrate_3d_ctu(aa_grid *g)
 {
+  if (!g->slab.empty()) return slabs_integrate(g, 0);
   const DevGrid &d = g->d; const int ns = g->p.nscal; const Real dt = g->dt;
   if (d.slope) { Scope s(g, "ppm_slopes"); for (int dir = 0; dir < 3; dir++) launch_slopes(d, ns, dir, g->st); }
   // x2 and x3 first, so that the x1 sweep can do its first pass and its correct pass in one go
@@ -357,6 +433,7 @@ int aa_integrate_3d_ctu(aa_grid *g)
 
 int aa_integrate_3d_vl(aa_grid *g)
 {
+  if (!g->slab.empty()) return slabs_integrate(g, 1);
   // integrate_3d_vl.c:96-: donor-cell fluxes -> U^{n+1/2} -> PLM (no tracing) + Roe -> update
   const DevGrid &d = g->d; const int ns = g->p.nscal; const Real dt = g->dt;
   // donor-cell fluxes + U^{n+1/2} in one marching kernel from 2^18 zones (512^3: 16.8 -> 9.7 ms; same at 80^3;
@@ -377,13 +454,17 @@ int aa_integrate_3d_vl(aa_grid *g)
 int aa_ion_begin(aa_grid *g)
 {
   if (!g->p.ion) return fail(-1, "[ion_radtransfer]: ion radiation is off");
+  if (!g->slab.empty()) return slabs_ion_begin(g);
   Scope s(g, "ion_begin");
-  launch_ion_begin(g->d, g->ion, g->st);
+  if (g->ion_fused) { launch_ion_begin16(g->d, g->ion, g->st); g->ion_cur = 0; g->ion_pending = false; }
+  else launch_ion_begin(g->d, g->ion, g->st);
   return 0;
 }
 
 int aa_ion_rates(aa_grid *g, double *dt_chem, double *dt_therm)
 {
+  if (!g->slab.empty()) return slabs_ion_rates(g, dt_chem, dt_therm);
+  if (g->ion_fused) return fail(-1, "[aa_ion_rates]: this Grid runs the one-kernel sub-cycle (aa_ion_pass / aa_ion_pick / aa_ion_fetch)");
   {
     DevScalars init; memset(&init, 0, sizeof init);
     init.dt_chem = double_to_bits(DBL_MAX); init.dt_therm = double_to_bits(DBL_MAX);
@@ -395,12 +476,13 @@ int aa_ion_rates(aa_grid *g, double *dt_chem, double *dt_therm)
     // host (it is the same for every ray of the root level)
     const Real flux0 = g->flux_i*(5.*(erf((g->time - 1.2e5)/8e4)+1)+0.1);
     // :264-271: a refined level starts every ray from the flux its parent left in EdgeFlux[..][..][0]
-    if (g->fused_rates) { Scope s(g, "ray_sweep_rates"); launch_ray_sweep_rates(g->d, g->ion, flux0, g->level > 0, g->sc, g->st); }
+    if (g->rad_dir == -2) { Scope s(g, "ray_sweep"); launch_ray_sweep_x2(g->d, g->ion, g->flux_i, g->st); }
+    else if (g->fused_rates) { Scope s(g, "ray_sweep_rates"); launch_ray_sweep_rates(g->d, g->ion, flux0, g->level > 0, g->sc, g->st); }
     else { Scope s(g, "ray_sweep"); launch_ray_sweep(g->d, g->ion, flux0, g->level > 0, g->st); }
   } else {
     HIPCHK(hipMemsetAsync(g->d.ph_rate, 0, (size_t)g->d.nc*sizeof(Real), g->st));
   }
-  if (!(g->fused_rates && g->nradplane > 0)) { Scope s(g, "ion_rates"); launch_ion_rates(g->d, g->ion, g->sc, g->st); }
+  if (!(g->fused_rates && g->nradplane > 0 && g->rad_dir == -1)) { Scope s(g, "ion_rates"); launch_ion_rates(g->d, g->ion, g->sc, g->st); }
   int rc = fetch_scalars(g); if (rc) return rc;
   if (g->sc_host->neg_dt_chem) return fail(-4, "[compute_chem_rates]: negative dt_chem");   // ionrad_3d.c:389-391
   *dt_chem = bits_to_double(g->sc_host->dt_chem);
@@ -410,6 +492,8 @@ int aa_ion_rates(aa_grid *g, double *dt_chem, double *dt_therm)
 
 int aa_ion_update(aa_grid *g, double dt, long long *cellcount, double *dt_hydro)
 {
+  if (!g->slab.empty()) return slabs_ion_update(g, dt, cellcount, dt_hydro);
+  if (g->ion_fused) return fail(-1, "[aa_ion_update]: this Grid runs the one-kernel sub-cycle (aa_ion_pass / aa_ion_pick / aa_ion_fetch)");
   HIPCHK(hipMemsetAsync(&g->sc->max_dti, 0, 2*sizeof(unsigned long long), g->st));
   { Scope s(g, "ion_update"); launch_ion_update(g->d, g->ion, dt, g->sc, g->st); }
   int rc = fetch_scalars(g); if (rc) return rc;
@@ -432,14 +516,16 @@ int aa_ion_arm(aa_grid *g)
 int aa_ion_subcycle(aa_grid *g, double dt_done, double limit, double *dt, int *limit_hit, double *dt_chem,
                     double *dt_therm, long long *cellcount, double *dt_hydro)
 {
+  if (g->ion_fused) return fail(-1, "[aa_ion_subcycle]: this Grid runs the one-kernel sub-cycle");
   if (g->nradplane > 0) {
     const Real flux0 = g->flux_i*(5.*(erf((g->time - 1.2e5)/8e4)+1)+0.1);     // ionradplane_3d.c:265
-    if (g->fused_rates) { Scope s(g, "ray_sweep_rates"); launch_ray_sweep_rates(g->d, g->ion, flux0, g->level > 0, g->sc, g->st); }
+    if (g->rad_dir == -2) { Scope s(g, "ray_sweep"); launch_ray_sweep_x2(g->d, g->ion, g->flux_i, g->st); }
+    else if (g->fused_rates) { Scope s(g, "ray_sweep_rates"); launch_ray_sweep_rates(g->d, g->ion, flux0, g->level > 0, g->sc, g->st); }
     else { Scope s(g, "ray_sweep"); launch_ray_sweep(g->d, g->ion, flux0, g->level > 0, g->st); }
   } else {
     HIPCHK(hipMemsetAsync(g->d.ph_rate, 0, (size_t)g->d.nc*sizeof(Real), g->st));
   }
-  if (!(g->fused_rates && g->nradplane > 0)) { Scope s(g, "ion_rates"); launch_ion_rates(g->d, g->ion, g->sc, g->st); }
+  if (!(g->fused_rates && g->nradplane > 0 && g->rad_dir == -1)) { Scope s(g, "ion_rates"); launch_ion_rates(g->d, g->ion, g->sc, g->st); }
   launch_ion_pick(g->sc, dt_done, limit, g->st);
   { Scope s(g, "ion_update"); launch_ion_update_sel(g->d, g->ion, g->sc, g->st); }
   int rc = fetch_scalars(g); if (rc) return rc;
@@ -451,27 +537,149 @@ int aa_ion_subcycle(aa_grid *g, double dt_done, double limit, double *dt, int *l
   return 0;
 }
 
+// ---- the one-kernel sub-cycle (ion_pass.hip), as phases: a driver that reduces over ranks puts ONE collective
+// (an all-gather of AA_ION_WORDS doubles per rank, on this Grid's stream) between aa_ion_pass and aa_ion_pick
+int aa_ion_is_fused(const aa_grid *g) { return g->ion_fused ? 1 : 0; }
+
+// pass n: update(n-1) with the dt aa_ion_pick chose (if `update`), then sweep(n) + rates(n) (if `sweep`); this
+// Grid's words of the reduction go to dev_words (DEVICE, AA_ION_WORDS doubles; NULL: kept in the Grid)
+int aa_ion_pass(aa_grid *g, int update, int sweep, double *dev_words)
+{
+  if (!g->ion_fused) return fail(-1, "[aa_ion_pass]: this Grid runs the two-kernel sub-cycle (aa_ion_rates / aa_ion_update)");
+  if (!g->slab.empty()) {
+    if (dev_words) return fail(-1, "[aa_ion_pass]: a Grid cut into slabs reduces over its slabs itself");
+    return slabs_ion_pass(g, update, sweep);
+  }
+  if (!update && !sweep) return fail(-1, "[aa_ion_pass]: nothing to do");
+  if (update) {
+    // relying on the rates of the previous sweep makes that sweep the one that counts
+    if (!g->ion_pending) return fail(-1, "[aa_ion_pass]: update without a preceding sweep");
+    g->ion_cur ^= 1; g->ion_pending = false;
+  }
+  // ionradplane_3d.c:265: the hard-coded time ramp of the incident flux (the same for every ray of the root
+  // level); :264-271: a refined level starts every ray from the flux its parent left in EdgeFlux[..][..][0];
+  // no radiation plane: flux 0 (every zone's ph_rate stays 0, as after ph_rate_init)
+  const Real flux0 = (g->nradplane > 0) ? g->flux_i*(5.*(erf((g->time - 1.2e5)/8e4)+1)+0.1) : 0.0;
+  { Scope s(g, update ? (sweep ? "ion_pass" : "ion_pass_last") : "ion_pass_first");
+    launch_ion_pass(g->d, g->ion, update != 0, sweep != 0, flux0, g->level > 0 && g->nradplane > 0, g->sc, g->ion_cur,
+                    g->ion_part, dev_words ? dev_words : g->ion_words, g->st); }
+  if (sweep) g->ion_pending = true;
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+// ionrad_3d.c:941-967 from the words of all ranks (DEVICE, nranks x AA_ION_WORDS doubles; NULL: this Grid's own): books
+// the update the pass just applied (its step, the time covered so far -- kept on the device) and picks the step of the
+// next one, cut back to `limit`; `first` = the pass was the first of the ion step (no update applied yet)
+int aa_ion_pick(aa_grid *g, const double *dev_words_all, int nranks, int first, double limit)
+{
+  if (!g->ion_fused) return fail(-1, "[aa_ion_pick]: this Grid runs the two-kernel sub-cycle");
+  if (!g->slab.empty()) return slabs_ion_pick(g, first, limit);
+  launch_ion_pick2(dev_words_all ? dev_words_all : g->ion_words, dev_words_all ? nranks : 1, g->sc, first, limit, g->st);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+// the ONE read-back of a sub-cycle, after pass + pick: of the update that pass applied its step `dt`, whether that step
+// was cut back to the limit, the stop criteria's operands (cells out of range, dt_hydro) and `neg` = compute_chem_rates'
+// negative-dt_chem flag of the rates the step came from; dt_chem / dt_therm are those of the NEXT step (diagnostics)
+int aa_ion_fetch(aa_grid *g, double *dt, int *limit_hit, double *dt_chem, double *dt_therm, long long *cellcount, double *dt_hydro, int *neg)
+{
+  // (a Grid cut into slabs: slabs_ion_pick has already brought the slabs' words to the host and left the result here)
+  if (g->slab.empty()) { int rc = fetch_scalars(g); if (rc) return rc; }
+  *dt = g->sc_host->dt_applied; *limit_hit = g->sc_host->hit_applied;
+  if (dt_chem) *dt_chem = g->sc_host->dt_chem_out;
+  if (dt_therm) *dt_therm = g->sc_host->dt_therm_out;
+  if (cellcount) *cellcount = (long long)g->sc_host->cellcount;
+  if (dt_hydro) *dt_hydro = g->p.cour_no/bits_to_double(g->sc_host->max_dti);
+  if (neg) *neg = g->sc_host->neg_applied;
+  return 0;
+}
+
+// GridS.EdgeFlux <- the last sweep that counted (outputs, restart dumps, ionrad_prolong_snd read it)
+int aa_ion_finish(aa_grid *g)
+{
+  if (!g->ion_fused) return 0;
+  if (!g->slab.empty()) return slabs_ion_finish(g);
+  Scope s(g, "ion_finish");
+  launch_ion_finish(g->d, g->ion_cur, g->st);
+  g->ion_pending = false;
+  return 0;
+}
+
+static int ion_run_fused(aa_grid *g, bool fine, double limit, int *niter_out, double *dt_done_out)
+{
+  double dt, dt_chem = 0, dt_therm = 0, dt_hydro = 0, dt_done = 0.0;
+  long long cellcount = 0;
+  int hit, neg, niter = 0, rc;
+  if ((rc = aa_ion_begin(g))) return rc;
+  if ((rc = aa_ion_pass(g, 0, 1, nullptr))) return rc;                       // sweep(0) + rates(0)
+  if ((rc = aa_ion_pick(g, nullptr, 1, 1, limit))) return rc;                // -> dt_0 (stays on the device)
+  for (;;) {
+    // update(n) with the step picked on the device, then -- unless that step was cut back to the limit -- sweep(n+1) and
+    // rates(n+1), speculatively: whether the loop goes on is only known from this pass's own reductions
+    if ((rc = aa_ion_pass(g, 1, 1, nullptr))) return rc;
+    if ((rc = aa_ion_pick(g, nullptr, 1, 0, limit))) return rc;
+    if ((rc = aa_ion_fetch(g, &dt, &hit, &dt_chem, &dt_therm, &cellcount, &dt_hydro, &neg))) return rc;   // the one read-back
+    if (neg) return fail(-4, "[compute_chem_rates]: negative dt_chem");      // ionrad_3d.c:389-391 (of the rates behind dt)
+    dt_done += dt;
+    niter++;
+    if (!fine) {
+      if (cellcount > MAXCELLCOUNT) { g->dt = dt_done; break; }
+      if (hit) break;
+      if (dt_hydro < dt_done) { g->dt = dt_done; break; }
+    } else if (hit) { g->dt = dt_done; break; }
+  }
+  if ((rc = aa_ion_finish(g))) return rc;
+  *niter_out = niter; *dt_done_out = dt_done;
+  return 0;
+}
+
+static int ion_run_phased(aa_grid *g, bool fine, double limit, int *niter_out, double *dt_done_out)
+{
+  double dt_chem, dt_therm, dt_hydro = 0, dt, dt_done = 0.0;
+  long long cellcount;
+  int niter = 0, rc;
+  if ((rc = aa_ion_begin(g))) return rc;
+  if ((rc = aa_ion_arm(g))) return rc;
+  for (;;) {
+    int hit = 0;
+    if ((rc = aa_ion_subcycle(g, dt_done, limit, &dt, &hit, &dt_chem, &dt_therm, &cellcount, &dt_hydro))) return rc;
+    dt_done += dt;
+    niter++;
+    if (!fine) {
+      if (cellcount > MAXCELLCOUNT) { g->dt = dt_done; break; }
+      if (hit) break;
+      if (dt_hydro < dt_done) { g->dt = dt_done; break; }
+    } else if (hit) { g->dt = dt_done; break; }
+  }
+  *niter_out = niter; *dt_done_out = dt_done;
+  return 0;
+}
+
+int aa_ion_run(aa_grid *g, int finegrid, double limit, int *niter_out, double *dt_done_out)
+{
+  if (!g->slab.empty() && !g->ion_fused) return slabs_ion_run_phased(g, limit, niter_out, dt_done_out);
+  return g->ion_fused ? ion_run_fused(g, finegrid != 0, limit, niter_out, dt_done_out)
+                      : ion_run_phased(g, finegrid != 0, limit, niter_out, dt_done_out);
+}
+
 int aa_ion_radtransfer_3d(aa_grid *g, int *niter_out)
 {
   // ionrad_3d.c:862-1047, root level
-  double dt_chem, dt_therm, dt_hydro = 0, dt, dt_done = 0.0;
-  long long cellcount;
-  int niter = 0, hydro_done = 0, rc;
-  if ((rc = aa_ion_begin(g))) return rc;
-  if ((rc = aa_ion_arm(g))) return rc;
-  while (!hydro_done) {
-    if ((rc = aa_ion_subcycle(g, dt_done, g->dt, &dt, &hydro_done, &dt_chem, &dt_therm, &cellcount, &dt_hydro))) return rc;
-    dt_done += dt;
-    niter++;
-    if (cellcount > MAXCELLCOUNT) { g->dt = dt_done; break; }
-    if (hydro_done) break;
-    if (dt_hydro < dt_done) { g->dt = dt_done; break; }
-  }
+  int niter = 0, rc; double dt_done = 0.0;
+  if ((rc = aa_ion_run(g, 0, g->dt, &niter, &dt_done))) return rc;
   if (niter == g->p.maxiter) g->dt = dt_done;
-  if (g->dt < 0) return fail(-4, "[ion_radtransfer_3d]: dt = %e, dt_chem = %e, dt_therm = %e, dt_hydro = %e, dt_done = %e",
-                             g->dt, dt_chem, dt_therm, dt_hydro, dt_done);
+  if (g->dt < 0) return fail(-4, "[ion_radtransfer_3d]: dt = %e, dt_done = %e", g->dt, dt_done);
   if (niter_out) *niter_out = niter;
   return 0;
+}
+
+int aa_host_syncs(aa_grid *g, int reset)
+{
+  int n = g->host_syncs; if (reset) g->host_syncs = 0;
+  for (aa_grid *c : g->slab) { n += c->host_syncs; if (reset) c->host_syncs = 0; }
+  return n;
 }
 
 int aa_start(aa_grid *g)
@@ -499,9 +707,11 @@ int aa_step(aa_grid *g, int *niter_out)
 }
 
 // ---- x3 halo ------------------------------------------------------------------------------
+#define NO_SLABS(name) if (!g->slab.empty()) return fail(-1, "[" name "]: not available on a Grid cut into slabs")
 long long aa_halo_doubles(const aa_grid *g) { return (long long)g->d.N1*g->d.N2*AA_NGHOST*(5 + g->p.nscal); }
 int aa_pack_x3(aa_grid *g, int side, double *buf)
 {
+  NO_SLABS("aa_pack_x3");
   Scope s(g, "halo_pack");
   const int k0 = side == 0 ? g->d.ks : g->d.ke - AA_NGHOST + 1;    // pack_ix3 / pack_ox3
   launch_pack_x3(g->d, 5 + g->p.nscal, k0, buf, g->st);
@@ -509,6 +719,7 @@ int aa_pack_x3(aa_grid *g, int side, double *buf)
 }
 int aa_unpack_x3(aa_grid *g, int side, const double *buf)
 {
+  NO_SLABS("aa_unpack_x3");
   Scope s(g, "halo_unpack");
   const int k0 = side == 0 ? g->d.ks - AA_NGHOST : g->d.ke + 1;    // unpack_ix3 / unpack_ox3
   launch_unpack_x3(g->d, 5 + g->p.nscal, k0, buf, g->st);
@@ -552,9 +763,25 @@ int aa_test_lr_states(int nscal, double gamma, int n, const double *W, double dt
 int aa_test_lr_states_ppm(int nscal, double gamma, int n, const double *W, double dt, double dx, int il, int iu, double *Wl, double *Wr)
 { return test_lr_any(3, nscal, gamma, n, W, dt, dx, il, iu, Wl, Wr); }
 
+// exp / log of the one-kernel sub-cycle (ion_pass.hip) on n values (n a multiple of 4): ye = exp(x), yl = ln|x|
+int aa_test_explog(int n, const double *x, double *ye, double *yl)
+{
+  if (n <= 0 || n % 4) return fail(-1, "[aa_test_explog]: n must be a positive multiple of 4");
+  Real *d = nullptr;
+  HIPCHK(hipMalloc(&d, 3*(size_t)n*sizeof(Real)));
+  HIPCHK(hipMemcpy(d, x, (size_t)n*sizeof(Real), hipMemcpyHostToDevice));
+  launch_test_explog(n, d, d + n, d + 2*(size_t)n, 0);
+  HIPCHK(hipDeviceSynchronize());
+  HIPCHK(hipMemcpy(ye, d + n, (size_t)n*sizeof(Real), hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(yl, d + 2*(size_t)n, (size_t)n*sizeof(Real), hipMemcpyDeviceToHost));
+  hipFree(d);
+  return 0;
+}
+
 // ---- history sums (dump_history.c:157-200) ---------------------------------------------------
 int aa_history(aa_grid *g, double *sums)
 {
+  if (!g->slab.empty()) return slabs_history(g, sums);
   // partial rows go through the face-state area, idle outside the integrator
   const int nb = launch_history(g->d, g->p.nscal, g->d.LR, g->st);
   std::vector<double> part((size_t)nb*9);
@@ -570,12 +797,16 @@ int aa_history(aa_grid *g, double *sums)
 }
 
 // ---- measurement -----------------------------------------------------------------------------
-int aa_profile_enable(aa_grid *g, int on) { prof_drain(g); g->prof = on != 0; return 0; }
-int aa_profile_reset(aa_grid *g) { prof_drain(g); for (auto &e : g->pe) { e.total_ms = 0; e.launches = 0; } return 0; }
-int aa_profile_count(const aa_grid *g) { return (int)g->pe.size(); }
-const char *aa_profile_name(const aa_grid *g, int i) { return (i >= 0 && i < (int)g->pe.size()) ? g->pe[i].name.c_str() : ""; }
+// (a Grid cut into slabs reports its first slab's kernels)
+int aa_profile_enable(aa_grid *g, int on) { if (!g->slab.empty()) return aa_profile_enable(g->slab[0], on); prof_drain(g); g->prof = on != 0; return 0; }
+int aa_profile_reset(aa_grid *g)
+{ if (!g->slab.empty()) return aa_profile_reset(g->slab[0]); prof_drain(g); for (auto &e : g->pe) { e.total_ms = 0; e.launches = 0; } return 0; }
+int aa_profile_count(const aa_grid *g) { if (!g->slab.empty()) return aa_profile_count(g->slab[0]); return (int)g->pe.size(); }
+const char *aa_profile_name(const aa_grid *g, int i)
+{ if (!g->slab.empty()) return aa_profile_name(g->slab[0], i); return (i >= 0 && i < (int)g->pe.size()) ? g->pe[i].name.c_str() : ""; }
 int aa_profile_get(aa_grid *g, int i, double *total_ms, long long *launches)
 {
+  if (!g->slab.empty()) return aa_profile_get(g->slab[0], i, total_ms, launches);
   if (i < 0 || i >= (int)g->pe.size()) return fail(-1, "[aa_profile_get]: bad index");
   prof_drain(g);
   if (total_ms) *total_ms = g->pe[i].total_ms;

@@ -30,11 +30,19 @@ struct aa_grid {
   bool fused_update = false;           // second-pass fluxes + update in one kernel (AA_FUSED_UPDATE=0 at aa_create: the unfused chain)
   bool correct_all = false;            // the three correct passes in one kernel (k_correct_all): Grids of 2^21 zones or more, or AA_CORRECT_ALL
   bool fused_rates = false;            // rates evaluated inside the ray sweep (k_ray_sweep<true>): 2^17 rays or more, or AA_FUSED_RATES
+  bool ion_fused = false;              // one-kernel radiation sub-cycle with the scan sweep (ion_pass.hip): rays of 64 zones or more, or AA_ION_FUSED
+  int ion_cur = 0; bool ion_pending = false;   // buffer of the last sweep that counts; a sweep launched but not yet relied upon
+  aa::IonPart *ion_part = nullptr; aa::Real *ion_words = nullptr;   // per-block records of a pass; this Grid's folded words
+  int host_syncs = 0;                  // stream synchronisations that return scalars to the host (bench: per step)
   bool vl_predict = false;             // van Leer predictor as one kernel (k_vl_predict): 2^18 zones or more, or AA_VL_PREDICT
   bool keep_flux = false;              // a level of an aa_mesh: RestrictCorrect reads the second-pass fluxes ...
   aa::KeepPlanes keep = {0, {{0}}};        // ... on these face planes (own boundaries + the child's outline)
   double time = 0, dt = 0; int nstep = 0;
   long long bytes = 0;
+  // composite (slabs.hip): this handle stands for ONE Grid of the caller cut into x3 slabs, one aa_grid per
+  // device; every entry point of the C-ABI forwards to the slabs and does the neighbour exchange / reductions
+  std::vector<aa_grid*> slab;
+  struct SlabLink *link = nullptr;
   bool prof = false;
   std::vector<ProfEntry> pe;
 };
@@ -55,11 +63,47 @@ struct Scope {
   }
 };
 
+// ---- composite Grids (slabs.hip) -------------------------------------------------------------
+int slabs_create(const aa_params *p, int nslab, aa_grid **out);
+void slabs_destroy(aa_grid *g);
+int slabs_sync(aa_grid *g);
+long long slabs_device_bytes(const aa_grid *g);
+int slabs_upload_cons(aa_grid *g, const double *U);
+int slabs_download_cons(aa_grid *g, double *U);
+int slabs_upload_edgeflux(aa_grid *g, const double *ef);
+int slabs_download_edgeflux(aa_grid *g, double *ef);
+int slabs_set_grav_tables(aa_grid *g, const double *pc, const double *p1, const double *p2, const double *p3);
+int slabs_set_pinned_cells(aa_grid *g, long long n, const long long *index, const double *values);
+int slabs_apply_pinned_cells(aa_grid *g);
+int slabs_add_radplane(aa_grid *g, int dir, double flux);
+int slabs_bvals_mhd(aa_grid *g);
+int slabs_bvals_mhd_side(aa_grid *g, int dir, int side);
+int slabs_bvals_ionrad(aa_grid *g);
+int slabs_new_dt_local(aa_grid *g, double *dt_cfl);
+int slabs_cfl_max_v(aa_grid *g, double *v);
+int slabs_integrate(aa_grid *g, int vl);
+int slabs_ion_begin(aa_grid *g);
+int slabs_ion_rates(aa_grid *g, double *dt_chem, double *dt_therm);
+int slabs_ion_update(aa_grid *g, double dt, long long *cellcount, double *dt_hydro);
+int slabs_ion_pass(aa_grid *g, int update, int sweep);
+int slabs_ion_pick(aa_grid *g, int first, double limit);
+int slabs_ion_finish(aa_grid *g);
+int slabs_ion_run_phased(aa_grid *g, double limit, int *niter_out, double *dt_done_out);
+int slabs_history(aa_grid *g, double *sums);
+void slabs_push_state(aa_grid *g);
+// evaluation of a StaticGravPot callback at zone centres and lower faces of a Grid (api.hip)
+void aa_eval_grav_tables(const aa_params &p, const double dx[3], int N1, int N2, int N3, aa_gravpot_fn fn, std::vector<double> t[4]);
+extern "C" int aa_download_cons_planes(aa_grid *g, int k_first, int nplanes, double *dst);
+extern "C" int aa_download_edgeflux_planes(aa_grid *g, int nplanes, double *dst);
+
 static inline double bits_to_double(unsigned long long b) { double x; memcpy(&x, &b, 8); return x; }
 static inline unsigned long long double_to_bits(double x) { unsigned long long b; memcpy(&b, &x, 8); return b; }
 extern "C" int aa_fetch_scalars(aa_grid *g);     // DevScalars device -> pinned host, synchronous
 // one radiation sub-cycle with the step chosen on the device (api.hip); used by the single-Grid and the
 // Mesh drivers (the multi-rank drivers need the reductions on the host and use aa_ion_rates/_update)
+// ionrad_3d.c:862-1047 for the Grid of one level (api.hip): root (finegrid 0, limit = its dt) or refined level
+// (limit = the time the root covered); *dt_done_out = the time the sub-cycles covered
+extern "C" int aa_ion_run(aa_grid *g, int finegrid, double limit, int *niter_out, double *dt_done_out);
 extern "C" int aa_ion_arm(aa_grid *g);
 extern "C" int aa_ion_subcycle(aa_grid *g, double dt_done, double limit, double *dt, int *limit_hit, double *dt_chem,
                                double *dt_therm, long long *cellcount, double *dt_hydro);

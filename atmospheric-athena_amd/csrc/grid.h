@@ -37,6 +37,11 @@ struct DevGrid {
   Real *ph_rate, *kin, *vmax, *e_init, *x_init;   // kin (kinetic energy), vmax: frozen during the ion step
   int2 *sign;                     // .x = last_sign, .y = sign_count
   Real *edgeflux;
+  // one-kernel sub-cycle (ion_pass.hip): flux entering every zone, double-buffered (the sweep after a
+  // data-dependent stop is speculative); flux leaving every ray [2][Nx3*Nx2]; last_sign/sign_count in 2 bytes
+  Real *fin[2];
+  Real *raylast;
+  unsigned short *sg16;
   int Nx1, Nx2, Nx3;
 };
 
@@ -65,7 +70,19 @@ struct DevScalars {
   // scalars once per sub-cycle): the dt handed to k_ion_update, the values it was derived from
   Real dt_sel, dt_chem_out, dt_therm_out;
   int limit_hit, neg_out;
+  // one-kernel sub-cycle (ion_pass.hip): k_ion_pick2 also keeps the time the applied updates have covered and hands
+  // the host what belongs to the update the last pass applied, so that the host reads back ONCE per sub-cycle
+  Real dt_done;                      // sum of the steps applied so far in this ion step
+  Real dt_applied;                   // the step of the update the last pass applied
+  int hit_applied, neg_applied;      // ... whether it was cut back to the limit; negative-dt_chem flag of the rates behind it
 };
+
+// what one block of k_ion_pass contributes to the reductions of a sub-cycle (all doubles: the record is
+// also what ranks exchange)
+struct IonPart { Real dt_chem, dt_therm, max_dti, cellcount, neg; };
+#ifndef AA_ION_WORDS
+#define AA_ION_WORDS 8               /* doubles per rank in the sub-cycle's reduction (5 used) */
+#endif
 
 // ---- launch wrappers (hydro_kernels.hip) ------------------------------------------
 void launch_slopes(const DevGrid &g, int nscal, int dir, hipStream_t st);          // order 3: before the sweeps of a step
@@ -110,5 +127,17 @@ void launch_ion_update(const DevGrid &g, const IonPar &p, Real dt, DevScalars *s
 void launch_ion_pick(DevScalars *sc, Real dt_done, Real dt_limit, hipStream_t st);      // ionrad_3d.c:941-963 on the device
 void launch_ion_update_sel(const DevGrid &g, const IonPar &p, DevScalars *sc, hipStream_t st);   // dt = sc->dt_sel
 void launch_edgeflux_bc(const DevGrid &g, Real flux_i, hipStream_t st);
+void launch_ray_sweep_x2(const DevGrid &g, const IonPar &p, Real flux_i, hipStream_t st);    // rays along +x2 (dir = -2)
+void launch_edgeflux_bc_x2(const DevGrid &g, Real flux_i, hipStream_t st);
+
+// ---- launch wrappers (ion_pass.hip): the one-kernel radiation sub-cycle ------------------
+int  ion_pass_blocks(const DevGrid &g);                       // launch size = number of IonPart records
+void launch_ion_begin16(const DevGrid &g, const IonPar &p, hipStream_t st);
+// update(n-1) with sc->dt_sel, then sweep(n) + rates(n) into buffer cur^1; folds the records into `words`
+void launch_ion_pass(const DevGrid &g, const IonPar &p, bool update, bool sweep, Real flux0, bool from_edgeflux,
+                     const DevScalars *sc, int cur, IonPart *part, Real *words, hipStream_t st);
+void launch_ion_pick2(const Real *words, int nranks, DevScalars *sc, int first, Real dt_limit, hipStream_t st);
+void launch_ion_finish(const DevGrid &g, int cur, hipStream_t st);
+void launch_test_explog(int n, const Real *x, Real *ye, Real *yl, hipStream_t st);   // n a multiple of 4
 
 }  // namespace aa

@@ -23,102 +23,9 @@
 //               HBM round trip -- applies them with the globally reduced dt, and reduces the
 //               out-of-range count and the hydro CFL limit.
 // HBM-bound FP64 streaming; no MFMA.
-#include <float.h>
-#include "grid.h"
-#include "hydro_dev.h"
+#include "ion_dev.h"
 
 namespace aa {
-
-#define MINFLUXFRAC 1.0e-3    /* ionrad.h:26 */
-#define IONFRACFLOOR 1.0e-4   /* :31 */
-#define CION 8.0e5            /* :36 */
-#define MAXSIGNCOUNT 4        /* ionrad_3d.c:286 */
-#define DAMPFACTOR 0.5        /* :287 */
-#define KB_CHEM 1.38e-16      /* ionrad_chemistry.c:43 */
-
-AA_DEV Real *Uq(const DevGrid &g, int v) { return g.U + (long)v*g.nc; }
-
-struct Cell { Real d, ke, E, s; };                       // what the ion step needs of a zone
-struct IonQ { Real n_H, n_Hplus, n_e, x, e_th, T, di, muq; };
-
-// ionrad_3d.c:82-101 (same expressions are repeated at :313-331 and :438-456).  The ion step is
-// not bit-reproducible against the CPU anyway (device exp/log vs glibc), so the seven divisions
-// of the reference are folded into two plus multiplications by host-computed reciprocals:
-// FP64 division is ~10x the cost of a multiply on CDNA4.
-AA_DEV IonQ ion_q(const Cell &c, const IonPar &p, Real Gamma_1)
-{
-  IonQ q;
-  q.n_H = c.s * p.inv_mH;
-  q.n_Hplus = (c.d - c.s) * p.inv_mH;
-  q.n_e = q.n_Hplus + c.d * p.aC14;
-  q.x = q.n_e / (q.n_H + q.n_Hplus);
-  q.di = 1.0 / c.d;
-  q.e_th = c.E - c.ke;
-  q.muq = q.x*0.5*p.m_H+(1.0-q.x)*p.mu;
-  q.T = Gamma_1 * (q.e_th * q.di) * q.muq * p.inv_kB;
-  return q;
-}
-
-AA_DEV Real neutral_lim(Real d, const IonPar &p)   // ionrad_3d.c:147-148
-{ Real d_nlim = d*IONFRACFLOOR; return d_nlim < p.d_nlo ? d_nlim : p.d_nlo; }
-
-// apply_temp_floor (:70-131) then apply_neutral_floor (:140-156) on one cell; `q` returns the derived
-// quantities of the cell as it entered, `changed` whether E or s was touched (then q is stale)
-AA_DEV void floors(Cell &c, const IonPar &p, Real Gamma_1, IonQ &q, bool &changed)
-{
-  const Real E0 = c.E, s0 = c.s;
-  q = ion_q(c, p, Gamma_1);
-  if (q.T < p.tfloor) {
-    Real e_sp = p.tfloor * p.k_B / (q.muq * Gamma_1);
-    c.E = c.ke + e_sp * c.d;
-  }
-  if ((q.T > p.tceil) && (p.tceil > 0)) {
-    Real e_sp = p.tceil * p.k_B / (q.muq * Gamma_1);
-    c.E = c.ke + e_sp * c.d;
-  }
-  Real d_nlim = neutral_lim(c.d, p);
-  if (c.s < d_nlim) c.s = d_nlim; else if (c.s > c.d) c.s = c.d;
-  changed = (c.E != E0) || (c.s != s0);
-}
-AA_DEV void floors(Cell &c, const IonPar &p, Real Gamma_1) { IonQ q; bool ch; floors(c, p, Gamma_1, q, ch); }
-
-// Undamped rate of change of the neutral density (compute_chem_rates, ionrad_3d.c:334-341).
-// recomb_rate_coef = 2.59e-13 (T/1e4)^-0.7 and recomb_cool_rate_coef = 6.11e-10 T^-0.89 k_B T
-// (ionrad_chemistry.c:111,:137) share ONE log: T^y = exp(y ln T) (rel. error ~|y ln T| eps ~1e-15);
-// the floored temperature uses the host-computed coefficient.
-AA_DEV Real chem_rate(const IonQ &q, Real ph, const IonPar &p, Real &lnT, bool &cold)
-{
-  cold = (q.T < p.tfloor);
-  Real rec;
-  if (cold) { lnT = 0.0; rec = p.rec_floor; }
-  else { lnT = log(q.T); rec = 2.59e-13*exp(-0.7*(lnT - 9.210340371976184)); }   // ln(1e4)
-  return rec * p.time_unit * q.n_e * q.n_Hplus - ph * q.n_H;
-}
-
-// edot of compute_therm_rates (ionrad_3d.c:460-490); `skip` cells get 0
-AA_DEV Real therm_rate(const IonQ &q, Real ph, Real lnT, const IonPar &p)
-{
-  const Real Tt = q.T;
-  const Real rcool = (Tt < 100.0) ? 0.0 : 6.11e-10*exp(-0.89*lnT)*KB_CHEM*Tt;          // chemistry :137
-  const Real arg = 118348/Tt;
-  const Real lya = (arg > 745.2) ? 0.0 : -7.5e-19*q.n_e*q.n_H*exp(-arg);              // :350, call at ionrad_3d.c:484
-  return ph * p.e_gamma * q.n_H - rcool * p.time_unit * q.n_Hplus * q.n_e + lya * p.time_unit;
-}
-
-AA_DEV Real damp(Real nHdot, int sign_count)          // ionrad_3d.c:360-363
-{ for (int n = MAXSIGNCOUNT; n < sign_count; n++) nHdot *= DAMPFACTOR; return nHdot; }
-
-AA_DEV bool ratio_ge(Real a, Real b, Real L)
-{ return (a > 0.0 && b > 0.0) ? (a >= L*b) : (a / b >= L); }
-
-AA_DEV bool active_cell(const DevGrid &g, long lin, long &m)
-{
-  const int ni = g.Nx1, nj = g.Nx2;
-  if (lin >= (long)ni*nj*g.Nx3) return false;
-  const int i = g.is + (int)(lin % ni), j = g.js + (int)((lin / ni) % nj), k = g.ks + (int)(lin / ((long)ni*nj));
-  m = (long)k*g.sK + (long)j*g.sJ + i;
-  return true;
-}
 
 // ---- entry of ion_radtransfer_3d: floors + save_energy_and_x (:896-905, :162-196) -------------
 // also freezes ke and max_d |v_d|
@@ -143,71 +50,6 @@ k_ion_begin(DevGrid g, IonPar p)
   // compute_dt_hydro takes max_d (|v_d| + a)/dx_d with one sound speed a: for dx1=dx2=dx3 that is
   // (max_d|v_d| + a)/dx exactly, so one frozen number per zone replaces the three momenta
   g.vmax[m] = rmax(rmax(fabs(M1*di), fabs(M2*di)), fabs(M3*di));
-}
-
-// ---- block reductions --------------------------------------------------------------------------
-AA_DEV void block_min_to(unsigned long long *addr, Real v, Real *red)
-{
-  red[threadIdx.x] = v;
-  __syncthreads();
-  for (int s = blockDim.x/2; s > 0; s >>= 1) {
-    if ((int)threadIdx.x < s) red[threadIdx.x] = rmin(red[threadIdx.x], red[threadIdx.x + s]);
-    __syncthreads();
-  }
-  if (threadIdx.x == 0) atomicMin(addr, (unsigned long long)__double_as_longlong(red[0]));
-  __syncthreads();
-}
-
-// compute_chem_rates :334-394 + compute_therm_rates :460-557 of one zone: the sign bookkeeping `sg`
-// (last_sign, sign_count) is updated in place, the two time-step limits of the zone are returned.  The
-// rates themselves are not stored (k_ion_update re-evaluates them).
-AA_DEV void rates_cell(const Cell &c, Real ph, int2 &sg, const IonPar &p, Real Gamma_1, DevScalars *sc, Real &dt_chem, Real &dt_therm)
-{
-  const IonQ iq = ion_q(c, p, Gamma_1);
-  Real lnT; bool cold;
-  Real nHdot = chem_rate(iq, ph, p, lnT, cold);
-  if (nHdot < 0.0) {
-    if (sg.x == 1) sg.y++; else if (sg.y > 0) sg.y--;
-    sg.x = -1;
-  } else if (nHdot > 0.0) {
-    if (sg.x == -1) sg.y++; else if (sg.y > 0) sg.y--;
-    sg.x = 1;
-  } else { sg.x = 0; sg.y = 0; }
-  nHdot = damp(nHdot, sg.y);
-  const Real d_nlim = neutral_lim(c.d, p);
-  const Real inv_n = 1.0/nHdot;
-  Real dt1, dt2;
-  if (nHdot == 0.0) { dt1 = dt2 = DBL_MAX; }
-  else if (nHdot > 0.0) {
-    dt1 = p.cx1 * iq.n_e * inv_n;               // max_dx_iter/(1+max_dx_iter) * n_e / nHdot
-    dt2 = p.max_dx_iter * iq.n_H * inv_n;
-  } else if (c.s > 1.0001*d_nlim) {
-    dt1 = -p.max_dx_iter * iq.n_e * inv_n;
-    dt2 = -p.cx1 * iq.n_H * inv_n;
-  } else { dt1 = dt2 = DBL_MAX; }
-  dt_chem = (dt1 < dt2) ? dt1 : dt2;
-  if (dt_chem < 0) { atomicExch(&sc->neg_dt_chem, 1); dt_chem = DBL_MAX; }
-  dt_therm = DBL_MAX;
-  const bool skip = cold || ((nHdot < 0) && (c.s < 1.0001*d_nlim));
-  if (!skip) {
-    const Real edot = therm_rate(iq, ph, lnT, p);
-    Real t1, t2; bool have = true;
-    const Real inv_e = 1.0/edot;
-    if (edot == 0.0) { t1 = t2 = DBL_MAX; }
-    else if (edot > 0.0) {
-      t1 = p.max_de_iter * c.E * inv_e;
-      t2 = p.max_de_therm_iter * iq.e_th * inv_e;
-    } else {
-      const Real e_sp_min = p.tfloor * p.k_B / (iq.muq * Gamma_1);
-      const Real e_th_min = e_sp_min * c.d;
-      const Real e_min = c.ke + e_th_min;
-      if ((iq.e_th*p.ie1 < e_th_min) && (c.E*p.ie2 < e_min)) have = false;   // e/(1+max_de*_iter)
-      t1 = -p.ce2 * c.E * inv_e;
-      t2 = -p.ce1 * iq.e_th * inv_e;
-    }
-    if (have) dt_therm = (t1 < t2) ? t1 : t2;
-    if (!(dt_therm == dt_therm) || dt_therm < 0) dt_therm = DBL_MAX;
-  }
 }
 
 // ---- ray sweep --------------------------------------------------------------------------------
@@ -368,6 +210,45 @@ k_ion_rates(DevGrid g, IonPar p, DevScalars *sc)
   block_min_to(&sc->dt_therm, dt_therm_min, red);
 }
 
+// ---- rays along +x2 (dir = -2): get_ph_rate_plane case -2, ionradplane_3d.c:323-354.  Thread = one ray (i,k), lanes
+// along i (every load and store of a wavefront is one contiguous row segment), marching along j with the flux in a
+// register: the reference's multiplication order, no staging.  As in the reference: the incident flux is flux_i
+// without the time ramp, tau uses dx1 (:337) while the rate divides by dx2 (cell_len :134, :339), the cut-off tests
+// flux/flux_i (:342), and EdgeFlux behind the cut keeps what earlier sweeps left there (ph_rate is 0 there: ph_rate_init).
+__global__ void __launch_bounds__(256)
+k_ray_sweep_x2(DevGrid g, IonPar p, Real flux_i)
+{
+  const long lin = (long)blockIdx.x*blockDim.x + threadIdx.x;
+  if (lin >= (long)g.Nx1*g.Nx3) return;
+  const int i = (int)(lin % g.Nx1), k = (int)(lin / g.Nx1);
+  const long efp = (long)(g.Nx1 + 1), efrow = (long)(g.Nx2 + 1)*efp;
+  Real flux = flux_i;
+  bool dead = false;
+  for (int j = 0; j < g.Nx2; j++) {
+    const long m = (long)(k + g.ks)*g.sK + (long)(j + g.js)*g.sJ + (i + g.is);
+    Real kph = 0.0;
+    if (!dead) {
+      g.edgeflux[(long)k*efrow + (long)j*efp + i] = flux;
+      const Real n_H = Uq(g,5)[m] / p.m_H;
+      const Real tau = p.sigma_ph * n_H * g.dx[0];
+      const Real etau = exp(-tau);
+      kph = flux * (1.0 - etau) / (n_H*g.dx[1]);
+      flux *= etau;
+      if (flux / flux_i < MINFLUXFRAC) dead = true;
+    }
+    g.ph_rate[m] = kph;
+  }
+}
+// bvals_ionrad.c:357 outflow_flux_ix2: EdgeFlux[k][0][i] = flux_i for k<=Nx3, i<=Nx1
+__global__ void k_edgeflux_bc_x2(DevGrid g, Real flux_i)
+{
+  const long lin = (long)blockIdx.x*blockDim.x + threadIdx.x;
+  const long n1 = g.Nx1 + 1;
+  if (lin >= n1*(g.Nx3 + 1)) return;
+  const long i = lin % n1, k = lin / n1;
+  g.edgeflux[k*(long)(g.Nx2 + 1)*n1 + i] = flux_i;
+}
+
 // bvals_ionrad.c:63 / outflow_flux_ix1 :308: EdgeFlux[k][j][0] = flux_i for k<=Nx3, j<=Nx2
 __global__ void k_edgeflux_bc(DevGrid g, Real flux_i)
 {
@@ -477,6 +358,10 @@ void launch_ray_sweep(const DevGrid &g, const IonPar &p, Real flux0, bool from_e
 // ray sweep + the rates of every zone + the two time-step limits (what launch_ray_sweep + launch_ion_rates do)
 void launch_ray_sweep_rates(const DevGrid &g, const IonPar &p, Real flux0, bool from_edgeflux, DevScalars *sc, hipStream_t st)
 { hipLaunchKernelGGL(k_ray_sweep<true>, dim3((g.Nx2 + RS_RAYS - 1)/RS_RAYS, g.Nx3), dim3(256), 0, st, g, p, flux0, from_edgeflux ? 1 : 0, sc); }
+void launch_ray_sweep_x2(const DevGrid &g, const IonPar &p, Real flux_i, hipStream_t st)
+{ const long n = (long)g.Nx1*g.Nx3; hipLaunchKernelGGL(k_ray_sweep_x2, dim3(nblk(n, 256)), dim3(256), 0, st, g, p, flux_i); }
+void launch_edgeflux_bc_x2(const DevGrid &g, Real flux_i, hipStream_t st)
+{ const long n = (long)(g.Nx1 + 1)*(g.Nx3 + 1); hipLaunchKernelGGL(k_edgeflux_bc_x2, dim3(nblk(n, 256)), dim3(256), 0, st, g, flux_i); }
 void launch_ion_rates(const DevGrid &g, const IonPar &p, DevScalars *sc, hipStream_t st)
 { const long n = (long)g.Nx1*g.Nx2*g.Nx3; const unsigned nb = reduce_blocks(n);
   hipLaunchKernelGGL(k_ion_rates, dim3(nb), dim3(256), 0, st, g, p, sc); }

@@ -1,0 +1,484 @@
+// slabs.hip -- ONE Grid of the caller on several GPUs, behind the unchanged C-ABI.
+//
+// The reference reaches N ranks through MPI: init_mesh.c:583-620 cuts a Domain into Grids, bvals_mhd.c:423-493
+// exchanges the x3 ghost zones, new_dt.c:177 and ionrad_3d.c:275,399,554,672 reduce scalars.  A driver that owns
+// ONE host Grid per Domain (the reference's main() linked on host/athena_shim.c, one process) gets the same
+// decomposition here, inside the library: aa_create with aa_params.nslab > 1 (or AA_NGPU in the environment)
+// returns a composite handle whose slabs are ordinary aa_grid objects, one per device, cut along x3 only (rays
+// travel along x1; x3 planes are contiguous).  Every entry point of include/athena_amd.h forwards to the slabs:
+//   * host transfers scatter / gather k-plane ranges of the caller's block (a slab's block incl. ghost planes is a
+//     contiguous sub-block of it);
+//   * bvals_mhd: x1, x2 and physical x3 boundaries per slab, then both directions of the 4-plane x3 halo as
+//     device-to-device copies between neighbouring slabs (hipMemcpyPeerAsync over xGMI), ordered by events on the
+//     slabs' own streams -- no host synchronisation;
+//   * new_dt and the radiation sub-cycle's reductions: every slab leaves its words in pinned host memory, the
+//     host folds them (MIN / MAX / integer SUM: bitwise independent of the cut) -- one wait per sub-cycle, the
+//     slabs' kernels running concurrently;
+//   * StaticGravPot is evaluated at the positions of the caller's undivided Grid, and the problem generator /
+//     Userwork hooks work on the caller's block, so an N-slab run reproduces the 1-slab run bit for bit.
+// Block decomposition as init_mesh.c:583-620: Nx3/N planes each, the remainder to the first slabs.
+#include <hip/hip_runtime.h>
+#include <float.h>
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#include <vector>
+#include "api_internal.h"
+
+using namespace aa;
+
+struct SlabLink {
+  int n = 0;
+  std::vector<int> k0, nk, dev;            // first active plane (0-based, global), planes, HIP device of every slab
+  std::vector<int> lo, hi;                 // neighbour slab below / above (-1: physical boundary)
+  std::vector<Real*> send[2], recv[2];     // halo buffers on every slab's device
+  std::vector<hipEvent_t> packed, copied;  // slab's send buffers are full / slab has pulled its neighbours' buffers
+  std::vector<bool> copied_valid;
+  double *hwords = nullptr;                // pinned: n x AA_ION_WORDS
+  DevScalars *hsc = nullptr;               // pinned: n
+  std::vector<Real*> dwords_all;           // device: n x AA_ION_WORDS on every slab
+  size_t halo = 0;
+};
+
+#define SLAB_DEV(L, s) HIPCHK(hipSetDevice((L)->dev[s]))
+
+void slabs_push_state(aa_grid *g)
+{ for (aa_grid *c : g->slab) { c->time = g->time; c->dt = g->dt; c->nstep = g->nstep; } }
+
+int slabs_create(const aa_params *p, int nslab, aa_grid **out)
+{
+  if (nslab > 64) return aa_fail(-1, "[aa_create]: %d slabs", nslab);
+  if (p->level != 0) return aa_fail(-1, "[aa_create]: only the root level can be cut into slabs");
+  if (p->Nx[2]/nslab < AA_NGHOST) return aa_fail(-1, "[aa_create]: %d x3 planes cut into %d slabs leave fewer than nghost = %d planes each",
+                                                  p->Nx[2], nslab, AA_NGHOST);
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+    return aa_fail(-3, "[aa_create]: no HIP device visible -- this library has no CPU path");
+  aa_grid *g = new aa_grid();
+  g->p = *p; g->p.nslab = nslab;
+  memset(&g->d, 0, sizeof g->d);
+  g->level = 0;
+  SlabLink *L = new SlabLink(); g->link = L; L->n = nslab;
+  // devices: AA_SLAB_DEVICES="0,1,2,.." or round robin over the visible ones (one device: a rehearsal of the
+  // multi-GPU path, every slab on it)
+  std::vector<int> devs;
+  if (const char *e = getenv("AA_SLAB_DEVICES")) { for (const char *q = e; *q; ) { devs.push_back(atoi(q)); while (*q && *q != ',') q++; if (*q) q++; } }
+  const bool periodic = (p->bc[4] == AA_BC_PERIODIC && p->bc[5] == AA_BC_PERIODIC);
+  const Real dx3 = (p->xmax[2] - p->xmin[2])/(Real)(p->rootNx[2]);
+  int k0 = 0; Real minx3 = p->MinX[2];
+  for (int s = 0; s < nslab; s++) {
+    const int nk = p->Nx[2]/nslab + (s < p->Nx[2] % nslab ? 1 : 0);      // init_mesh.c:583-620
+    aa_params ps = *p;
+    ps.nslab = 1;
+    ps.Nx[2] = nk; ps.MinX[2] = minx3;                                    // init_grid.c:104-111
+    ps.device = devs.empty() ? (p->device + s) % ndev : devs[s % devs.size()];
+    if (ps.device >= ndev) { aa_destroy(g); return aa_fail(-1, "[aa_create]: slab %d wants HIP device %d of %d", s, ps.device, ndev); }
+    const int lo = (s > 0) ? s - 1 : (periodic ? nslab - 1 : -1), hi = (s < nslab - 1) ? s + 1 : (periodic ? 0 : -1);
+    if (lo >= 0) ps.bc[4] = AA_BC_NONE;
+    if (hi >= 0) ps.bc[5] = AA_BC_NONE;
+    aa_grid *c = nullptr;
+    int rc = aa_create(&ps, &c);
+    if (rc) { aa_destroy(g); return rc; }
+    g->slab.push_back(c);
+    L->k0.push_back(k0); L->nk.push_back(nk); L->dev.push_back(ps.device); L->lo.push_back(lo); L->hi.push_back(hi);
+    k0 += nk; minx3 += (Real)nk*dx3;
+  }
+  g->ion_fused = g->slab[0]->ion_fused;
+  for (aa_grid *c : g->slab) if (c->ion_fused != g->ion_fused) { aa_destroy(g); return aa_fail(-1, "[aa_create]: slabs disagree on the sub-cycle path"); }
+  L->halo = (size_t)aa_halo_doubles(g->slab[0]);
+  L->packed.resize(nslab); L->copied.resize(nslab); L->copied_valid.assign(nslab, false);
+  L->dwords_all.assign(nslab, nullptr);
+  for (int w = 0; w < 2; w++) { L->send[w].assign(nslab, nullptr); L->recv[w].assign(nslab, nullptr); }
+  for (int s = 0; s < nslab; s++) {
+    SLAB_DEV(L, s);
+    for (int w = 0; w < 2; w++) {
+      HIPCHK(hipMalloc(&L->send[w][s], L->halo*sizeof(Real)));
+      HIPCHK(hipMalloc(&L->recv[w][s], L->halo*sizeof(Real)));
+    }
+    HIPCHK(hipMalloc(&L->dwords_all[s], (size_t)nslab*AA_ION_WORDS*sizeof(Real)));
+    HIPCHK(hipEventCreateWithFlags(&L->packed[s], hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&L->copied[s], hipEventDisableTiming));
+    for (int o : {L->lo[s], L->hi[s]})
+      if (o >= 0 && L->dev[o] != L->dev[s]) {
+        int can = 0;
+        if (hipDeviceCanAccessPeer(&can, L->dev[s], L->dev[o]) == hipSuccess && can) {
+          hipError_t e = hipDeviceEnablePeerAccess(L->dev[o], 0);
+          if (e != hipSuccess) (void)hipGetLastError();                    // already enabled
+        }
+      }
+  }
+  HIPCHK(hipHostMalloc(&L->hwords, (size_t)nslab*AA_ION_WORDS*sizeof(double)));
+  HIPCHK(hipHostMalloc(&L->hsc, (size_t)nslab*sizeof(DevScalars)));
+  HIPCHK(hipHostMalloc(&g->sc_host, sizeof(DevScalars)));
+  for (aa_grid *c : g->slab) g->bytes += c->bytes;
+  *out = g;
+  return 0;
+}
+
+void slabs_destroy(aa_grid *g)
+{
+  SlabLink *L = g->link;
+  for (size_t s = 0; s < g->slab.size(); s++) {
+    hipSetDevice(L->dev[s]);
+    hipStreamSynchronize(g->slab[s]->st);
+    if (s < L->send[0].size()) for (int w = 0; w < 2; w++) { if (L->send[w][s]) hipFree(L->send[w][s]); if (L->recv[w][s]) hipFree(L->recv[w][s]); }
+    if (s < L->dwords_all.size() && L->dwords_all[s]) hipFree(L->dwords_all[s]);
+    if (s < L->packed.size() && L->packed[s]) { hipEventDestroy(L->packed[s]); hipEventDestroy(L->copied[s]); }
+    aa_destroy(g->slab[s]);
+  }
+  if (L->hwords) hipHostFree(L->hwords);
+  if (L->hsc) hipHostFree(L->hsc);
+  if (g->sc_host) hipHostFree(g->sc_host);
+  delete L;
+  g->slab.clear();
+  delete g;
+}
+
+int slabs_sync(aa_grid *g)
+{
+  SlabLink *L = g->link;
+  for (int s = 0; s < L->n; s++) { SLAB_DEV(L, s); HIPCHK(hipStreamSynchronize(g->slab[s]->st)); }
+  return 0;
+}
+long long slabs_device_bytes(const aa_grid *g) { return g->bytes; }
+
+// ---- host transfers: k-plane ranges of the caller's block --------------------------------------------
+int slabs_upload_cons(aa_grid *g, const double *U)
+{
+  SlabLink *L = g->link;
+  const size_t pl = (size_t)(g->p.Nx[0] + 2*AA_NGHOST)*(g->p.Nx[1] + 2*AA_NGHOST)*(5 + g->p.nscal);
+  for (int s = 0; s < L->n; s++) {
+    SLAB_DEV(L, s);
+    int rc = aa_upload_cons(g->slab[s], U + (size_t)L->k0[s]*pl);       // planes k0 .. k0 + nk + 8 of the block
+    if (rc) return rc;
+  }
+  return 0;
+}
+int slabs_download_cons(aa_grid *g, double *U)
+{
+  SlabLink *L = g->link;
+  const size_t pl = (size_t)(g->p.Nx[0] + 2*AA_NGHOST)*(g->p.Nx[1] + 2*AA_NGHOST)*(5 + g->p.nscal);
+  for (int s = 0; s < L->n; s++) {
+    SLAB_DEV(L, s);
+    // the slab's active planes, plus the ghost planes only where it ends at the Grid's own boundary
+    int kf = AA_NGHOST, np = L->nk[s];
+    if (s == 0) { kf = 0; np += AA_NGHOST; }
+    if (s == L->n - 1) np += AA_NGHOST;
+    int rc = aa_download_cons_planes(g->slab[s], kf, np, U + (size_t)(L->k0[s] + kf)*pl);
+    if (rc) return rc;
+  }
+  return 0;
+}
+int slabs_upload_edgeflux(aa_grid *g, const double *ef)
+{
+  SlabLink *L = g->link;
+  const size_t pl = (size_t)(g->p.Nx[0] + 1)*(g->p.Nx[1] + 1);
+  for (int s = 0; s < L->n; s++) { SLAB_DEV(L, s); int rc = aa_upload_edgeflux(g->slab[s], ef + (size_t)L->k0[s]*pl); if (rc) return rc; }
+  return 0;
+}
+int slabs_download_edgeflux(aa_grid *g, double *ef)
+{
+  SlabLink *L = g->link;
+  const size_t pl = (size_t)(g->p.Nx[0] + 1)*(g->p.Nx[1] + 1);
+  for (int s = 0; s < L->n; s++) {
+    SLAB_DEV(L, s);
+    int rc = aa_download_edgeflux_planes(g->slab[s], L->nk[s] + (s == L->n - 1 ? 1 : 0), ef + (size_t)L->k0[s]*pl);
+    if (rc) return rc;
+  }
+  return 0;
+}
+
+// ---- hooks ---------------------------------------------------------------------------------------------
+int slabs_set_grav_tables(aa_grid *g, const double *pc, const double *p1, const double *p2, const double *p3)
+{
+  SlabLink *L = g->link;
+  const size_t pl = (size_t)(g->p.Nx[0] + 2*AA_NGHOST)*(g->p.Nx[1] + 2*AA_NGHOST);
+  for (int s = 0; s < L->n; s++) {
+    SLAB_DEV(L, s);
+    const size_t o = (size_t)L->k0[s]*pl;
+    int rc = pc ? aa_set_static_grav_tables(g->slab[s], pc + o, p1 + o, p2 + o, p3 + o)
+                : aa_set_static_grav_tables(g->slab[s], nullptr, nullptr, nullptr, nullptr);
+    if (rc) return rc;
+  }
+  g->grav = (pc != nullptr);
+  return 0;
+}
+
+int slabs_set_pinned_cells(aa_grid *g, long long n, const long long *index, const double *values)
+{
+  SlabLink *L = g->link;
+  const int nvar = 5 + g->p.nscal;
+  const long long pl = (long long)(g->p.Nx[0] + 2*AA_NGHOST)*(g->p.Nx[1] + 2*AA_NGHOST);
+  g->npin = 0;
+  for (int s = 0; s < L->n; s++) {
+    // a zone belongs to the slab in which it is active (or a ghost zone of the Grid's own boundary)
+    const long long klo = (s == 0) ? 0 : L->k0[s] + AA_NGHOST;
+    const long long khi = (s == L->n - 1) ? g->p.Nx[2] + 2*AA_NGHOST : L->k0[s] + AA_NGHOST + L->nk[s];
+    std::vector<long long> idx; std::vector<double> val;
+    for (long long q = 0; q < n; q++) {
+      const long long k = index[q]/pl;
+      if (k < klo || k >= khi) continue;
+      idx.push_back(index[q] - (long long)L->k0[s]*pl);
+      for (int v = 0; v < nvar; v++) val.push_back(values[q*nvar + v]);
+    }
+    SLAB_DEV(L, s);
+    int rc = aa_set_pinned_cells(g->slab[s], (long long)idx.size(), idx.data(), val.data());
+    if (rc) return rc;
+    g->npin += (long long)idx.size();
+  }
+  return 0;
+}
+int slabs_apply_pinned_cells(aa_grid *g)
+{
+  SlabLink *L = g->link;
+  for (int s = 0; s < L->n; s++) { SLAB_DEV(L, s); int rc = aa_apply_pinned_cells(g->slab[s]); if (rc) return rc; }
+  return 0;
+}
+int slabs_add_radplane(aa_grid *g, int dir, double flux)
+{
+  SlabLink *L = g->link;
+  if (dir == -2) g->ion_fused = false;
+  for (int s = 0; s < L->n; s++) { SLAB_DEV(L, s); int rc = aa_add_radplane_3d(g->slab[s], dir, flux); if (rc) return rc; }
+  return 0;
+}
+int slabs_bvals_ionrad(aa_grid *g)
+{
+  SlabLink *L = g->link;
+  for (int s = 0; s < L->n; s++) { SLAB_DEV(L, s); int rc = aa_bvals_ionrad(g->slab[s]); if (rc) return rc; }
+  return 0;
+}
+
+// ---- ghost zones: bvals_mhd.c:423-493 between slabs ---------------------------------------------------
+static int exchange_x3(aa_grid *g)
+{
+  SlabLink *L = g->link;
+  const int nvar = 5 + g->p.nscal;
+  const size_t bytes = L->halo*sizeof(Real);
+  for (int s = 0; s < L->n; s++) {
+    if (L->lo[s] < 0 && L->hi[s] < 0) continue;
+    SLAB_DEV(L, s);
+    aa_grid *c = g->slab[s];
+    // my send buffers are free once both neighbours have pulled the previous exchange out of them
+    for (int o : {L->lo[s], L->hi[s]}) if (o >= 0 && L->copied_valid[o]) HIPCHK(hipStreamWaitEvent(c->st, L->copied[o], 0));
+    if (L->lo[s] >= 0) launch_pack_x3(c->d, nvar, c->d.ks, L->send[0][s], c->st);                       // pack_ix3
+    if (L->hi[s] >= 0) launch_pack_x3(c->d, nvar, c->d.ke - AA_NGHOST + 1, L->send[1][s], c->st);       // pack_ox3
+    HIPCHK(hipEventRecord(L->packed[s], c->st));
+  }
+  for (int r = 0; r < L->n; r++) {
+    if (L->lo[r] < 0 && L->hi[r] < 0) continue;
+    SLAB_DEV(L, r);
+    aa_grid *c = g->slab[r];
+    if (L->lo[r] >= 0) {         // the lower neighbour's upper planes fill my lower ghost planes
+      const int o = L->lo[r];
+      HIPCHK(hipStreamWaitEvent(c->st, L->packed[o], 0));
+      HIPCHK(hipMemcpyPeerAsync(L->recv[0][r], L->dev[r], L->send[1][o], L->dev[o], bytes, c->st));
+      launch_unpack_x3(c->d, nvar, c->d.ks - AA_NGHOST, L->recv[0][r], c->st);
+    }
+    if (L->hi[r] >= 0) {
+      const int o = L->hi[r];
+      HIPCHK(hipStreamWaitEvent(c->st, L->packed[o], 0));
+      HIPCHK(hipMemcpyPeerAsync(L->recv[1][r], L->dev[r], L->send[0][o], L->dev[o], bytes, c->st));
+      launch_unpack_x3(c->d, nvar, c->d.ke + 1, L->recv[1][r], c->st);
+    }
+    HIPCHK(hipEventRecord(L->copied[r], c->st));
+    L->copied_valid[r] = true;
+  }
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+int slabs_bvals_mhd(aa_grid *g)
+{
+  SlabLink *L = g->link;
+  for (int s = 0; s < L->n; s++) { SLAB_DEV(L, s); int rc = aa_bvals_mhd(g->slab[s]); if (rc) return rc; }   // x1, x2, physical x3
+  return exchange_x3(g);        // after x1 and x2, all i and j incl. ghosts: the corners travel (bvals_mhd.c:170)
+}
+
+// one (*BCFun)(pGrid) call of bvals_mhd.c:196-420 for drivers that interleave user boundary functions: the slabs'
+// exchange belongs to the x3 step and is done with its inner side
+int slabs_bvals_mhd_side(aa_grid *g, int dir, int side)
+{
+  SlabLink *L = g->link;
+  if (dir < 2) {
+    for (int s = 0; s < L->n; s++) { SLAB_DEV(L, s); int rc = aa_bvals_mhd_side(g->slab[s], dir, side); if (rc) return rc; }
+    return 0;
+  }
+  const int s = side ? L->n - 1 : 0;
+  SLAB_DEV(L, s);
+  int rc = aa_bvals_mhd_side(g->slab[s], dir, side); if (rc) return rc;
+  return side == 0 ? exchange_x3(g) : 0;
+}
+
+// ---- time step: new_dt.c:72-177 ----------------------------------------------------------------------
+static int cfl_all(aa_grid *g)
+{
+  SlabLink *L = g->link;
+  for (int s = 0; s < L->n; s++) {
+    SLAB_DEV(L, s);
+    aa_grid *c = g->slab[s];
+    { Scope sc(c, "new_dt");
+      HIPCHK(hipMemsetAsync(c->sc->max_v, 0, 3*sizeof(unsigned long long), c->st));
+      launch_cfl(c->d, c->sc, c->st); }
+    HIPCHK(hipMemcpyAsync(&L->hsc[s], c->sc, sizeof(DevScalars), hipMemcpyDeviceToHost, c->st));
+  }
+  for (int s = 0; s < L->n; s++) { SLAB_DEV(L, s); HIPCHK(hipStreamSynchronize(g->slab[s]->st)); }
+  g->host_syncs++;
+  return 0;
+}
+int slabs_cfl_max_v(aa_grid *g, double *v)
+{
+  int rc = cfl_all(g); if (rc) return rc;
+  for (int d = 0; d < 3; d++) {
+    v[d] = 0.0;
+    for (int s = 0; s < g->link->n; s++) { const double q = bits_to_double(g->link->hsc[s].max_v[d]); v[d] = (v[d] > q) ? v[d] : q; }
+  }
+  return 0;
+}
+int slabs_new_dt_local(aa_grid *g, double *dt_cfl)
+{
+  // every slab's own dt as new_dt.c:159-170 computes it, then the MIN over slabs (:177)
+  int rc = cfl_all(g); if (rc) return rc;
+  double dt = DBL_MAX;
+  for (int s = 0; s < g->link->n; s++) {
+    double max_dti = 0.0;
+    for (int d = 0; d < 3; d++) { const double v = bits_to_double(g->link->hsc[s].max_v[d])/g->slab[s]->d.dx[d]; max_dti = (max_dti > v) ? max_dti : v; }
+    const double q = g->p.cour_no/max_dti;
+    dt = (q < dt) ? q : dt;
+  }
+  *dt_cfl = dt;
+  return 0;
+}
+
+int slabs_integrate(aa_grid *g, int vl)
+{
+  SlabLink *L = g->link;
+  slabs_push_state(g);
+  for (int s = 0; s < L->n; s++) {
+    SLAB_DEV(L, s);
+    int rc = vl ? aa_integrate_3d_vl(g->slab[s]) : aa_integrate_3d_ctu(g->slab[s]);
+    if (rc) return rc;
+  }
+  return 0;
+}
+
+// ---- radiation -----------------------------------------------------------------------------------------
+int slabs_ion_begin(aa_grid *g)
+{
+  SlabLink *L = g->link;
+  slabs_push_state(g);
+  for (int s = 0; s < L->n; s++) { SLAB_DEV(L, s); int rc = aa_ion_begin(g->slab[s]); if (rc) return rc; }
+  return 0;
+}
+
+// the one-kernel sub-cycle: every slab runs its pass; slabs_ion_pick folds the slabs' words on the host
+int slabs_ion_pass(aa_grid *g, int update, int sweep)
+{
+  SlabLink *L = g->link;
+  for (int s = 0; s < L->n; s++) {
+    SLAB_DEV(L, s);
+    aa_grid *c = g->slab[s];
+    int rc = aa_ion_pass(c, update, sweep, nullptr); if (rc) return rc;
+    HIPCHK(hipMemcpyAsync(L->hwords + (size_t)s*AA_ION_WORDS, c->ion_words, AA_ION_WORDS*sizeof(double), hipMemcpyDeviceToHost, c->st));
+  }
+  return 0;
+}
+
+int slabs_ion_pick(aa_grid *g, int first, double limit)
+{
+  SlabLink *L = g->link;
+  for (int s = 0; s < L->n; s++) { SLAB_DEV(L, s); HIPCHK(hipStreamSynchronize(g->slab[s]->st)); }
+  g->host_syncs++;
+  // every slab gets all words and picks the step itself (its next pass reads it from its own memory) ...
+  for (int s = 0; s < L->n; s++) {
+    SLAB_DEV(L, s);
+    aa_grid *c = g->slab[s];
+    HIPCHK(hipMemcpyAsync(L->dwords_all[s], L->hwords, (size_t)L->n*AA_ION_WORDS*sizeof(double), hipMemcpyHostToDevice, c->st));
+    launch_ion_pick2(L->dwords_all[s], L->n, c->sc, first, limit, c->st);
+  }
+  // ... and the host does the same arithmetic (k_ion_pick2; ionrad_3d.c:941-967) for its own control flow: no second wait
+  double dt_chem = DBL_MAX, dt_therm = DBL_MAX, max_dti = 0.0, count = 0.0, neg = 0.0;
+  for (int r = 0; r < L->n; r++) {
+    const double *w = L->hwords + (size_t)r*AA_ION_WORDS;
+    dt_chem = (dt_chem < w[0]) ? dt_chem : w[0]; dt_therm = (dt_therm < w[1]) ? dt_therm : w[1];
+    max_dti = (max_dti > w[2]) ? max_dti : w[2]; count += w[3]; neg = (neg > w[4]) ? neg : w[4];
+  }
+  DevScalars *h = g->sc_host;
+  double dt_done = 0.0;
+  if (!first) {
+    h->dt_applied = h->dt_sel; h->hit_applied = h->limit_hit; h->neg_applied = h->neg_out;
+    dt_done = h->dt_done + h->dt_sel;
+  }
+  h->dt_done = dt_done;
+  h->max_dti = double_to_bits(max_dti); h->cellcount = (unsigned long long)count;
+  double dt = (dt_therm < dt_chem) ? dt_therm : dt_chem;
+  int hit = 0;
+  if (dt_done + dt > limit) { dt = limit - dt_done; hit = 1; }
+  h->dt_sel = dt; h->limit_hit = hit; h->dt_chem_out = dt_chem; h->dt_therm_out = dt_therm; h->neg_out = (neg != 0.0);
+  return 0;
+}
+
+int slabs_ion_finish(aa_grid *g)
+{
+  SlabLink *L = g->link;
+  for (int s = 0; s < L->n; s++) { SLAB_DEV(L, s); int rc = aa_ion_finish(g->slab[s]); if (rc) return rc; }
+  return 0;
+}
+
+// the two-kernel sub-cycle (short rays): the reductions go through the host twice per sub-cycle, as under MPI
+int slabs_ion_rates(aa_grid *g, double *dt_chem, double *dt_therm)
+{
+  SlabLink *L = g->link;
+  *dt_chem = DBL_MAX; *dt_therm = DBL_MAX;
+  for (int s = 0; s < L->n; s++) {
+    SLAB_DEV(L, s);
+    double a, b; int rc = aa_ion_rates(g->slab[s], &a, &b); if (rc) return rc;
+    *dt_chem = (a < *dt_chem) ? a : *dt_chem; *dt_therm = (b < *dt_therm) ? b : *dt_therm;
+  }
+  return 0;
+}
+int slabs_ion_update(aa_grid *g, double dt, long long *cellcount, double *dt_hydro)
+{
+  SlabLink *L = g->link;
+  long long n = 0; double h = DBL_MAX;
+  for (int s = 0; s < L->n; s++) {
+    SLAB_DEV(L, s);
+    long long a; double b; int rc = aa_ion_update(g->slab[s], dt, &a, &b); if (rc) return rc;
+    n += a; h = (b < h) ? b : h;
+  }
+  if (cellcount) *cellcount = n;
+  if (dt_hydro) *dt_hydro = h;
+  return 0;
+}
+int slabs_ion_run_phased(aa_grid *g, double limit, int *niter_out, double *dt_done_out)
+{
+  // ionrad_3d.c:862-1012, root level
+  double dt_chem, dt_therm, dt_hydro = 0, dt, dt_done = 0.0;
+  long long cellcount = 0;
+  int niter = 0, hydro_done = 0, rc;
+  if ((rc = slabs_ion_begin(g))) return rc;
+  while (!hydro_done) {
+    if ((rc = slabs_ion_rates(g, &dt_chem, &dt_therm))) return rc;
+    dt = (dt_therm < dt_chem) ? dt_therm : dt_chem;
+    if (dt_done + dt > limit) { dt = limit - dt_done; hydro_done = 1; }
+    if ((rc = slabs_ion_update(g, dt, &cellcount, &dt_hydro))) return rc;
+    dt_done += dt;
+    niter++;
+    if (cellcount > MAXCELLCOUNT) { g->dt = dt_done; break; }
+    if (hydro_done) break;
+    if (dt_hydro < dt_done) { g->dt = dt_done; break; }
+  }
+  *niter_out = niter; *dt_done_out = dt_done;
+  return 0;
+}
+
+int slabs_history(aa_grid *g, double *sums)
+{
+  SlabLink *L = g->link;
+  for (int q = 0; q < 9; q++) sums[q] = 0.0;
+  for (int s = 0; s < L->n; s++) {            // dump_history.c:257 MPI_Reduce(SUM) over the Grids of a Domain
+    SLAB_DEV(L, s);
+    double part[9]; int rc = aa_history(g->slab[s], part); if (rc) return rc;
+    for (int q = 0; q < 9; q++) sums[q] += part[q];
+  }
+  return 0;
+}

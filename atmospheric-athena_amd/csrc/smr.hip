@@ -512,25 +512,11 @@ int aa_mesh_ion_radtransfer(aa_mesh *m, int l, int *niter_out)
 {
   aa_grid *g = m->lev[l];
   const bool finegrid = (l != 0);
-  double dt_chem, dt_therm, dt_hydro = 0, dt, dt_done = 0.0;
-  long long cellcount;
-  int niter = 0, hydro_done = 0, coarsetime_done = 0, rc;
+  double dt_done = 0.0;
+  int niter = 0, rc;
   if (finegrid) { if ((rc = aa_mesh_ionflux_prolong(m, l))) return rc; }
   else m->tcoarse = 0;
-  if ((rc = aa_ion_begin(g))) return rc;
-  if ((rc = aa_ion_arm(g))) return rc;
-  while (finegrid || !hydro_done) {
-    int hit = 0;
-    if ((rc = aa_ion_subcycle(g, dt_done, finegrid ? m->tcoarse : g->dt, &dt, &hit, &dt_chem, &dt_therm, &cellcount, &dt_hydro))) return rc;
-    if (finegrid) coarsetime_done = hit; else hydro_done = hit;
-    dt_done += dt;
-    niter++;
-    if (!finegrid) {
-      if (cellcount > MAXCELLCOUNT) { g->dt = dt_done; break; }
-      if (hydro_done) break;
-      if (dt_hydro < dt_done) { g->dt = dt_done; break; }
-    } else if (coarsetime_done) { g->dt = dt_done; break; }
-  }
+  if ((rc = aa_ion_run(g, finegrid ? 1 : 0, finegrid ? m->tcoarse : g->dt, &niter, &dt_done))) return rc;
   if (!finegrid) {
     if (niter == g->p.maxiter) g->dt = dt_done;
     m->tcoarse = dt_done;

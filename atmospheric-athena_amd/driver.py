@@ -47,6 +47,11 @@ class HipEngine:
             self.g.set_stream(torch.cuda.current_stream().cuda_stream)
         n = self.g.halo_doubles()
         dev = torch.device("cuda", device)
+        # the one-kernel radiation sub-cycle leaves this slab's reduction words in device memory; with several
+        # ranks they are all-gathered on the stream (ONE collective per sub-cycle, no host round trip)
+        self.ion_fused = bool(grid.run.ion) and self.g.ion_is_fused()
+        self.words = torch.zeros(lib.ION_WORDS, dtype=torch.float64, device=dev)
+        self.words_all = torch.zeros(lib.ION_WORDS * max(1, grid.nranks), dtype=torch.float64, device=dev)
         self.send = [torch.empty(n, dtype=torch.float64, device=dev) for _ in range(2)]
         self.recv = [torch.empty(n, dtype=torch.float64, device=dev) for _ in range(2)]
         self.scalar_device = dev
@@ -60,6 +65,24 @@ class HipEngine:
     def ion_begin(self): self.g.ion_begin()
     def ion_rates(self): return self.g.ion_rates()
     def ion_update(self, dt): return self.g.ion_update(dt)
+    def ion_pass(self, update, sweep): self.g.ion_pass(update, sweep, self.words.data_ptr())
+
+    def ion_pick(self, dist, first, limit):
+        """the step of the sub-cycle from the words of all slabs (ionrad_3d.c:399,:554,:275,:672 in one round)"""
+        if dist is None:
+            self.g.ion_pick(self.words.data_ptr(), 1, first, limit)
+            return
+        if dist.get_backend() == "gloo":                     # rehearsal on one GPU: gloo moves host tensors
+            w = self.words.cpu(); wa = self.words_all.cpu()
+            dist.all_gather_into_tensor(wa, w)
+            self.words_all.copy_(wa)
+        else:
+            dist.all_gather_into_tensor(self.words_all, self.words)
+        self.g.ion_pick(self.words_all.data_ptr(), self.cfg.nranks, first, limit)
+
+    def ion_fetch(self): return self.g.ion_fetch()
+    def ion_finish(self): self.g.ion_finish()
+    def host_syncs(self, reset=False): return self.g.host_syncs(reset)
     def set_mesh_state(self, time, dt, nstep): self.g.set_mesh_state(time, dt, nstep)
     def has_radiation(self) -> bool: return bool(self.cfg.run.ion)
     def step_local(self) -> int: return self.g.step()
@@ -89,6 +112,7 @@ class Driver:
         self.eng = engine_factory(self.grid) if engine_factory else HipEngine(self.grid, device, strict)
         self.time, self.dt, self.nstep = 0.0, 0.0, 0
         self.niter_trace: List[int] = []
+        self._py_syncs = 0        # host round trips of collectives issued from here (bench: host_syncs_per_step)
         # AA_FORCE_DISTRIBUTED=1 runs the Python-orchestrated loop (with its collectives) even on one
         # rank: used to rehearse the N>1 code path on a single GPU
         self.distributed = nranks > 1 or bool(os.environ.get("AA_FORCE_DISTRIBUTED"))
@@ -105,7 +129,15 @@ class Driver:
             return list(vals)
         t = self.torch.tensor(list(vals), dtype=self.torch.float64, device=self._sdev)
         self.dist.all_reduce(t, op=op)
+        self._py_syncs += 1
         return t.tolist()
+
+    def host_sync_count(self, reset: bool = False) -> int:
+        """Times the host waited for the device to hand back scalars (library read-backs + collectives' .tolist())."""
+        n = self._py_syncs + (self.eng.host_syncs(reset) if hasattr(self.eng, "host_syncs") else 0)
+        if reset:
+            self._py_syncs = 0
+        return n
 
     def _min(self, *vals): return self._allreduce(vals, self.dist.ReduceOp.MIN if self.distributed else None)
 
@@ -182,8 +214,44 @@ class Driver:
             self.dt = self.run.tlim - self.time
         self.eng.set_mesh_state(self.time, self.dt, self.nstep)
 
+    def _ion_radtransfer_fused(self) -> int:
+        """ionrad_3d.c:862-1047 with the one-kernel sub-cycle (include/athena_amd.h, aa_ion_pass): the loop is cut at
+        the reduction that yields the step, so a sub-cycle is one pass, ONE all-gather of the slabs' words and one
+        read-back; the sweep after a data-dependent stop is speculative and dropped by ion_finish."""
+        e = self.eng
+        dist = self.dist if self.distributed else None
+        dt_done, niter = 0.0, 0
+        e.ion_begin()
+        e.ion_pass(False, True)
+        e.ion_pick(dist, True, self.dt)
+        while True:
+            e.ion_pass(True, True)          # the pass skips its sweep by itself once the step was cut back to the limit
+            e.ion_pick(dist, False, self.dt)
+            dt, hit, dt_chem, dt_therm, cellcount, dt_hydro, neg = e.ion_fetch()       # the one read-back
+            if neg:
+                raise RuntimeError("[compute_chem_rates]: negative dt_chem")           # ionrad_3d.c:389-391
+            dt_done += dt
+            niter += 1
+            if cellcount > MAXCELLCOUNT:
+                self.dt = dt_done
+                break
+            if hit:
+                break
+            if dt_hydro < dt_done:
+                self.dt = dt_done
+                break
+        e.ion_finish()
+        if niter == self.run.maxiter:
+            self.dt = dt_done
+        if self.dt < 0:
+            raise RuntimeError(f"[ion_radtransfer_3d]: dt = {self.dt}")
+        e.set_mesh_state(self.time, self.dt, self.nstep)
+        return niter
+
     def ion_radtransfer(self) -> int:   # ionrad_3d.c:862-1047, root level
         e = self.eng
+        if getattr(e, "ion_fused", False):
+            return self._ion_radtransfer_fused()
         dt_done, niter, hydro_done = 0.0, 0, False
         e.ion_begin()
         while not hydro_done:
@@ -266,7 +334,8 @@ class HipMeshEngine:
         self.torch = torch
         self.cfg = cfg
         torch.cuda.set_device(device)
-        self.mesh = lib.Mesh(cfg.levels, device, strict, links=cfg.links)
+        # (the multi-rank SMR loop still reduces the sub-cycle's scalars on the host: two-kernel sub-cycle)
+        self.mesh = lib.Mesh(cfg.levels, device, strict, links=cfg.links, ion_path=2)
         if use_torch_stream:
             self.mesh.set_stream(torch.cuda.current_stream().cuda_stream)
         self.lev = self.mesh.lev

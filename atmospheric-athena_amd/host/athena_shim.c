@@ -110,6 +110,9 @@ static void ensure_grid(MeshS *pM)
       if ((pD->Disp[d] + pD->Nx[d])/irefine != pM->Nx[d]) p.bc[2*d + 1] = 0;
     }
     p.level = l;
+#ifdef AA_SMR
+    p.nslab = 1;                                   /* nested levels stay on one GPU */
+#endif
     p.nscal = AA_NSCALARS;
 #if AA_ION_RADPLANE
     p.ion = (pM->radplanelist != NULL && pM->radplanelist->nradplane > 0);
@@ -141,6 +144,11 @@ static void ensure_grid(MeshS *pM)
     if (p.ion) CHK(aa_add_radplane_3d(G[l], pM->radplanelist->dir[0], pM->radplanelist->flux_i));
 #endif
     if (StaticGravPot != NULL) CHK(aa_set_static_grav_pot(G[l], StaticGravPot));
+    env = getenv("AA_NGPU");
+    if (env && atoi(env) > 1 && pM->NLevels == 1)   /* the library cuts the Grid into x3 slabs, one per GPU (csrc/slabs.hip) */
+      fprintf(stderr, "[athena_amd] Grid %dx%dx%d in %d slabs along x3 on HIP devices %d.., %.2f GB resident, coherence=%s\n",
+              p.Nx[0], p.Nx[1], p.Nx[2], atoi(env), p.device, aa_device_bytes(G[l])/1e9, learn ? "learn" : "step");
+    else
     fprintf(stderr, "[athena_amd] Grid %dx%dx%d (level %d) on HIP device %d, %.2f GB resident, coherence=%s\n",
             p.Nx[0], p.Nx[1], p.Nx[2], l, p.device, aa_device_bytes(G[l])/1e9, learn ? "learn" : "step");
   }

@@ -33,9 +33,11 @@ class aa_params(C.Structure):
         ("max_de_step", C.c_double), ("max_de_therm_step", C.c_double), ("max_dx_step", C.c_double),
         ("tfloor", C.c_double), ("tceil", C.c_double),
         ("maxiter", C.c_int), ("device", C.c_int), ("integrator", C.c_int), ("level", C.c_int),
-        ("order", C.c_int),
+        ("order", C.c_int), ("ion_path", C.c_int), ("nslab", C.c_int),
     ]
 
+
+ION_WORDS = 8     # AA_ION_WORDS of include/athena_amd.h
 
 GRAVPOT = C.CFUNCTYPE(C.c_double, C.c_double, C.c_double, C.c_double)
 
@@ -61,6 +63,8 @@ def load(strict: bool | None = None) -> C.CDLL:
     if strict in _libs:
         return _libs[strict]
     name = "libathena_amd_strict.so" if strict else "libathena_amd.so"
+    if os.environ.get("ATHENA_AMD_VARIANT") and not strict:        # A/B experiment builds (csrc/Makefile `variant`)
+        name = f"libathena_amd_{os.environ['ATHENA_AMD_VARIANT']}.so"
     path = os.path.join(HERE, name)
     if not os.path.exists(path):
         raise AthenaError(f"{path} is missing: run __graft_entry__.build() (no CPU fallback exists)")
@@ -93,6 +97,8 @@ def load(strict: bool | None = None) -> C.CDLL:
         "aa_start": (I, [P]), "aa_step": (I, [P, ip]),
         "aa_new_dt_local": (I, [P, dp]), "aa_ion_begin": (I, [P]), "aa_ion_rates": (I, [P, dp, dp]),
         "aa_ion_update": (I, [P, D, llp, dp]),
+        "aa_ion_is_fused": (I, [P]), "aa_ion_pass": (I, [P, I, I, P]), "aa_ion_pick": (I, [P, P, I, I, D]),
+        "aa_ion_fetch": (I, [P, dp, ip, dp, dp, llp, dp, ip]), "aa_ion_finish": (I, [P]), "aa_host_syncs": (I, [P, I]),
         "aa_halo_doubles": (LL, [P]), "aa_pack_x3": (I, [P, I, P]), "aa_unpack_x3": (I, [P, I, P]),
         "aa_mesh_create": (I, [I, C.POINTER(P), ip, C.POINTER(P)]), "aa_mesh_destroy": (None, [P]),
         "aa_mesh_get_state": (I, [P, dp, dp, ip]), "aa_mesh_set_state": (I, [P, D, D, I]),
@@ -105,6 +111,7 @@ def load(strict: bool | None = None) -> C.CDLL:
         "aa_test_fluxes": (I, [I, D, I, dp, dp, dp, dp]),
         "aa_test_lr_states": (I, [I, D, I, dp, D, D, I, I, dp, dp]),
         "aa_test_lr_states_ppm": (I, [I, D, I, dp, D, D, I, I, dp, dp]),
+        "aa_test_explog": (I, [I, dp, dp, dp]),
         "aa_history": (I, [P, dp]),
         "aa_profile_enable": (I, [P, I]), "aa_profile_reset": (I, [P]), "aa_profile_count": (I, [P]),
         "aa_profile_name": (C.c_char_p, [P, I]), "aa_profile_get": (I, [P, I, dp, llp]),
@@ -140,7 +147,7 @@ def _dp(a: np.ndarray):
     return a.ctypes.data_as(C.POINTER(C.c_double))
 
 
-def params_from_grid(g: GridConfig, device: int = 0) -> aa_params:
+def params_from_grid(g: GridConfig, device: int = 0, ion_path: int = 0, nslab: int = 1) -> aa_params:
     r = g.run
     p = aa_params()
     for d in range(3):
@@ -157,16 +164,19 @@ def params_from_grid(g: GridConfig, device: int = 0) -> aa_params:
     p.integrator = 1 if r.integrator == "vl" else 0
     p.level = g.level
     p.order = getattr(r, "order", 2)
+    p.ion_path = ion_path
+    p.nslab = nslab
     return p
 
 
 class Grid:
     """Device-resident Grid.  Method names follow the reference's call sites."""
 
-    def __init__(self, grid: GridConfig, device: int = 0, strict: bool | None = None):
+    def __init__(self, grid: GridConfig, device: int = 0, strict: bool | None = None, ion_path: int = 0, nslab: int = 1):
+        """nslab > 1: the Grid is cut into x3 slabs inside the library (aa_params.nslab), one per GPU."""
         self.cfg = grid
         self.L = load(strict)
-        self.params = params_from_grid(grid, device)
+        self.params = params_from_grid(grid, device, ion_path, nslab)
         self.nvar = 5 + grid.run.nscal
         self.N = tuple(n + 2 * NGHOST for n in grid.Nx)          # (N1, N2, N3)
         h = C.c_void_p()
@@ -276,6 +286,25 @@ class Grid:
         c = C.c_longlong(); h = C.c_double()
         self._chk(self.L.aa_ion_update(self._h, dt, C.byref(c), C.byref(h))); return c.value, h.value
 
+    # the one-kernel sub-cycle (aa_ion_is_fused): pass / [all-gather of the words] / pick / fetch
+    def ion_is_fused(self) -> bool: return bool(self.L.aa_ion_is_fused(self._h))
+
+    def ion_pass(self, update: bool, sweep: bool, dev_words: int = 0):
+        self._chk(self.L.aa_ion_pass(self._h, int(update), int(sweep), C.c_void_p(dev_words or None)))
+
+    def ion_pick(self, dev_words_all: int, nranks: int, first: bool, limit: float):
+        self._chk(self.L.aa_ion_pick(self._h, C.c_void_p(dev_words_all or None), nranks, int(first), limit))
+
+    def ion_fetch(self):
+        """-> (dt, limit_hit, dt_chem, dt_therm, cellcount, dt_hydro, neg_dt_chem) of the update the last pass applied:
+        the one read-back of a sub-cycle"""
+        dt = C.c_double(); a = C.c_double(); b = C.c_double(); h = C.c_double(); hit = C.c_int(); neg = C.c_int(); n = C.c_longlong()
+        self._chk(self.L.aa_ion_fetch(self._h, C.byref(dt), C.byref(hit), C.byref(a), C.byref(b), C.byref(n), C.byref(h), C.byref(neg)))
+        return dt.value, bool(hit.value), a.value, b.value, n.value, h.value, bool(neg.value)
+
+    def ion_finish(self): self._chk(self.L.aa_ion_finish(self._h))
+    def host_syncs(self, reset: bool = False) -> int: return int(self.L.aa_host_syncs(self._h, int(reset)))
+
     def cfl_max_v(self):
         v = (C.c_double * 3)(); self._chk(self.L.aa_cfl_max_v(self._h, v)); return list(v)
 
@@ -305,11 +334,11 @@ class Grid:
         return out
 
 
-def setup_problem(grid: GridConfig, device: int = 0, strict: bool | None = None) -> Grid:
+def setup_problem(grid: GridConfig, device: int = 0, strict: bool | None = None, ion_path: int = 0, nslab: int = 1) -> Grid:
     """problem(DomainS*) of the reference for the shipped decks: fill the host block with the
     C problem generator, upload it, register the hooks (main.c:393)."""
     r = grid.run; pr = r.prob
-    g = Grid(grid, device, strict)
+    g = Grid(grid, device, strict, ion_path, nslab)
     H = host()
     U = g.new_host_block()
     if r.problem == "ifront":
@@ -349,9 +378,9 @@ class Mesh:
     names follow the reference: RestrictCorrect, Prolongate (smr.c), new_dt, and the per-level
     ion_radtransfer_3d with its coarse -> fine EdgeFlux hand-off (ionrad_smr.c)."""
 
-    def __init__(self, grids, device: int = 0, strict: bool | None = None, links=None):
+    def __init__(self, grids, device: int = 0, strict: bool | None = None, links=None, ion_path: int = 0):
         """links: config.LinkConfig list for one rank's stack of slabs (multi-GPU SMR); None = the whole Mesh."""
-        self.lev = [setup_problem(g, device, strict) for g in grids]
+        self.lev = [setup_problem(g, device, strict, ion_path) for g in grids]
         self.L = self.lev[0].L
         n = len(grids)
         hs = (C.c_void_p * n)(*[g._h for g in self.lev])

@@ -45,6 +45,15 @@ typedef struct aa_params {
                               (init_mesh.c:245); 0 for a single-level run                      */
   int    order;            /* configure --with-order: 2 (or 0) piecewise linear, lr_states_plm.c;
                               3 piecewise parabolic, lr_states_ppm.c (CTU integrator only)    */
+  int    ion_path;         /* radiation sub-cycle: 0 by size (one kernel from rays of 64 zones, or as
+                              AA_ION_FUSED says), 1 the one-kernel form (aa_ion_pass ...), 2 the
+                              two-kernel form (aa_ion_rates / aa_ion_update)                   */
+  int    nslab;            /* > 1: this ONE Grid of the caller is cut into that many x3 slabs, one per
+                              GPU (devices `device`, `device`+1, ... modulo the visible ones, or
+                              AA_SLAB_DEVICES=0,1,..), behind this same interface: the library does
+                              what init_mesh.c:583-620, bvals_mhd.c:423-493 and the MPI_Allreduce
+                              calls of new_dt.c / ionrad_3d.c do for the reference's ranks.  0: one
+                              GPU unless AA_NGPU is set in the environment; 1: one GPU          */
 } aa_params;
 
 typedef struct aa_grid aa_grid;
@@ -100,6 +109,26 @@ int aa_new_dt_local(aa_grid *g, double *dt_cfl);                /* new_dt.c:72-1
 int aa_ion_begin(aa_grid *g);                                   /* ionrad_3d.c:896-905            */
 int aa_ion_rates(aa_grid *g, double *dt_chem, double *dt_therm);/* :922-938 before Allreduce      */
 int aa_ion_update(aa_grid *g, double dt, long long *cellcount, double *dt_hydro); /* :965-1002    */
+/* The same loop for Grids that run the ONE-KERNEL sub-cycle (aa_ion_is_fused: rays of 64 zones or more; the two
+ * calls above refuse such a Grid).  The loop is cut at its only true barrier, the reduction that yields the step:
+ * pass n applies update(n-1) and runs sweep(n) + rates(n) on the updated zones; its reduction words (MIN dt_chem,
+ * MIN dt_therm, MAX (|v|+a)/dx, SUM cells out of range, OR negative-dt_chem -- the operands of the reference's four
+ * MPI_Allreduce calls ionrad_3d.c:275,399,554,672) land in DEVICE memory, AA_ION_WORDS doubles per rank.  aa_ion_pick
+ * (a one-thread kernel) folds the words of all ranks, books the update just applied -- the time covered so far stays on
+ * the device -- and picks the next step; a pass whose step was cut back to the limit skips its sweep by itself.  So a
+ * multi-rank driver issues ONE all-gather per sub-cycle on the Grid's stream and the host reads back ONCE per sub-cycle:
+ *   aa_ion_begin; aa_ion_pass(0,1); [all-gather]; aa_ion_pick(first=1);
+ *   repeat: aa_ion_pass(1,1); [all-gather]; aa_ion_pick(first=0); aa_ion_fetch -> step, limit flag and stop criteria of
+ *           the update that pass applied; the reference's stop tests (:974-1002);
+ *   aa_ion_finish (GridS.EdgeFlux of the last sweep that counted; the one after a stop was speculative).       */
+#define AA_ION_WORDS 8
+int aa_ion_is_fused(const aa_grid *g);
+int aa_ion_pass(aa_grid *g, int update, int sweep, double *dev_words);
+int aa_ion_pick(aa_grid *g, const double *dev_words_all, int nranks, int first, double limit);
+int aa_ion_fetch(aa_grid *g, double *dt, int *limit_hit, double *dt_chem, double *dt_therm, long long *cellcount,
+                 double *dt_hydro, int *neg_dt_chem);
+int aa_ion_finish(aa_grid *g);
+int aa_host_syncs(aa_grid *g, int reset);   /* stream synchronisations that returned scalars to the host so far */
 /* x3 halo: pack_ix3/pack_ox3/unpack_* (bvals_mhd.c:2608-3175).  side 0 = inner (ks..ks+3),
  * side 1 = outer; buffers are DEVICE pointers of aa_halo_doubles() doubles.                */
 long long aa_halo_doubles(const aa_grid *g);
@@ -152,6 +181,9 @@ int aa_test_lr_states(int nscal, double gamma, int n, const double *W, double dt
                       int il, int iu, double *Wl, double *Wr);          /* lr_states_plm.c:62 */
 int aa_test_lr_states_ppm(int nscal, double gamma, int n, const double *W, double dt, double dx,
                           int il, int iu, double *Wl, double *Wr);      /* lr_states_ppm.c:91  */
+
+int aa_test_explog(int n, const double *x, double *y_exp, double *y_log);  /* the exp / ln of csrc/ion_pass.hip
+                                                                             (n a multiple of 4): exp(x), ln|x|  */
 
 /* ---- dump_history.c:157-200: volume integrals over the active zones of this Grid, in the column
  *      order of the .hst file: mass, total E, x1/x2/x3 Mom., x1/x2/x3-KE, scalar 0 (0 if NSCALARS=0).

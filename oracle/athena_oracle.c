@@ -860,13 +860,18 @@ void orc_bvals(OrcSim *s)
   }
 }
 
-/* bvals_ionrad.c:63 + outflow_flux_ix1 :308 (dir=-1 only) */
+/* bvals_ionrad.c:63 + outflow_flux_ix1 :308 (dir=-1), outflow_flux_ix2 :357 (dir=-2); bvals_ionrad_init :176-232
+ * enrols the function of the lit face only */
 void orc_bvals_ionrad(OrcSim *s)
 {
-  int j, k, n0 = s->p.Nx[0]+1, n1 = s->p.Nx[1]+1;
-  if (!s->p.ion || s->rad_dir != -1) return;
-  for (k = 0; k <= s->p.Nx[2]; k++) for (j = 0; j <= s->p.Nx[1]; j++)
-    s->EdgeFlux[((size_t)k*n1 + j)*n0 + 0] = s->flux_i;
+  int i, j, k, n0 = s->p.Nx[0]+1, n1 = s->p.Nx[1]+1;
+  if (!s->p.ion) return;
+  if (s->rad_dir == -1)
+    for (k = 0; k <= s->p.Nx[2]; k++) for (j = 0; j <= s->p.Nx[1]; j++)
+      s->EdgeFlux[((size_t)k*n1 + j)*n0 + 0] = s->flux_i;
+  else if (s->rad_dir == -2)
+    for (k = 0; k <= s->p.Nx[2]; k++) for (i = 0; i <= s->p.Nx[0]; i++)
+      s->EdgeFlux[((size_t)k*n1 + 0)*n0 + i] = s->flux_i;
 }
 
 /* ------------------------------------------------------------------------------------ */
@@ -968,6 +973,32 @@ static void save_energy_and_x(OrcSim *s)           /* ionrad_3d.c:162-196 */
 
 void orc_ion_begin(OrcSim *s) { apply_temp_floor(s); apply_neutral_floor(s); save_energy_and_x(s); }
 
+/* rays along +x2 (dir=-2): ionradplane_3d.c:323-354.  Unlike case -1 the incident flux is the plane's flux_i without
+ * the time ramp, the optical depth of a zone still uses dx1 (:337) while the rate divides by dx2 (:339, cell_len :134),
+ * the cut-off compares flux/flux_i, and EdgeFlux behind the cut keeps what earlier sweeps left there */
+static void get_ph_rate_plane_x2(OrcSim *s)
+{
+  const OrcParams *p = &s->p;
+  const int n0 = p->Nx[0]+1, n1 = p->Nx[1]+1;
+  int i, j, k;
+  for (k = s->ks; k <= s->ke; k++) for (i = s->is; i <= s->ie; i++) {
+    Real flux = s->flux_i, flux_frac;
+    for (j = s->js; j <= s->je; j++) {
+      size_t m = IDX(s,k,j,i);
+      Real n_H, tau, etau, kph;
+      s->EdgeFlux[((size_t)(k-s->ks)*n1 + (j-s->js))*n0 + (i-s->is)] = flux;
+      n_H = s->U[m].s / p->m_H;
+      tau = p->sigma_ph * n_H * s->dx[0];
+      etau = exp(-tau);
+      kph = flux * (1.0-etau) / (n_H*s->dx[1]);
+      s->ph_rate[m] += kph;
+      flux *= etau;
+      flux_frac = flux / s->flux_i;
+      if (flux_frac < MINFLUXFRAC) break;
+    }
+  }
+}
+
 /* ray sweep, dir=-1: ionradplane_3d.c:88-320 */
 static void get_ph_rate_plane(OrcSim *s)
 {
@@ -975,6 +1006,7 @@ static void get_ph_rate_plane(OrcSim *s)
   const int n0 = p->Nx[0]+1, n1 = p->Nx[1]+1;
   const int st = s->is, e = s->ie;
   int i, j, k, ii;
+  if (s->rad_dir == -2) { get_ph_rate_plane_x2(s); return; }
   for (k = s->ks; k <= s->ke; k++) for (j = s->js; j <= s->je; j++) {
     Real *ef = &s->EdgeFlux[((size_t)(k-s->ks)*n1 + (j-s->js))*n0];
     /* :264-270: the root level carries the time ramp, finer levels start from the flux their

@@ -10,7 +10,7 @@ through oracle/_ref/libref_<cfg>.so to produce function-level known-answer vecto
 
 Fixtures are DATA (arrays + the scalar trace of each run); no reference text is stored.
 
-usage: python tests/golden/make_golden.py [whole] [shk] [dev] [kernels] [ppm] [smr] [hst]
+usage: python tests/golden/make_golden.py [whole] [shk] [dev] [kernels] [ppm] [smr] [hst] [ray]
 """
 import ctypes as C
 import os
@@ -122,6 +122,22 @@ def whole_runs():
                                      ["job/num_domains=1", "job/maxout=1", "output1/out_fmt=rst",
                                       "output1/dt=1e300"], "Blast", 0, False)
             save(f"blast_{nx[0]}x{nx[1]}x{nx[2]}_n{nlim}", f, l, it, nx, [])
+
+
+def rayplane_runs():
+    """Radiation planes along -x1 ... no: dir=-1 (rays along +x1) and dir=-2 (rays along +x2) with our own problem file
+    tests/fixtures/rayplane_dir.c (a density pattern that depends on the zone indices only) linked into the reference's
+    ifront configuration.  dir=-3 is not pinned: ionradplane_3d.c:136-145 leaves cell_len uninitialised for it."""
+    deck0 = open(os.path.join(REF, "tst/ionradiation/athinput.ifront")).read()
+    tmp = tempfile.mkdtemp(prefix="golden_deck_")
+    deck = os.path.join(tmp, "athinput.rayplane")
+    open(deck, "w").write(re.sub(r"(?m)^(nradplanes\s*=.*)$", r"\1\nraydir = -1", deck0, count=1))
+    for d, nx, nlim in ((-1, (12, 10, 8), 3), (-2, (12, 10, 8), 3), (-2, (6, 70, 5), 2)):
+        f, l, it = run_reference("rayplane", deck, nx, nlim,
+                                 ["job/maxout=3", "output3/out_fmt=rst", "output3/dt=1e300", "output1/dt=1e300", "output2/dt=1e300",
+                                  f"problem/raydir={d}"], "ifront", 1, True)
+        save(f"rayplane_dir{-d}_{nx[0]}x{nx[1]}x{nx[2]}_n{nlim}", f, l, it, nx, [f"raydir={d}"])
+    shutil.rmtree(tmp)
 
 
 def shock_tubes():
@@ -379,7 +395,9 @@ def kernel_vectors():
 if __name__ == "__main__":
     if not os.path.isdir(REF) or not os.path.isdir(REFBIN):
         sys.exit("needs /root/reference and oracle/_ref (make -C oracle ref)")
-    which = sys.argv[1:] or ["whole", "shk", "dev", "kernels", "ppm", "smr", "hst"]
+    which = sys.argv[1:] or ["whole", "shk", "dev", "kernels", "ppm", "smr", "hst", "ray"]
+    if "ray" in which:
+        rayplane_runs()
     if "hst" in which:
         history_runs()
     if "whole" in which:

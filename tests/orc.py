@@ -172,6 +172,7 @@ class Sim:
     dt = property(lambda s: s.L.orc_get_dt(s.h), lambda s, v: s.L.orc_set_dt(s.h, v))
     nstep = property(lambda s: s.L.orc_get_nstep(s.h), lambda s, v: s.L.orc_set_nstep(s.h, v))
 
+    def add_radplane(self, dir, flux): self.L.orc_add_radplane(self.h, int(dir), float(flux))
     def start(self): self.L.orc_start(self.h); return self
     def step(self): return self.L.orc_step(self.h)
     def bvals(self): self.L.orc_bvals(self.h)
@@ -211,6 +212,26 @@ def make_sim(problem, overrides=None, rank=0, nranks=1, integrator="ctu", order=
     run.integrator = integrator
     run.order = order
     return Sim(aa.config.slab(run, rank, nranks)).problem()
+
+
+def rayplane_pattern(nx, n_H, m_H, cs, gamma):
+    """Initial state of tests/fixtures/rayplane_dir.c on the active zones [k][j][i][6]: gas at rest, neutral, density by a
+    fixed integer pattern of the zone indices."""
+    k, j, i = np.meshgrid(np.arange(nx[2]), np.arange(nx[1]), np.arange(nx[0]), indexing="ij")
+    rho = n_H * m_H * (0.02 + 0.09 * ((7 * i + 3 * j + 5 * k) % 11).astype(np.float64))
+    U = np.zeros(rho.shape + (6,))
+    U[..., 0] = rho; U[..., 4] = rho * cs * cs / (gamma - 1.0); U[..., 5] = rho
+    return U
+
+
+def make_rayplane_sim(nx, raydir):
+    """The oracle set up like the reference built on tests/fixtures/rayplane_dir.c: ifront deck, the pattern state, a
+    radiation plane with rays along +x1 (raydir -1) or +x2 (-2)."""
+    s = make_sim("ifront", [f"domain1/Nx{d + 1}={int(nx[d])}" for d in range(3)])
+    r = s.grid.run
+    s.active[...] = rayplane_pattern(nx, r.prob["n_H"], r.ionp["m_H"], r.prob["cs"], r.gamma)
+    s.add_radplane(raydir, r.prob["flux"])
+    return s
 
 
 class Mesh:

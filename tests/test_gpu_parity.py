@@ -190,9 +190,17 @@ def test_sod_shock_tube_golden_fixtures(aa, lib, name, strict):
     g.close()
 
 
+@pytest.fixture(params=["tile", "scan"])
+def ion_path(request, monkeypatch):
+    """AA_ION_FUSED: the radiation sub-cycle as tile sweep + separate update (ion_kernels.hip, short rays' default) /
+    as ONE kernel with the wavefront-scan sweep (ion_pass.hip, the default from 64 zones along the rays)"""
+    monkeypatch.setenv("AA_ION_FUSED", "1" if request.param == "scan" else "0")
+    return request.param
+
+
 @pytest.mark.parametrize("strict", [True, False])
-@pytest.mark.parametrize("nx,nsteps", [((16, 8, 8), 3), ((8, 12, 16), 4), ((32, 16, 16), 3)])
-def test_ifront_vs_oracle(aa, lib, nx, nsteps, strict):
+@pytest.mark.parametrize("nx,nsteps", [((16, 8, 8), 3), ((8, 12, 16), 4), ((32, 16, 16), 3), ((100, 8, 6), 3), ((192, 6, 5), 2)])
+def test_ifront_vs_oracle(aa, lib, nx, nsteps, strict, ion_path):
     """Hydro + ion radiation.  Same sub-cycle counts; fields within 1e-9 of each field's max
     (device exp/pow differ from glibc in the last bits)."""
     o, g, nv, trace = run_pair(aa, lib, "ifront", nx, nsteps, strict)
@@ -221,7 +229,7 @@ def fused_rates(request, monkeypatch):
     return request.param
 
 
-def test_ifront_golden_fixture(aa, lib, fused_rates):
+def test_ifront_golden_fixture(aa, lib, fused_rates, ion_path):
     gz = np.load(os.path.join(GOLD, "ifront_16x8x8_n6.npz"))
     o, g, nv, trace = run_pair(aa, lib, "ifront", (16, 8, 8), 6, False)
     assert [t[1] for t in trace] == [int(x) for x in gz["niter"]]
@@ -235,7 +243,7 @@ def test_ifront_golden_fixture(aa, lib, fused_rates):
 
 @pytest.mark.parametrize("strict", [True, False])
 @pytest.mark.parametrize("nx,nsteps", [((20, 20, 20), 1), ((24, 16, 12), 2), ((40, 40, 40), 2)])
-def test_ioniz_sphere_vs_oracle(aa, lib, nx, nsteps, strict, fused_rates):
+def test_ioniz_sphere_vs_oracle(aa, lib, nx, nsteps, strict, fused_rates, ion_path):
     """Hydro + static gravity (potential tables) + ion radiation + per-step core reset."""
     o, g, nv, trace = run_pair(aa, lib, "ioniz_sphere", nx, nsteps, strict)
     assert [t[0] for t in trace] == [t[1] for t in trace], trace
@@ -289,7 +297,7 @@ def test_vl_ion_problems_vs_oracle(aa, lib, problem, nx, nsteps, vl_predict):
                                                    ("blast", (7, 4, 5), "vl"), ("ifront", (4, 5, 6), "ctu"),
                                                    ("blast", (65, 4, 4), "ctu"), ("blast", (4, 4, 67), "ctu"),
                                                    ("ifront", (70, 4, 66), "ctu")])
-def test_tiny_and_awkward_grids(aa, lib, problem, nx, integrator):
+def test_tiny_and_awkward_grids(aa, lib, problem, nx, integrator, ion_path):
     """Grids as thin as nghost, sizes straddling the 64-lane / 256-thread / 32-cell tile edges."""
     strict = problem == "blast"
     o, g, nv, trace = run_pair(aa, lib, problem, nx, 2, strict, integrator)
@@ -306,7 +314,7 @@ def test_tiny_and_awkward_grids(aa, lib, problem, nx, integrator):
                                              ("dev_ioniz_sphere_32x32x32_s12_s15", True, 1e-9),
                                              ("dev_ioniz_sphere_32x32x32_s12_s15", False, 1e-3),
                                              ("dev_ifront_24x8x8_s40_s44", False, 1e-8)])
-def test_from_developed_reference_state(aa, lib, name, strict, tol):
+def test_from_developed_reference_state(aa, lib, name, strict, tol, ion_path):
     """Load a reference state deep into the run (shocks, an evolved ionization front with up to 65
     sub-cycles per step) the way a restart would, advance, compare with the reference's later state."""
     gz = np.load(os.path.join(GOLD, name + ".npz"))
@@ -339,6 +347,53 @@ def test_from_developed_reference_state(aa, lib, name, strict, tol):
             # (the strict build of the same sources matches to 1e-9, in fact bit for bit); everywhere
             # else the default build stays at rounding level
             assert (err > 1e-9).any(axis=-1).mean() < 0.005
+    g.close()
+
+
+def test_ioniz_sphere_default_kernels_vs_oracle(aa, lib):
+    """128^3, 2 steps (11 + 5 sub-cycles): the size from which every size-switched kernel is the default (k_correct_all,
+    the one-kernel sub-cycle with the scan sweep, k_vl_predict's threshold too), compared with the oracle, default
+    (fused multiply-add) build: north_star's bar is 1e-6 on density and ion fraction; asserted 1e-8."""
+    o, g, nv, trace = run_pair(aa, lib, "ioniz_sphere", (128, 128, 128), 2, False)
+    assert [t[0] for t in trace] == [t[1] for t in trace], trace
+    a = g.download()[4:-4, 4:-4, 4:-4, :nv]; b = o.active[..., :nv]
+    assert np.isfinite(a).all() and np.isfinite(b).all()
+    err = relerr(a, b)
+    assert max(err) < 1e-8, err
+    xg = 1.0 - a[..., 5] / a[..., 0]; xo = 1.0 - b[..., 5] / b[..., 0]
+    assert np.max(np.abs(xg - xo)) < 1e-8
+    ef = g.download_edgeflux()
+    assert np.allclose(ef, o.edgeflux, rtol=1e-9, atol=1e-9 * np.abs(o.edgeflux).max())
+    g.close()
+
+
+@pytest.mark.parametrize("strict", [True, False])
+@pytest.mark.parametrize("name", ["rayplane_dir1_12x10x8_n3", "rayplane_dir2_12x10x8_n3", "rayplane_dir2_6x70x5_n2"])
+def test_ray_directions_golden_fixtures(aa, lib, name, strict, ion_path):
+    """Radiation planes with rays along +x1 (dir=-1) and +x2 (dir=-2; get_ph_rate_plane case -2, ionradplane_3d.c:323-354)
+    against runs of the reference on our own problem file tests/fixtures/rayplane_dir.c.  dir=-3 and dir>0 have no
+    defined behaviour in the reference and are refused."""
+    gz = np.load(os.path.join(GOLD, name + ".npz"))
+    nx = tuple(int(x) for x in gz["nx"]); raydir = -int(name.split("_dir")[1][0])
+    ov = [f"domain1/Nx{d + 1}={nx[d]}" for d in range(3)]
+    run = aa.config.load(os.path.join(orc.DECKS, "athinput.ifront"), ov, "ifront")
+    g = lib.Grid(aa.config.slab(run), 0, strict)
+    U = g.new_host_block()
+    U[4:-4, 4:-4, 4:-4, :] = orc.rayplane_pattern(nx, run.prob["n_H"], run.ionp["m_H"], run.prob["cs"], run.gamma)
+    assert np.array_equal(U[4:-4, 4:-4, 4:-4], gz["U0"])
+    g.upload(U)
+    g.add_radplane_3d(raydir, run.prob["flux"])
+    for bad in (1, 2, 3, -3):
+        with pytest.raises(lib.AthenaError, match="defined behaviour"):
+            g.add_radplane_3d(bad, 1.0)
+    g.start()
+    niter = [g.step() for _ in range(int(gz["nstep"]))]
+    assert niter == [int(x) for x in gz["niter"]]
+    assert abs(g.time / float(gz["time"]) - 1) < 1e-10 and abs(g.dt / float(gz["dt"]) - 1) < 1e-10
+    out = g.download()[4:-4, 4:-4, 4:-4]
+    assert max(relerr(out, gz["U"])) < 1e-9, relerr(out, gz["U"])            # north_star: 1e-6
+    ef = g.download_edgeflux()
+    assert np.allclose(ef, gz["edgeflux"], rtol=1e-9, atol=1e-9 * np.abs(gz["edgeflux"]).max())
     g.close()
 
 

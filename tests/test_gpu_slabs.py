@@ -34,7 +34,10 @@ def _worker(rank, world, port, problem, overrides, nsteps, q):
 
 @pytest.mark.parametrize("correct_all", ["0", "1"])
 @pytest.mark.parametrize("problem,nx,nsteps", [("blast", (24, 16, 32), 3), ("ifront", (16, 8, 16), 3),
-                                               ("ioniz_sphere", (24, 24, 24), 2)])
+                                               ("ioniz_sphere", (24, 24, 24), 2),
+                                               # rays of 64 zones: the one-kernel sub-cycle, one all-gather of the
+                                               # slabs' reduction words per sub-cycle (driver._ion_radtransfer_fused)
+                                               ("ifront", (64, 8, 16), 3), ("ioniz_sphere", (64, 16, 16), 2)])
 def test_two_slabs_equal_one(problem, nx, nsteps, correct_all, monkeypatch):
     """correct_all: the tile kernels of the correct passes / the one marching kernel big Grids use (its
     chunks start at the slab's first plane, so the default build must not depend on where a chunk starts)"""

@@ -1,0 +1,92 @@
+"""Multi-GPU behind the C call sites: ONE Grid of the caller cut into x3 slabs inside the
+library (aa_params.nslab / AA_NGPU; csrc/slabs.hip), rehearsed with every slab on cuda:0.  The N-slab run must
+reproduce the 1-slab run BIT FOR BIT: same per-zone arithmetic, reductions that are MIN / MAX / integer sums, the
+static potential evaluated at the positions of the caller's undivided Grid.  Also the reference's own main() on the
+shim with AA_NGPU=2 (the drop-in executable, one process driving two slabs)."""
+import importlib
+import os
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, HERE)
+
+
+def _run(problem, nx, nsteps, nslab, integrator="ctu", strict=True):
+    aa = importlib.import_module("atmospheric-athena_amd")
+    lib = importlib.import_module("atmospheric-athena_amd.lib")
+    ov = [f"domain1/Nx{d + 1}={nx[d]}" for d in range(3)]
+    run = aa.config.load(os.path.join(ROOT, "atmospheric-athena_amd", "decks", "athinput." + problem), ov, problem, integrator)
+    g = lib.setup_problem(aa.config.slab(run), 0, strict, nslab=nslab)
+    g.start()
+    its = [g.step() for _ in range(nsteps)]
+    out = {"U": g.download(), "its": its, "time": g.time, "dt": g.dt, "hist": g.history()}
+    if run.ion:
+        out["ef"] = g.download_edgeflux()
+    g.close()
+    return out
+
+
+@pytest.mark.parametrize("problem,nx,nsteps,nslab,integrator", [
+    ("blast", (24, 16, 32), 3, 2, "ctu"),            # periodic: the first and the last slab are neighbours
+    ("blast", (24, 16, 33), 3, 3, "ctu"),            # remainder plane goes to the first slab (init_mesh.c:583-620)
+    ("blast", (16, 12, 20), 3, 2, "vl"),
+    ("ifront", (16, 8, 16), 3, 2, "ctu"),            # two-kernel sub-cycle (short rays)
+    ("ifront", (64, 6, 12), 3, 3, "ctu"),            # one-kernel sub-cycle, words folded over the slabs
+    ("ioniz_sphere", (24, 24, 24), 2, 2, "ctu"),     # static potential tables + pinned core zones
+    ("ioniz_sphere", (64, 20, 20), 2, 4, "ctu"),
+])
+@pytest.mark.parametrize("strict", [True, False])
+def test_slabs_inside_the_library_equal_one_grid(problem, nx, nsteps, nslab, integrator, strict):
+    """strict build (-ffp-contract=off): bit for bit.  Default build: hipcc contracts multiply-adds differently in
+    the peeled first iteration of a marching kernel's chunk than in its loop body, and where the chunks start depends
+    on the slab: rounding-level differences (asserted < 1e-13 of each field's maximum)."""
+    one = _run(problem, nx, nsteps, 1, integrator, strict)
+    many = _run(problem, nx, nsteps, nslab, integrator, strict)
+    assert many["its"] == one["its"]
+    if strict:
+        assert many["time"] == one["time"] and many["dt"] == one["dt"]
+        a, b = many["U"][4:-4, 4:-4, 4:-4], one["U"][4:-4, 4:-4, 4:-4]
+        assert np.array_equal(a, b, equal_nan=True), np.abs(a - b).max(axis=(0, 1, 2))
+        # ghost zones of the Grid's own boundary travel back to the caller too
+        assert np.array_equal(many["U"], one["U"], equal_nan=True)
+        if "ef" in one:
+            assert np.array_equal(many["ef"], one["ef"])
+    else:
+        assert abs(many["dt"] / one["dt"] - 1) < 1e-13
+        scale = np.nanmax(np.abs(one["U"]), axis=(0, 1, 2)); scale[scale == 0] = 1
+        assert (np.nanmax(np.abs(many["U"] - one["U"]), axis=(0, 1, 2)) / scale).max() < 1e-13
+        if "ef" in one:
+            assert np.allclose(many["ef"], one["ef"], rtol=1e-12, atol=1e-12 * np.abs(one["ef"]).max())
+    assert np.allclose(many["hist"], one["hist"], rtol=1e-13)      # sums over slabs: a different summation order
+
+
+def test_too_thin_slabs_are_refused():
+    aa = importlib.import_module("atmospheric-athena_amd")
+    lib = importlib.import_module("atmospheric-athena_amd.lib")
+    run = aa.config.load(os.path.join(ROOT, "atmospheric-athena_amd", "decks", "athinput.blast"),
+                         ["domain1/Nx1=16", "domain1/Nx2=16", "domain1/Nx3=12"], "blast")
+    with pytest.raises(lib.AthenaError, match="fewer than nghost"):
+        lib.setup_problem(aa.config.slab(run), 0, False, nslab=4)
+
+
+@pytest.mark.parametrize("problem,nx,nlim", [("blast", (24, 16, 20), 4), ("ioniz_sphere", (32, 32, 32), 3)])
+def test_reference_driver_with_two_slabs(problem, nx, nlim):
+    """`AA_NGPU=2 athena_<problem>_amd`: the reference's main(), init_mesh, outputs and problem file own ONE host
+    Grid; the shim's library calls cut it into two device slabs.  Restart dumps must equal the one-slab run's bit
+    for bit."""
+    from test_gpu_dropin import REFBIN, run
+    if not os.path.exists(os.path.join(REFBIN, f"athena_{problem}_amd")):
+        pytest.skip("oracle/_ref drop-in executables not built (make -C oracle ref)")
+    one, _ = run(f"athena_{problem}_amd", problem, nx, nlim)
+    two, err = run(f"athena_{problem}_amd", problem, nx, nlim, {"AA_NGPU": "2"})
+    assert "in 2 slabs" in err
+    assert two["nstep"] == one["nstep"] == nlim and abs(two["dt"] / one["dt"] - 1) < 1e-13
+    scale = np.abs(one["U"]).max(axis=(0, 1, 2)); scale[scale == 0] = 1
+    assert (np.abs(two["U"] - one["U"]).max(axis=(0, 1, 2)) / scale).max() < 1e-13       # the drop-in links the default build
+    if problem != "blast":
+        assert np.allclose(two["edgeflux"], one["edgeflux"], rtol=1e-12, atol=1e-12 * np.abs(one["edgeflux"]).max())
