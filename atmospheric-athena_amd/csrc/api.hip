@@ -118,6 +118,7 @@ int aa_create(const aa_params *p, aa_grid **out)
   const size_t nef = (size_t)(d.Nx1 + 1)*(d.Nx2 + 1)*(d.Nx3 + 1);
   size_t n = nc*(6 + 36 + 18 + 3 + 1 + 4);
   // the one-kernel sub-cycle wants whole wavefronts along the rays; AA_ION_FUSED forces either path
+  { const char *e = getenv("AA_ION_BEGIN_FUSED"); g->ion_begin_fused = e ? atoi(e) != 0 : true; }
   { const char *e = getenv("AA_ION_FUSED");
     g->ion_fused = p->ion && (p->ion_path ? p->ion_path == 1 : (e ? atoi(e) != 0 : p->Nx[0] >= 64)); }
   const size_t nrays = (size_t)d.Nx2*d.Nx3;
@@ -237,6 +238,7 @@ int aa_download_cons_planes(aa_grid *g, int k_first, int nplanes, double *dst)
 int aa_download_edgeflux_planes(aa_grid *g, int nplanes, double *dst)
 {
   if (!g->p.ion) return fail(-1, "[aa_download_edgeflux]: ion radiation is off");
+  { int rc = aa_edgeflux_ready(g); if (rc) return rc; }
   const size_t n = (size_t)(g->d.Nx1 + 1)*(g->d.Nx2 + 1)*(size_t)nplanes;
   HIPCHK(hipMemcpyAsync(dst, g->d.edgeflux, n*sizeof(Real), hipMemcpyDeviceToHost, g->st));
   HIPCHK(hipStreamSynchronize(g->st));
@@ -246,6 +248,7 @@ int aa_upload_edgeflux(aa_grid *g, const double *ef)
 {
   if (!g->slab.empty()) return slabs_upload_edgeflux(g, ef);
   if (!g->p.ion) return fail(-1, "[aa_upload_edgeflux]: ion radiation is off");
+  g->ef_stale = false;
   const size_t n = (size_t)(g->d.Nx1 + 1)*(g->d.Nx2 + 1)*(g->d.Nx3 + 1);
   HIPCHK(hipMemcpyAsync(g->d.edgeflux, ef, n*sizeof(Real), hipMemcpyHostToDevice, g->st));
   HIPCHK(hipStreamSynchronize(g->st));
@@ -255,6 +258,7 @@ int aa_download_edgeflux(aa_grid *g, double *ef)
 {
   if (!g->slab.empty()) return slabs_download_edgeflux(g, ef);
   if (!g->p.ion) return fail(-1, "[aa_download_edgeflux]: ion radiation is off");
+  { int rc = aa_edgeflux_ready(g); if (rc) return rc; }
   const size_t n = (size_t)(g->d.Nx1 + 1)*(g->d.Nx2 + 1)*(g->d.Nx3 + 1);
   HIPCHK(hipMemcpyAsync(ef, g->d.edgeflux, n*sizeof(Real), hipMemcpyDeviceToHost, g->st));
   HIPCHK(hipStreamSynchronize(g->st));
@@ -455,9 +459,16 @@ int aa_ion_begin(aa_grid *g)
 {
   if (!g->p.ion) return fail(-1, "[ion_radtransfer]: ion radiation is off");
   if (!g->slab.empty()) return slabs_ion_begin(g);
+  if (g->ion_fused) {
+    // (a sweep of the previous ion step that nobody asked for is dropped here: its buffers are about to be reused)
+    g->ion_cur = 0; g->ion_pending = false; g->ef_stale = false;
+    if (g->ion_begin_fused) { g->ion_begin_due = true; return 0; }       // rides on the first pass
+    Scope s(g, "ion_begin");
+    launch_ion_begin16(g->d, g->ion, g->st);
+    return 0;
+  }
   Scope s(g, "ion_begin");
-  if (g->ion_fused) { launch_ion_begin16(g->d, g->ion, g->st); g->ion_cur = 0; g->ion_pending = false; }
-  else launch_ion_begin(g->d, g->ion, g->st);
+  launch_ion_begin(g->d, g->ion, g->st);
   return 0;
 }
 
@@ -560,8 +571,11 @@ int aa_ion_pass(aa_grid *g, int update, int sweep, double *dev_words)
   // level); :264-271: a refined level starts every ray from the flux its parent left in EdgeFlux[..][..][0];
   // no radiation plane: flux 0 (every zone's ph_rate stays 0, as after ph_rate_init)
   const Real flux0 = (g->nradplane > 0) ? g->flux_i*(5.*(erf((g->time - 1.2e5)/8e4)+1)+0.1) : 0.0;
-  { Scope s(g, update ? (sweep ? "ion_pass" : "ion_pass_last") : "ion_pass_first");
-    launch_ion_pass(g->d, g->ion, update != 0, sweep != 0, flux0, g->level > 0 && g->nradplane > 0, g->sc, g->ion_cur,
+  const bool begin = g->ion_begin_due;
+  if (begin && update) return fail(-1, "[aa_ion_pass]: the first pass of an ion step cannot apply an update");
+  g->ion_begin_due = false;
+  { Scope s(g, update ? (sweep ? "ion_pass" : "ion_pass_last") : (begin ? "ion_pass_begin" : "ion_pass_first"));
+    launch_ion_pass(g->d, g->ion, update != 0, sweep != 0, begin, flux0, g->level > 0 && g->nradplane > 0, g->sc, g->ion_cur,
                     g->ion_part, dev_words ? dev_words : g->ion_words, g->st); }
   if (sweep) g->ion_pending = true;
   HIPCHK(hipGetLastError());
@@ -596,16 +610,27 @@ int aa_ion_fetch(aa_grid *g, double *dt, int *limit_hit, double *dt_chem, double
   return 0;
 }
 
-// GridS.EdgeFlux <- the last sweep that counted (outputs, restart dumps, ionrad_prolong_snd read it)
+// GridS.EdgeFlux <- the last sweep that counted (outputs, restart dumps, ionrad_prolong_snd read it).  Only marked here:
+// the array is filled when somebody reads it (aa_download_edgeflux, the hand-off to a refined level) -- 16 B/zone that a
+// step without output does not have to move
 int aa_ion_finish(aa_grid *g)
 {
   if (!g->ion_fused) return 0;
   if (!g->slab.empty()) return slabs_ion_finish(g);
-  Scope s(g, "ion_finish");
-  launch_ion_finish(g->d, g->ion_cur, g->st);
   g->ion_pending = false;
+  g->ef_stale = true;
   return 0;
 }
+} // extern "C"
+int aa_edgeflux_ready(aa_grid *g)
+{
+  if (!g->ef_stale) return 0;
+  { Scope s(g, "ion_finish"); launch_ion_finish(g->d, g->ion_cur, g->st); }
+  g->ef_stale = false;
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+extern "C" {
 
 static int ion_run_fused(aa_grid *g, bool fine, double limit, int *niter_out, double *dt_done_out)
 {

@@ -31,6 +31,9 @@ struct aa_grid {
   bool correct_all = false;            // the three correct passes in one kernel (k_correct_all): Grids of 2^21 zones or more, or AA_CORRECT_ALL
   bool fused_rates = false;            // rates evaluated inside the ray sweep (k_ray_sweep<true>): 2^17 rays or more, or AA_FUSED_RATES
   bool ion_fused = false;              // one-kernel radiation sub-cycle with the scan sweep (ion_pass.hip): rays of 64 zones or more, or AA_ION_FUSED
+  bool ion_begin_fused = true;         // the entry of the ion step rides on its first pass (AA_ION_BEGIN_FUSED=0: k_ion_begin16 on its own)
+  bool ion_begin_due = false;          // aa_ion_begin was called: the next first pass does the entry
+  bool ef_stale = false;               // GridS.EdgeFlux has not been filled from the last sweep yet (done when somebody reads it)
   int ion_cur = 0; bool ion_pending = false;   // buffer of the last sweep that counts; a sweep launched but not yet relied upon
   aa::IonPart *ion_part = nullptr; aa::Real *ion_words = nullptr;   // per-block records of a pass; this Grid's folded words
   int host_syncs = 0;                  // stream synchronisations that return scalars to the host (bench: per step)
@@ -93,6 +96,7 @@ int slabs_history(aa_grid *g, double *sums);
 void slabs_push_state(aa_grid *g);
 // evaluation of a StaticGravPot callback at zone centres and lower faces of a Grid (api.hip)
 void aa_eval_grav_tables(const aa_params &p, const double dx[3], int N1, int N2, int N3, aa_gravpot_fn fn, std::vector<double> t[4]);
+int aa_edgeflux_ready(aa_grid *g);    // fill GridS.EdgeFlux from the buffers of the one-kernel sub-cycle if that is still due
 extern "C" int aa_download_cons_planes(aa_grid *g, int k_first, int nplanes, double *dst);
 extern "C" int aa_download_edgeflux_planes(aa_grid *g, int nplanes, double *dst);
 

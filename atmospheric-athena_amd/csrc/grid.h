@@ -133,8 +133,9 @@ void launch_edgeflux_bc_x2(const DevGrid &g, Real flux_i, hipStream_t st);
 // ---- launch wrappers (ion_pass.hip): the one-kernel radiation sub-cycle ------------------
 int  ion_pass_blocks(const DevGrid &g);                       // launch size = number of IonPart records
 void launch_ion_begin16(const DevGrid &g, const IonPar &p, hipStream_t st);
-// update(n-1) with sc->dt_sel, then sweep(n) + rates(n) into buffer cur^1; folds the records into `words`
-void launch_ion_pass(const DevGrid &g, const IonPar &p, bool update, bool sweep, Real flux0, bool from_edgeflux,
+// [entry of the ion step: floors, save_energy_and_x, if `begin`;] update(n-1) with sc->dt_sel, then sweep(n) + rates(n)
+// into buffer cur^1; folds the records into `words`
+void launch_ion_pass(const DevGrid &g, const IonPar &p, bool update, bool sweep, bool begin, Real flux0, bool from_edgeflux,
                      const DevScalars *sc, int cur, IonPart *part, Real *words, hipStream_t st);
 void launch_ion_pick2(const Real *words, int nranks, DevScalars *sc, int first, Real dt_limit, hipStream_t st);
 void launch_ion_finish(const DevGrid &g, int cur, hipStream_t st);

@@ -21,11 +21,48 @@ AA_DEV Real rmax(Real a, Real b) { return (a > b) ? a : b; }
 AA_DEV Real rmin(Real a, Real b) { return (a < b) ? a : b; }
 AA_DEV Real sqr(Real x) { return x*x; }
 
+// ---- the default build (AA_FAST_DIV; the Makefile sets it for libathena_amd.so only).  An FP64 division is ~12
+// instructions on CDNA4, five of them quarter rate, a square root ~22, and a first-pass face costs 18 + 4 of them --
+// a third of the instructions of the VALU-bound sweeps.  Where AA_FAST_DIV is set, quotients with a positive normal
+// denominator (densities, sound speeds and their squares) become products with a reciprocal / reciprocal square root
+// refined by two Newton steps (~1 ulp), and several quotients by the same denominator share it.  Results move by a
+// few 1e-16 per operation; libathena_amd_strict.so (-ffp-contract=off, no AA_FAST_DIV) keeps the reference's
+// operations and stays bit-identical to the CPU.
+#ifndef AA_FAST_DIV
+#define AA_FAST_DIV 0
+#endif
+AA_DEV Real q_rcp(Real x)
+{
+  Real r = __builtin_amdgcn_rcp(x);
+  Real e = fma(-x, r, 1.0); r = fma(e, r, r);
+  e = fma(-x, r, 1.0); r = fma(e, r, r);
+  return r;
+}
+AA_DEV Real q_rsqrt(Real x)
+{
+  Real r = __builtin_amdgcn_rsq(x);
+  Real h = 0.5*r, e = fma(-x*r, h, 0.5);          // e = (1 - x r^2)/2
+  r = fma(r, e, r);
+  h = 0.5*r; e = fma(-x*r, h, 0.5);
+  r = fma(r, e, r);
+  return r;
+}
+// a/b for a denominator that may leave the range in which the Newton steps are safe
+AA_DEV Real q_div_checked(Real a, Real b)
+{
+  const Real ab = fabs(b);
+  return (ab > 1.0e-280 && ab < 1.0e280) ? a*q_rcp(b) : a/b;
+}
+
 // convert_var.c:389 Cons1D_to_Prim1D
 template <int NS>
 AA_DEV void cons_to_prim(const Real u[6], Real w[6], Real Gamma_1)
 {
+#if AA_FAST_DIV
+  Real di = q_rcp(u[0]);
+#else
   Real di = 1.0/u[0];
+#endif
   w[0] = u[0]; w[1] = u[1]*di; w[2] = u[2]*di; w[3] = u[3]*di;
   Real p = u[4] - 0.5*(sqr(u[1]) + sqr(u[2]) + sqr(u[3]))*di;
   p *= Gamma_1;
@@ -93,19 +130,37 @@ AA_DEV void flux_hlle(const Real ul[6], const Real ur[6], const Real wl[6], cons
 
 // rsolvers/roe.c:59 fluxes() with the H-correction etah and the HLLE fallback;
 // eigensystem rsolvers/esystem_roe.c:132
-template <int NS>
+// FAST: the AA_FAST_DIV forms; the marching kernel that solves three faces per zone (k_flux2_update) runs at its
+// register limit and is faster WITHOUT them (17.4 against 15.0 ms at 512^3)
+template <int NS, bool FAST = (AA_FAST_DIV != 0)>
 AA_DEV void flux_roe(const Real ul[6], const Real ur[6], const Real wl[6], const Real wr[6],
                      Real etah, Real Gamma, Real Gamma_1, Real f[6])
 {
-  Real sqrtdl = sqrt(wl[0]), sqrtdr = sqrt(wr[0]);
-  Real isdlpdr = 1.0/(sqrtdl + sqrtdr);
-  Real v1 = (sqrtdl*wl[1] + sqrtdr*wr[1])*isdlpdr;
-  Real v2 = (sqrtdl*wl[2] + sqrtdr*wr[2])*isdlpdr;
-  Real v3 = (sqrtdl*wl[3] + sqrtdr*wr[3])*isdlpdr;
-  Real h  = ((ul[4] + wl[4] + 0.0)/sqrtdl + (ur[4] + wr[4] + 0.0)/sqrtdr)*isdlpdr;
-  Real vsq = v1*v1 + v2*v2 + v3*v3;
-  Real asq = Gamma_1*rmax((h - 0.5*vsq), AA_TINY);
-  Real a = sqrt(asq);
+  Real sqrtdl, sqrtdr, isdlpdr, v1, v2, v3, h, vsq, asq, a, iasq = 0.0;
+  if (FAST) {
+  const Real isl = q_rsqrt(wl[0]), isr = q_rsqrt(wr[0]);
+    sqrtdl = wl[0]*isl; sqrtdr = wr[0]*isr;
+    isdlpdr = q_rcp(sqrtdl + sqrtdr);
+    v1 = (sqrtdl*wl[1] + sqrtdr*wr[1])*isdlpdr;
+    v2 = (sqrtdl*wl[2] + sqrtdr*wr[2])*isdlpdr;
+    v3 = (sqrtdl*wl[3] + sqrtdr*wr[3])*isdlpdr;
+    h  = ((ul[4] + wl[4] + 0.0)*isl + (ur[4] + wr[4] + 0.0)*isr)*isdlpdr;
+    vsq = v1*v1 + v2*v2 + v3*v3;
+    asq = Gamma_1*rmax((h - 0.5*vsq), AA_TINY);
+    const Real ia = q_rsqrt(asq);
+    iasq = ia*ia;
+    a = asq*ia;
+  } else {
+    sqrtdl = sqrt(wl[0]); sqrtdr = sqrt(wr[0]);
+    isdlpdr = 1.0/(sqrtdl + sqrtdr);
+    v1 = (sqrtdl*wl[1] + sqrtdr*wr[1])*isdlpdr;
+    v2 = (sqrtdl*wl[2] + sqrtdr*wr[2])*isdlpdr;
+    v3 = (sqrtdl*wl[3] + sqrtdr*wr[3])*isdlpdr;
+    h  = ((ul[4] + wl[4] + 0.0)/sqrtdl + (ur[4] + wr[4] + 0.0)/sqrtdr)*isdlpdr;
+    vsq = v1*v1 + v2*v2 + v3*v3;
+    asq = Gamma_1*rmax((h - 0.5*vsq), AA_TINY);
+    a = sqrt(asq);
+  }
   Real ev0 = v1 - a, ev4 = v1 + a;
 
   Real Fl[6], Fr[6];
@@ -130,13 +185,13 @@ AA_DEV void flux_roe(const Real ul[6], const Real ur[6], const Real wl[6], const
     return;
   }
 
-  Real na = 0.5/asq;
+  Real na = FAST ? 0.5*iasq : 0.5/asq;
   Real l00 = na*(0.5*Gamma_1*vsq + v1*a);
   Real l01 = -na*(Gamma_1*v1 + a);
   Real l02 = -na*Gamma_1*v2;
   Real l03 = -na*Gamma_1*v3;
   Real l04 = na*Gamma_1;
-  Real qa = Gamma_1/asq;
+  Real qa = FAST ? Gamma_1*iasq : Gamma_1/asq;
   Real l30 = 1.0 - na*Gamma_1*vsq;
   Real l31 = qa*v1, l32 = qa*v2, l33 = qa*v3, l34 = -qa;
   Real l40 = na*(0.5*Gamma_1*vsq - v1*a);
@@ -157,7 +212,10 @@ AA_DEV void flux_roe(const Real ul[6], const Real ur[6], const Real wl[6], const
   u0 += aa_[0]; u1 += aa_[0]*(v1 - a); u2 += aa_[0]*v2; u3 += aa_[0]*v3; u4 += aa_[0]*(h - v1*a);
   if (v1 > ev0) {
     if (u0 <= 0.0) hlle = true;
-    else { Real p_inter = u4 - 0.5*(sqr(u1) + sqr(u2) + sqr(u3))/u0; if (p_inter < 0.0) hlle = true; }
+    else {
+      Real p_inter = FAST ? u4 - q_div_checked(0.5*(sqr(u1) + sqr(u2) + sqr(u3)), u0) : u4 - 0.5*(sqr(u1) + sqr(u2) + sqr(u3))/u0;
+      if (p_inter < 0.0) hlle = true;
+    }
   }
   if (!hlle) {
     u2 += aa_[1]; u4 += aa_[1]*v2;
@@ -165,7 +223,10 @@ AA_DEV void flux_roe(const Real ul[6], const Real ur[6], const Real wl[6], const
     u0 += aa_[3]; u1 += aa_[3]*v1; u2 += aa_[3]*v2; u3 += aa_[3]*v3; u4 += aa_[3]*(0.5*vsq);
     if (ev4 > v1) {
       if (u0 <= 0.0) hlle = true;
-      else { Real p_inter = u4 - 0.5*(sqr(u1) + sqr(u2) + sqr(u3))/u0; if (p_inter < 0.0) hlle = true; }
+      else {
+      Real p_inter = FAST ? u4 - q_div_checked(0.5*(sqr(u1) + sqr(u2) + sqr(u3)), u0) : u4 - 0.5*(sqr(u1) + sqr(u2) + sqr(u3))/u0;
+      if (p_inter < 0.0) hlle = true;
+    }
     }
   }
   if (hlle) { flux_hlle<NS>(ul, ur, wl, wr, Gamma, Gamma_1, f); return; }
@@ -195,16 +256,32 @@ AA_DEV void plm_cell(const Real wm[6], const Real w[6], const Real wp[6], Real d
 {
   constexpr int NV = 5 + NS;
   Real d = w[0], vx = w[1];
+#if AA_FAST_DIV
+  const Real id = q_rcp(d);
+  Real asq = (Gamma*w[4])*id;
+  const Real ia = q_rsqrt(asq), iasq = ia*ia;
+  Real a = asq*ia;
+  Real ev0 = vx - a, ev4 = vx + a;
+  Real r10 = -a*id, r14 = -r10;
+  Real l01 = -0.5*d*ia, l04 = 0.5*iasq, l14 = -iasq, l41 = -l01;
+#else
   Real asq = (Gamma*w[4])/d, a = sqrt(asq);
   Real ev0 = vx - a, ev4 = vx + a;
   Real r10 = -a/d, r14 = -r10;
   Real l01 = -0.5*d/a, l04 = 0.5/asq, l14 = -1.0/asq, l41 = -l01;
+#endif
 
   Real dWc[6], dWl[6], dWr[6], dWg[6];
 #pragma unroll
   for (int n = 0; n < NV; n++) {
     dWc[n] = wp[n] - wm[n]; dWl[n] = w[n] - wm[n]; dWr[n] = wp[n] - w[n];
+#if AA_FAST_DIV
+    // (where the product is positive the sum is a normal number: two operands small enough for a subnormal sum have
+    //  a product that underflows to zero)
+    dWg[n] = (dWl[n]*dWr[n] > 0.0) ? 2.0*dWl[n]*dWr[n]*q_rcp(dWl[n] + dWr[n]) : 0.0;
+#else
     dWg[n] = (dWl[n]*dWr[n] > 0.0) ? 2.0*dWl[n]*dWr[n]/(dWl[n] + dWr[n]) : 0.0;
+#endif
   }
   Real dac[6], dal[6], dar[6], dag[6];
 #define AA_PROJ(o, x) { o[0] = l01*x[1]; o[0] += l04*x[4]; o[1] = x[0]; o[1] += l14*x[4]; \

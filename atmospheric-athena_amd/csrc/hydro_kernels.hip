@@ -223,7 +223,7 @@ AA_DEV bool decode_zone(const Order o, int ni, int nj, int nk, int &i, int &j, i
 // One thread owns one (i, transverse) column and a chunk of `chunk` interfaces; lanes are
 // consecutive in i.  Cells reconstructed: l..u = s-2..e+2; interfaces l+1..u (:179-184).
 template <int NS, int D, bool GRAV, int MODE, int ORD>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, 3)      // 3 waves per SIMD (168 VGPRs): the kernel is VALU-bound and sits right at that edge
 k_sweep_march(DevGrid g, const Real *src, Real dt, int chunk)
 {
   static_assert(D == 1 || D == 2, "march kernel is for the strided directions");
@@ -426,7 +426,11 @@ AA_DEV void load_prim3(const DevGrid &g, long m, Real w[6], Real &p0, Real &p1)
 #pragma unroll
   for (int v = 0; v < 5 + NS; v++) u[v] = Uf(g, v)[m];
   if (!NS) u[5] = 0.0;
+#if AA_FAST_DIV
+  const Real di = q_rcp(u[0]);          // as cons_to_prim: the same bits whichever kernel converts the zone
+#else
   const Real di = 1.0/u[0];
+#endif
   w[0] = u[0]; w[1] = u[1]*di; w[2] = u[2]*di; w[3] = u[3]*di;
   Real pa = u[4] - 0.5*(sqr(u[1]) + sqr(u[2]) + sqr(u[3]))*di;
   Real pb = u[4] - 0.5*(sqr(u[2]) + sqr(u[3]) + sqr(u[1]))*di;
@@ -723,7 +727,7 @@ AA_DEV void face_solve(const DevGrid &g, const FaceIn &in, Real f[6])
   Real wl[6], wr[6];
   cons_to_prim<NS>(in.ul, wl, g.Gamma_1);
   cons_to_prim<NS>(in.ur, wr, g.Gamma_1);
-  flux_roe<NS>(in.ul, in.ur, wl, wr, etah, g.Gamma, g.Gamma_1, f);
+  flux_roe<NS, false>(in.ul, in.ur, wl, wr, etah, g.Gamma, g.Gamma_1, f);      // (see flux_roe: faster without the AA_FAST_DIV forms here)
 }
 template <int NS, int D>
 AA_DEV void face_flux2(const DevGrid &g, long m, Real f[6])

@@ -279,7 +279,9 @@ struct Ops { Real d, ke, E, s, fp, e0, x0, vm; unsigned short sg; };
 #ifndef AA_ION_PASS_WAVES
 #define AA_ION_PASS_WAVES 3          /* waves per SIMD the register budget is cut for */
 #endif
-template <bool UPD, bool SWP>
+// BEG: the first pass of an ion step also does the step's entry -- floors, save_energy_and_x, the frozen kinetic
+// energy and max|v| (ionrad_3d.c:896-905; k_ion_begin16's arithmetic, bit for bit) -- on the zones it reads anyway
+template <bool UPD, bool SWP, bool BEG>
 __global__ void __launch_bounds__(256, AA_ION_PASS_WAVES)
 k_ion_pass(DevGrid g, IonPar p_arg, Real flux0, int from_edgeflux, const DevScalars *sc, int cur, IonPart *part)
 {
@@ -318,9 +320,10 @@ k_ion_pass(DevGrid g, IonPar p_arg, Real flux0, int from_edgeflux, const DevScal
     // lanes past the end of the row take part in the shuffles with harmless operands
     o.d = 1.0; o.ke = 0.0; o.E = 1.0; o.s = 1.0; o.fp = 0.0; o.e0 = 1.0; o.x0 = 0.5; o.vm = 0.0; o.sg = 1;
     if (in_) {
-      o.d = Uq(g,0)[m_]; o.ke = g.kin[m_]; o.E = Uq(g,4)[m_]; o.s = Uq(g,5)[m_];
+      o.d = Uq(g,0)[m_]; o.E = Uq(g,4)[m_]; o.s = Uq(g,5)[m_];
+      if (BEG) { o.fp = Uq(g,1)[m_]; o.e0 = Uq(g,2)[m_]; o.x0 = Uq(g,3)[m_]; }      // the momenta, in the slots UPD would use
+      else { o.ke = g.kin[m_]; o.sg = g.sg16[m_]; }
       if (UPD) { o.fp = fprev[m_]; o.e0 = g.e_init[m_]; o.x0 = g.x_init[m_]; o.vm = g.vmax[m_]; }
-      o.sg = g.sg16[m_];
     }
   };
 
@@ -357,8 +360,24 @@ k_ion_pass(DevGrid g, IonPar p_arg, Real flux0, int from_edgeflux, const DevScal
     }
     Cell c; c.d = o.d; c.ke = o.ke; c.E = o.E; c.s = o.s;
     const Real E0 = c.E, s0 = c.s;
-    const Real di = frcp_n(c.d);
     int2 sg = sg_unpack(o.sg);
+    bool sg_new = false;
+    if (BEG) {
+      PAR_HERE(p);
+      const Real M1 = o.fp, M2 = o.e0, M3 = o.x0, die = 1.0/c.d;
+      c.ke = 0.5 * (M1*M1 + M2*M2 + M3*M3) * die;
+      IonQ qb; bool floored;
+      floors(c, p, g.Gamma_1, qb, floored);
+      if (floored) qb = ion_q(c, p, g.Gamma_1);
+      if (in) {
+        if (c.E != E0) Uq(g,4)[m] = c.E;
+        if (c.s != s0) Uq(g,5)[m] = c.s;
+        g.e_init[m] = c.E; g.x_init[m] = qb.x; g.kin[m] = c.ke;
+        g.vmax[m] = rmax(rmax(fabs(M1*die), fabs(M2*die)), fabs(M3*die));
+      }
+      sg = make_int2(0, 0); sg_new = true;
+    }
+    const Real di = frcp_n(c.d);
     IonQ q; Therm th;
     { PAR_HERE(p); q = zone_q(c, di, p, g.Gamma_1); th = zone_therm(q, p.sigma_ph * q.n_H * dx1, p); }
     if (UPD) {
@@ -409,7 +428,7 @@ k_ion_pass(DevGrid g, IonPar p_arg, Real flux0, int from_edgeflux, const DevScal
         dt_chem_min = rmin(dt_chem_min, dtc);
         dt_therm_min = rmin(dt_therm_min, dtt);
         fnext[m] = fin;
-        if (sg.x != sg0.x || sg.y != sg0.y) g.sg16[m] = sg_pack(sg);
+        if (sg_new || sg.x != sg0.x || sg.y != sg0.y) g.sg16[m] = sg_pack(sg);
       }
       if (t == ntile - 1 && lane == 0) g.raylast[(long)(cur ^ 1)*nrays + ray] = dead ? 0.0 : carry;   // :308
     }
@@ -572,15 +591,16 @@ int ion_pass_blocks(const DevGrid &g)
 void launch_ion_begin16(const DevGrid &g, const IonPar &p, hipStream_t st)
 { const long n = (long)g.Nx1*g.Nx2*g.Nx3; hipLaunchKernelGGL(k_ion_begin16, dim3(nblk(n, 256)), dim3(256), 0, st, g, p); }
 
-void launch_ion_pass(const DevGrid &g, const IonPar &p, bool update, bool sweep, Real flux0, bool from_edgeflux,
+void launch_ion_pass(const DevGrid &g, const IonPar &p, bool update, bool sweep, bool begin, Real flux0, bool from_edgeflux,
                      const DevScalars *sc, int cur, IonPart *part, Real *words, hipStream_t st)
 {
   const int nb = ion_pass_blocks(g);
   const dim3 grid(nb), blk(256);
   const int fe = from_edgeflux ? 1 : 0;
-  if (update && sweep) hipLaunchKernelGGL((k_ion_pass<true, true>), grid, blk, 0, st, g, p, flux0, fe, sc, cur, part);
-  else if (sweep)      hipLaunchKernelGGL((k_ion_pass<false, true>), grid, blk, 0, st, g, p, flux0, fe, sc, cur, part);
-  else                 hipLaunchKernelGGL((k_ion_pass<true, false>), grid, blk, 0, st, g, p, flux0, fe, sc, cur, part);
+  if (update && sweep) hipLaunchKernelGGL((k_ion_pass<true, true, false>), grid, blk, 0, st, g, p, flux0, fe, sc, cur, part);
+  else if (sweep && begin) hipLaunchKernelGGL((k_ion_pass<false, true, true>), grid, blk, 0, st, g, p, flux0, fe, sc, cur, part);
+  else if (sweep)      hipLaunchKernelGGL((k_ion_pass<false, true, false>), grid, blk, 0, st, g, p, flux0, fe, sc, cur, part);
+  else                 hipLaunchKernelGGL((k_ion_pass<true, false, false>), grid, blk, 0, st, g, p, flux0, fe, sc, cur, part);
   hipLaunchKernelGGL(k_ion_reduce, dim3(1), dim3(256), 0, st, part, nb, words);
 }
 void launch_ion_pick2(const Real *words, int nranks, DevScalars *sc, int first, Real dt_limit, hipStream_t st)

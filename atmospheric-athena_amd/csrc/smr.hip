@@ -480,6 +480,7 @@ int aa_mesh_ionflux_prolong(aa_mesh *m, int l)
 {
   if (l < 1 || l >= m->nl) return aa_fail(-1, "[aa_mesh_ionflux_prolong]: level %d", l);
   const Link &L = m->link[l - 1];
+  { int rc = aa_edgeflux_ready(m->lev[l - 1]); if (rc) return rc; }       // the parent's EdgeFlux of its last sweep
   if (L.prol[0])
     hipLaunchKernelGGL(k_ionflux_prolong, dim3(nblk((long)(L.n[1] + 1)*(L.n[2] + 1), 256)), dim3(256), 0, m->st,
                        m->lev[l]->d, m->lev[l - 1]->d, L);

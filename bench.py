@@ -91,11 +91,13 @@ KERNEL_BYTES = {
     # E, s0, incoming flux out; 2-byte sign word in + out
     "ion_pass": 8 * (7 + 3) + 4,
     "ion_pass_first": 8 * (4 + 1) + 4, "ion_pass_last": 8 * (7 + 2) + 2,
+    "ion_pass_begin": 8 * (6 + 4 + 1) + 2,      # the entry of the ion step on the first pass: U in; ke, max|v|, e_init, x_init, incoming flux, sign word out
     "ion_begin": 8 * (6 + 6), "ion_finish": 8 * 2,
     "bvals_mhd": 0, "new_dt": 8 * 5, "pinned_cells": 0, "ppm_slopes": 3 * 8 * (6 + 6),
 }
 HYDRO_KERNELS = ("sweep_", "sweep_correct_x1", "correct_", "flux2_", "update", "vl_", "ppm_slopes")
-SUBCYCLE_KERNELS = ("ray_sweep", "ray_sweep_rates", "ion_rates", "ion_update", "ion_pass", "ion_pass_first", "ion_pass_last", "ion_pick")
+SUBCYCLE_KERNELS = ("ray_sweep", "ray_sweep_rates", "ion_rates", "ion_update", "ion_pass", "ion_pass_first", "ion_pass_last", "ion_pass_begin",
+                    "ion_pick")
 
 
 def kernel_class(name):
@@ -492,7 +494,15 @@ def main():
                 ms_sub = cls["subcycle"] * a.steps / nsub_tot
                 a_s = 64 * zones_gpu / (ms_sub * 1e-3) / 1e9
                 ph["subcycle"] = {"ms_per_subcycle": ms_sub, "bytes_per_cell": 64, "achieved_GBs": a_s, "frac_hbm": a_s / HBM_PEAK_GBS,
-                                  "ns_per_zone": 1e6 * ms_sub / zones_gpu, "subcycles_timed": nsub_tot}
+                                  "ns_per_zone": 1e6 * ms_sub / zones_gpu, "subcycles_timed": nsub_tot,
+                                  "note": "all kernels of the ion step's loop / sub-cycles timed; with ONE sub-cycle per step that is the first pass "
+                                          "(which also does the step's entry: floors, save_energy_and_x) plus the closing update-only pass"}
+                if prof.get("ion_pass", (0, 0))[1] > 0 and nsub > 1.5:
+                    # the repeating unit of a long loop: one full pass = update(n-1) + sweep(n) + rates(n)
+                    ms_full = prof["ion_pass"][0] / prof["ion_pass"][1]
+                    a_f = 64 * zones_gpu / (ms_full * 1e-3) / 1e9
+                    ph["subcycle"]["full_pass_ms"] = ms_full
+                    ph["subcycle"]["full_pass_frac_hbm"] = a_f / HBM_PEAK_GBS
             ph["ion_step_overhead_ms"] = cls["ion_step"]
             ph["other_ms"] = cls["other"]
             ph["unattributed_ms"] = 1e3 * elapsed / a.steps - sum(cls.values())

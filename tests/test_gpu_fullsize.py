@@ -95,7 +95,8 @@ def test_ioniz_sphere_512_ray_and_state_properties():
             assert np.max(np.abs(U[..., c] - F[..., c])) <= 1e-9 * np.max(np.abs(U[..., c]))
 
 
-def test_smr_256_conservation_across_levels():
+@pytest.mark.parametrize("strict", [True, False])
+def test_smr_256_conservation_across_levels(strict):
     """2-level blast, root 256^3 periodic + level 1 256^3 over the central half, blast sphere straddling
     the fine/coarse boundary.  The flux correction (smr.c:1277-1340) makes the composite update
     conservative: the root-level sums of mass, momentum and energy (the parent zones under the child
@@ -109,7 +110,7 @@ def test_smr_256_conservation_across_levels():
           + [f"domain2/{k}Disp={n // 2}" for k in "ijk"] + ["domain1/x2min=-0.5", "domain1/x2max=0.5", "problem/radius=0.27"])
     par = aa.athinput.ParTable.from_file(os.path.join(DECKS, "athinput.blast")).cmdline(ov)
     run = aa.config.from_par(par, "blast")
-    m = lib.Mesh(aa.config.levels(par, run), 0, False).start()
+    m = lib.Mesh(aa.config.levels(par, run), 0, strict).start()
     U0 = m.lev[0].download()[4:-4, 4:-4, 4:-4]
     tot0 = U0.sum(axis=(0, 1, 2), dtype=np.longdouble)
     for _ in range(4):
@@ -133,7 +134,11 @@ def test_smr_256_conservation_across_levels():
     s = s + (((R[:, 1, :, 0, :, 0] + R[:, 1, :, 0, :, 1]) + R[:, 1, :, 1, :, 0]) + R[:, 1, :, 1, :, 1])
     assert np.array_equal(s * 0.125, U[q:3 * q, q:3 * q, q:3 * q])
     # mirror symmetry of the composite solution on both levels
+    # (rounding is not mirror-symmetric -- a*b + c*d contracts to fma(a, b, c*d) -- and a limiter / Roe-HLLE decision
+    #  on a knife edge then falls differently in a zone and its mirror image: 1e-11 with the reference's operations,
+    #  1e-9 for the default build)
+    tol = 1e-11 if strict else 1e-9
     for A in (U, F):
-        assert np.allclose(A[..., 0], A[::-1, :, :, 0], rtol=1e-11, atol=0)
-        assert np.allclose(A[..., 0], A[:, ::-1, :, 0], rtol=1e-11, atol=0)
+        assert np.allclose(A[..., 0], A[::-1, :, :, 0], rtol=tol, atol=0)
+        assert np.allclose(A[..., 0], A[:, ::-1, :, 0], rtol=tol, atol=0)
         assert np.allclose(A[..., 1], -A[:, :, ::-1, 1], rtol=1e-9, atol=1e-12)

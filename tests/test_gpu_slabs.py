@@ -68,8 +68,10 @@ def test_two_slabs_equal_one(problem, nx, nsteps, correct_all, monkeypatch):
         if problem == "ioniz_sphere":
             # cc_pos of the upper slab accumulates MinX (init_grid.c:109-110): positions, hence the
             # potential tables, may differ in the last bit -- the reference has the same property
-            scale = np.abs(U1).max(axis=(0, 1, 2))
-            assert (np.abs(U - U1[disp:disp + n3]).max(axis=(0, 1, 2)) / scale).max() < 1e-9
+            # (a planet a few zones across: the reference itself produces NaN zones there; they must be the same zones)
+            assert np.array_equal(np.isnan(U), np.isnan(U1[disp:disp + n3]))
+            scale = np.nanmax(np.abs(U1), axis=(0, 1, 2))
+            assert (np.nanmax(np.abs(U - U1[disp:disp + n3]), axis=(0, 1, 2)) / scale).max() < 1e-9
         else:
             assert np.array_equal(U, U1[disp:disp + n3]), f"slab {rank}"
     one.eng.close()
