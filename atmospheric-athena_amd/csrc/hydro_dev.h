@@ -31,6 +31,20 @@ AA_DEV Real sqr(Real x) { return x*x; }
 #ifndef AA_FAST_DIV
 #define AA_FAST_DIV 0
 #endif
+#ifndef AA_FD_C2P
+#define AA_FD_C2P AA_FAST_DIV
+#endif
+#ifndef AA_FD_PLM
+#define AA_FD_PLM AA_FAST_DIV
+#endif
+// The Riemann solver keeps the reference's operations in every build: its switch to HLLE (negative density or pressure of
+// an intermediate state, roe.c:256-286) is the one DISCONTINUOUS decision of the hydro step, and symmetric flows sit
+// exactly on it -- with the reciprocal forms in flux_roe a 3-level blast differed from the reference by 2.6e-3 in 116
+// zones after two steps (one flipped switch; 5e-16 without them).  Reconstruction and the variable conversion are
+// continuous in their inputs: there a changed last bit stays a changed last bit.
+#ifndef AA_FD_ROE
+#define AA_FD_ROE 0
+#endif
 AA_DEV Real q_rcp(Real x)
 {
   Real r = __builtin_amdgcn_rcp(x);
@@ -58,7 +72,7 @@ AA_DEV Real q_div_checked(Real a, Real b)
 template <int NS>
 AA_DEV void cons_to_prim(const Real u[6], Real w[6], Real Gamma_1)
 {
-#if AA_FAST_DIV
+#if AA_FD_C2P
   Real di = q_rcp(u[0]);
 #else
   Real di = 1.0/u[0];
@@ -130,9 +144,8 @@ AA_DEV void flux_hlle(const Real ul[6], const Real ur[6], const Real wl[6], cons
 
 // rsolvers/roe.c:59 fluxes() with the H-correction etah and the HLLE fallback;
 // eigensystem rsolvers/esystem_roe.c:132
-// FAST: the AA_FAST_DIV forms; the marching kernel that solves three faces per zone (k_flux2_update) runs at its
-// register limit and is faster WITHOUT them (17.4 against 15.0 ms at 512^3)
-template <int NS, bool FAST = (AA_FAST_DIV != 0)>
+// FAST: the reciprocal forms (AA_FD_ROE, off: see above; k_flux2_update, at its register limit, was also slower with them)
+template <int NS, bool FAST = (AA_FD_ROE != 0)>
 AA_DEV void flux_roe(const Real ul[6], const Real ur[6], const Real wl[6], const Real wr[6],
                      Real etah, Real Gamma, Real Gamma_1, Real f[6])
 {
@@ -256,7 +269,7 @@ AA_DEV void plm_cell(const Real wm[6], const Real w[6], const Real wp[6], Real d
 {
   constexpr int NV = 5 + NS;
   Real d = w[0], vx = w[1];
-#if AA_FAST_DIV
+#if AA_FD_PLM
   const Real id = q_rcp(d);
   Real asq = (Gamma*w[4])*id;
   const Real ia = q_rsqrt(asq), iasq = ia*ia;
@@ -275,7 +288,7 @@ AA_DEV void plm_cell(const Real wm[6], const Real w[6], const Real wp[6], Real d
 #pragma unroll
   for (int n = 0; n < NV; n++) {
     dWc[n] = wp[n] - wm[n]; dWl[n] = w[n] - wm[n]; dWr[n] = wp[n] - w[n];
-#if AA_FAST_DIV
+#if AA_FD_PLM
     // (where the product is positive the sum is a normal number: two operands small enough for a subnormal sum have
     //  a product that underflows to zero)
     dWg[n] = (dWl[n]*dWr[n] > 0.0) ? 2.0*dWl[n]*dWr[n]*q_rcp(dWl[n] + dWr[n]) : 0.0;

@@ -426,7 +426,7 @@ AA_DEV void load_prim3(const DevGrid &g, long m, Real w[6], Real &p0, Real &p1)
 #pragma unroll
   for (int v = 0; v < 5 + NS; v++) u[v] = Uf(g, v)[m];
   if (!NS) u[5] = 0.0;
-#if AA_FAST_DIV
+#if AA_FD_C2P
   const Real di = q_rcp(u[0]);          // as cons_to_prim: the same bits whichever kernel converts the zone
 #else
   const Real di = 1.0/u[0];

@@ -26,6 +26,10 @@
 // counted (k_ion_finish).  ph_rate is not stored at all: the update re-derives it from the stored incoming
 // flux and the zone's own neutral density (one more exp per zone instead of 16 B of traffic).
 //
+// Tried and dropped here: the per-zone logic without divergent branches (selects for the sign cases of the rates, product
+// tests for check_range's quotients): 602 instead of 562 vector instructions per zone and 3.37 instead of 3.02 ms per
+// pass -- the selects cost more than the skipped branches, and the extra lane masks spill scalar registers to scratch.
+//
 // Multiplication order: the reference multiplies the flux zone by zone; the scan multiplies in a tree
 // (differences ~1e-16, below those of device exp vs glibc exp, which no implementation can avoid).  The
 // tile kernel of ion_kernels.hip keeps the serial order and remains the path for short rays (Nx1 < 64).
@@ -283,8 +287,11 @@ struct Ops { Real d, ke, E, s, fp, e0, x0, vm; unsigned short sg; };
 // energy and max|v| (ionrad_3d.c:896-905; k_ion_begin16's arithmetic, bit for bit) -- on the zones it reads anyway
 template <bool UPD, bool SWP, bool BEG>
 __global__ void __launch_bounds__(256, AA_ION_PASS_WAVES)
-k_ion_pass(DevGrid g, IonPar p_arg, Real flux0, int from_edgeflux, const DevScalars *sc, int cur, IonPart *part)
+k_ion_pass(DevGrid g, IonPar p_arg, Real flux0, int from_edgeflux, const DevScalars *sc, int cur, IonPart *part, int only_if_hit)
 {
+  // an updating pass is launched in both forms -- with and without the sweep of a further sub-cycle -- and the one
+  // that does not match what the device picked (sc->limit_hit; the host has not read it yet) leaves at once
+  if (UPD && only_if_hit >= 0 && (sc->limit_hit != 0) != (only_if_hit != 0)) return;
   // ~35 FP64 parameters on top of a dozen field pointers do not fit the 102 scalar registers of a wave (the first
   // build spilled 58 of them, partly to scratch): the parameter block lives in LDS and is re-read per tile through a
   // pointer the compiler cannot see through, i.e. as short-lived vector registers next to their uses
@@ -597,10 +604,13 @@ void launch_ion_pass(const DevGrid &g, const IonPar &p, bool update, bool sweep,
   const int nb = ion_pass_blocks(g);
   const dim3 grid(nb), blk(256);
   const int fe = from_edgeflux ? 1 : 0;
-  if (update && sweep) hipLaunchKernelGGL((k_ion_pass<true, true, false>), grid, blk, 0, st, g, p, flux0, fe, sc, cur, part);
-  else if (sweep && begin) hipLaunchKernelGGL((k_ion_pass<false, true, true>), grid, blk, 0, st, g, p, flux0, fe, sc, cur, part);
-  else if (sweep)      hipLaunchKernelGGL((k_ion_pass<false, true, false>), grid, blk, 0, st, g, p, flux0, fe, sc, cur, part);
-  else                 hipLaunchKernelGGL((k_ion_pass<true, false, false>), grid, blk, 0, st, g, p, flux0, fe, sc, cur, part);
+  if (update && sweep) {
+    hipLaunchKernelGGL((k_ion_pass<true, true, false>), grid, blk, 0, st, g, p, flux0, fe, sc, cur, part, 0);
+    hipLaunchKernelGGL((k_ion_pass<true, false, false>), grid, blk, 0, st, g, p, flux0, fe, sc, cur, part, 1);
+  }
+  else if (sweep && begin) hipLaunchKernelGGL((k_ion_pass<false, true, true>), grid, blk, 0, st, g, p, flux0, fe, sc, cur, part, -1);
+  else if (sweep)      hipLaunchKernelGGL((k_ion_pass<false, true, false>), grid, blk, 0, st, g, p, flux0, fe, sc, cur, part, -1);
+  else                 hipLaunchKernelGGL((k_ion_pass<true, false, false>), grid, blk, 0, st, g, p, flux0, fe, sc, cur, part, -1);
   hipLaunchKernelGGL(k_ion_reduce, dim3(1), dim3(256), 0, st, part, nb, words);
 }
 void launch_ion_pick2(const Real *words, int nranks, DevScalars *sc, int first, Real dt_limit, hipStream_t st)

@@ -8,7 +8,16 @@
  * Prolongate and ionradRestrictCorrect (smr.c) on top of aa_mesh_*.
  *
  * Host/device coherence (the reference's problem files and outputs index pG->U on the host):
- *   AA_COHERENCE=step  (default) the host block is refreshed after Integrate() (so that
+ *   AA_COHERENCE=auto  (default) the first two steps run as `step` below while the zones Userwork_in_loop writes are
+ *                      recorded; if both steps wrote the same values into the same zones (prob/ioniz_sphere.c:255-306
+ *                      does; a problem without Userwork trivially does) they are re-imposed on the device from then on
+ *                      (aa_apply_pinned_cells) and the host block is refreshed only when main() is about to read it:
+ *                      when an <outputN> block is due at the next data_output (its schedule, output.c:205-208 and
+ *                      :507-522, is mirrored from the same par table), when the loop is about to end (tlim / nlim:
+ *                      the forced final output, main.c:743) and after SIGTERM (ath_signal.c).  Otherwise `step`.
+ *                      Not seen: outputs enrolled by the problem file itself at run time, and reads of pG->U by
+ *                      problem-file code other than Userwork_in_loop's writes -- use `step` for those.
+ *   AA_COHERENCE=step  the host block is refreshed after Integrate() (so that
  *                      Userwork_in_loop sees and may edit it; re-uploaded before new_dt) and
  *                      after the end-of-step bvals_mhd (so data_output sees ghost zones too).
  *                      Always correct; costs three PCIe transfers of U per step.
@@ -19,6 +28,7 @@
  *                      values every step, as prob/ioniz_sphere.c:255-306 does.
  */
 #include <math.h>
+#include <signal.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -30,6 +40,9 @@ extern Real CourNo, Gamma, Gamma_1;
 extern GravPotFun_t StaticGravPot;
 extern CoolingFun_t CoolingFunc;
 extern double par_getd(char *block, char *name);
+extern double par_getd_def(char *block, char *name, double def);
+extern int par_geti_def(char *block, char *name, int def);
+extern int par_exist(char *block, char *name);
 extern void ath_error(char *fmt, ...);
 
 #define MAXLEV 8
@@ -42,6 +55,15 @@ static aa_mesh *MM = NULL;
 #endif
 static int host_newer[MAXLEV];      /* the host block of this level holds data the device has not seen */
 static int learn = 0, learned = 0, sync_every = 1;
+/* AA_COHERENCE=auto: the write set of Userwork_in_loop must repeat before it is trusted; the output schedule */
+static int automode = 0, gave_up = 0;
+static long long nw_prev[MAXLEV]; static long long *iw_prev[MAXLEV]; static double *vw_prev[MAXLEV];
+#define MAXOUT_MIRROR 64
+static int nout = 0; static double out_t[MAXOUT_MIRROR], out_dt[MAXOUT_MIRROR];
+static double tlim_ = 0; static int nlim_ = -1;
+static volatile sig_atomic_t term_seen = 0;
+static void (*old_term)(int) = SIG_DFL;
+static int term_hooked = 0;
 static double *snap[MAXLEV];        /* copy of U after Integrate (learn mode) */
 static size_t ncell[MAXLEV];
 static int integrated = 0;          /* Integrate ran since the last host refresh (SMR) */
@@ -90,7 +112,24 @@ static void ensure_grid(MeshS *pM)
   if (CoolingFunc != NULL) ath_error("[athena_amd]: CoolingFunc is not supported on this path\n");
   if (sizeof(ConsS) != (5 + AA_NSCALARS)*sizeof(double)) ath_error("[athena_amd]: ConsS layout\n");
   M = pM;
-  env = getenv("AA_COHERENCE"); learn = (env && strcmp(env, "learn") == 0);
+  env = getenv("AA_COHERENCE");
+  automode = (!env || strcmp(env, "auto") == 0);
+  learn = automode || (env && strcmp(env, "learn") == 0);
+  if (env && strcmp(env, "step") != 0 && strcmp(env, "learn") != 0 && strcmp(env, "auto") != 0)
+    ath_error("[athena_amd]: AA_COHERENCE=%s (auto, step or learn)\n", env);
+  if (automode) {            /* the <outputN> schedule main()'s data_output will follow (output.c:183-208) */
+    int outn, maxout = par_geti_def("job", "maxout", 10); char block[32];
+    for (outn = 1; outn <= maxout && nout < MAXOUT_MIRROR; outn++) {
+      sprintf(block, "output%d", outn);
+      if (!par_exist(block, "out_fmt") && !par_exist(block, "name")) continue;
+      out_dt[nout] = par_getd(block, "dt");
+      /* a fresh run's forced first dump (main.c:500) moves every next-output time on by one dt (output.c:509-511); a
+       * block that carries its own "time" (restart files do) is taken as is: at worst one refresh too many */
+      out_t[nout] = par_exist(block, "time") ? par_getd(block, "time") : pM->time + out_dt[nout];
+      nout++;
+    }
+    tlim_ = par_getd("time", "tlim"); nlim_ = par_geti_def("time", "nlim", -1);
+  }
   env = getenv("AA_SYNC_EVERY"); sync_every = env ? atoi(env) : 1; if (sync_every < 1) sync_every = 1;
   for (l = 0, irefine = 1; l < pM->NLevels; l++, irefine *= 2) {
     pD = &pM->Domain[l][0]; PG[l] = pD->Grid;
@@ -147,10 +186,10 @@ static void ensure_grid(MeshS *pM)
     env = getenv("AA_NGPU");
     if (env && atoi(env) > 1 && pM->NLevels == 1)   /* the library cuts the Grid into x3 slabs, one per GPU (csrc/slabs.hip) */
       fprintf(stderr, "[athena_amd] Grid %dx%dx%d in %d slabs along x3 on HIP devices %d.., %.2f GB resident, coherence=%s\n",
-              p.Nx[0], p.Nx[1], p.Nx[2], atoi(env), p.device, aa_device_bytes(G[l])/1e9, learn ? "learn" : "step");
+              p.Nx[0], p.Nx[1], p.Nx[2], atoi(env), p.device, aa_device_bytes(G[l])/1e9, automode ? "auto" : (learn ? "learn" : "step"));
     else
     fprintf(stderr, "[athena_amd] Grid %dx%dx%d (level %d) on HIP device %d, %.2f GB resident, coherence=%s\n",
-            p.Nx[0], p.Nx[1], p.Nx[2], l, p.device, aa_device_bytes(G[l])/1e9, learn ? "learn" : "step");
+            p.Nx[0], p.Nx[1], p.Nx[2], l, p.device, aa_device_bytes(G[l])/1e9, automode ? "auto" : (learn ? "learn" : "step"));
   }
   NL = pM->NLevels;
 #ifdef AA_SMR
@@ -238,12 +277,32 @@ void bvals_mhd_fun(DomainS *pD, enum BCDirection dir, VGFun_t prob_bc)
 
 static int after_new_dt = 0, steps_since_sync = 0;
 
+static void on_term(int sgn)
+{
+  term_seen = 1;
+  if (old_term != SIG_DFL && old_term != SIG_IGN && old_term != on_term) (*old_term)(sgn);     /* ath_signal.c's handler */
+}
+
+/* AA_COHERENCE=auto: will main() read the host blocks before the next step?  data_output at the top of the next cycle
+ * (an <outputN> block is due: output.c:507-522), the forced final output when the loop ends (main.c:519, :743), SIGTERM */
+static int host_read_due(void)
+{
+  int n, due = 0;
+  for (n = 0; n < nout; n++) if (M->time >= out_t[n]) { out_t[n] += out_dt[n]; due = 1; }
+  if (M->time >= tlim_ || (nlim_ >= 0 && M->nstep >= nlim_)) due = 1;
+  if (term_seen) due = 1;
+  return due;
+}
+
 /* data_output() at the top of the next cycle reads the host blocks */
 static void refresh_for_output(void)
 {
-  int l;
+  int l, due;
   after_new_dt = 0;
-  if (!(learn && learned) || (++steps_since_sync >= sync_every)) { for (l = 0; l < NL; l++) to_host(l); steps_since_sync = 0; }
+  if (!(learn && learned)) due = 1;
+  else if (automode) due = host_read_due();
+  else due = (++steps_since_sync >= sync_every);
+  if (due) { for (l = 0; l < NL; l++) to_host(l); steps_since_sync = 0; }
 }
 
 void bvals_mhd(DomainS *pD)
@@ -275,21 +334,47 @@ void new_dt(MeshS *pM)
 {
   int nl, nd, l; double t, dt; int n;
   ensure_grid(pM);
-  if (learn && !learned && snap[0]) {           /* what did Userwork_in_loop change? */
+  if (learn && !learned && !gave_up && snap[0]) {           /* what did Userwork_in_loop change? */
     const int nv = 5 + AA_NSCALARS;
+    int same = 1;
+    long long cnt_l[MAXLEV]; long long *idx_l[MAXLEV]; double *val_l[MAXLEV];
     for (l = 0; l < NL; l++) {
-      const double *h = host_block(l); long long cnt = 0, c; size_t i; int v; long long *idx; double *val;
+      const double *h = host_block(l); long long cnt = 0, c; size_t i; int v;
       for (i = 0; i < ncell[l]; i++) if (memcmp(h + i*nv, snap[l] + i*nv, nv*sizeof(double)) != 0) cnt++;
-      idx = (long long*)malloc((size_t)(cnt + 1)*sizeof(long long)); val = (double*)malloc((size_t)(cnt + 1)*nv*sizeof(double));
+      idx_l[l] = (long long*)malloc((size_t)(cnt + 1)*sizeof(long long)); val_l[l] = (double*)malloc((size_t)(cnt + 1)*nv*sizeof(double));
       for (i = 0, c = 0; i < ncell[l]; i++) if (memcmp(h + i*nv, snap[l] + i*nv, nv*sizeof(double)) != 0) {
-        idx[c] = (long long)i; for (v = 0; v < nv; v++) val[c*nv + v] = h[i*nv + v]; c++;
+        idx_l[l][c] = (long long)i; for (v = 0; v < nv; v++) val_l[l][c*nv + v] = h[i*nv + v]; c++;
       }
-      CHK(aa_set_pinned_cells(G[l], cnt, idx, val));
-      free(idx); free(val); free(snap[l]); snap[l] = NULL;
-      CHK(aa_apply_pinned_cells(G[l]));          /* this step's Userwork, on the device */
-      fprintf(stderr, "[athena_amd] Userwork_in_loop pins %lld cells on level %d; re-imposed on the device from now on\n", cnt, l);
+      cnt_l[l] = cnt;
+      free(snap[l]); snap[l] = NULL;
+      /* auto: trusted only when two consecutive steps wrote the same values into the same zones */
+      if (automode) {
+        if (iw_prev[l] == NULL) same = 0;
+        else if (nw_prev[l] != cnt || memcmp(iw_prev[l], idx_l[l], (size_t)cnt*sizeof(long long)) != 0 ||
+                 memcmp(vw_prev[l], val_l[l], (size_t)cnt*nv*sizeof(double)) != 0) same = -1;
+      }
     }
-    learned = 1;
+    if (automode && same == 0) {               /* first step: remember, look again after the next one */
+      for (l = 0; l < NL; l++) { nw_prev[l] = cnt_l[l]; iw_prev[l] = idx_l[l]; vw_prev[l] = val_l[l]; }
+    } else if (automode && same < 0) {          /* Userwork_in_loop is not a fixed imprint: keep the host in the loop every step */
+      for (l = 0; l < NL; l++) { free(idx_l[l]); free(val_l[l]); free(iw_prev[l]); free(vw_prev[l]); iw_prev[l] = NULL; vw_prev[l] = NULL; }
+      gave_up = 1; learn = 0;
+      fprintf(stderr, "[athena_amd] Userwork_in_loop writes differ from step to step: coherence stays `step`\n");
+    } else {
+      for (l = 0; l < NL; l++) {
+        CHK(aa_set_pinned_cells(G[l], cnt_l[l], idx_l[l], val_l[l]));
+        CHK(aa_apply_pinned_cells(G[l]));          /* this step's Userwork, on the device */
+        fprintf(stderr, "[athena_amd] Userwork_in_loop pins %lld cells on level %d; re-imposed on the device from now on\n", cnt_l[l], l);
+        free(idx_l[l]); free(val_l[l]);
+        if (iw_prev[l]) { free(iw_prev[l]); free(vw_prev[l]); iw_prev[l] = NULL; vw_prev[l] = NULL; }
+      }
+      learned = 1;
+      if (automode && !term_hooked) {              /* from here on the host block is only as fresh as host_read_due() makes it */
+        void (*h)(int) = signal(SIGTERM, on_term);
+        if (h != on_term) old_term = h;
+        term_hooked = 1;
+      }
+    }
   }
   for (l = 0; l < NL; l++) {
     if (learn && learned) host_newer[l] = 0;    /* the stale host copy must not travel back */

@@ -10,10 +10,12 @@ keys at 512^3 single level (hydro + static gravity + ion radiation).
 Regime.  The deck starts with dt = 4.7e-6 s, which new_dt lets double once per step; around step 19
 (512^3) dt reaches the chemical time scale and the ion step takes 30-80 sub-cycles for a few dozen
 steps; from about step 60 on dt sits at the CFL limit (5.4-6.5 s) and the ion step needs ONE
-sub-cycle per step, for as long as the run can be followed (profiles/r02_regime_512.txt).  The timed
+sub-cycle per step (a few more bursts until about step 150), for as long as the run can be followed
+(profiles/r02_regime_512.txt).  The timed
 region therefore starts after an untimed SPIN-UP that runs until that stationary state is reached
-(--spinup auto: dt no longer doubling and the sub-cycle count unchanged over 12 consecutive steps,
-at most 200 steps; --spinup N: exactly N steps, e.g. 19 to land in the burst of sub-cycles).
+(--spinup auto: dt no longer doubling and the sub-cycle count unchanged over 48 consecutive steps -- bursts of
+sub-cycles recur sporadically until about step 150 --, at most 320 steps; --spinup N: exactly N steps, e.g. 19 to land
+in the bursts).
 `value` is what the timed region gives; `phases` breaks it into the hydro chain, one radiation
 sub-cycle and the rest, each with its roofline on SURVEY 8(d)'s algorithmic bytes (96 B per
 cell-update, 64 B per cell and sub-cycle), so the number can be re-derived for any sub-cycle count.
@@ -301,7 +303,7 @@ def spin_up(drv, mode, log):
             log.append(drv.step())
         return
     quiet = 0
-    while len(log) < 200 and quiet < 12:
+    while len(log) < 320 and quiet < 48:
         dt0 = drv.dt
         n = drv.step()
         log.append(n)

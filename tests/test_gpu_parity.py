@@ -256,8 +256,15 @@ def test_ioniz_sphere_vs_oracle(aa, lib, nx, nsteps, strict, fused_rates, ion_pa
     # 24x16x12 puts the planet (radius 2 cells) next to a 1e5 density jump: face pressures go
     # negative there (NaN etas, Roe->HLLE switches), so any last-bit difference (device exp/log,
     # fused multiply-adds) moves a few cells by ~1e-6; every other case holds 1e-8.
+    # tests/test_conditioning.py: the ORACLE run again from a start state moved by one unit in the last place spreads
+    # by 5e-6 .. 7e-6 on this case -- 2e-5 is what arithmetic that differs in the last bit can be held to here.
     tol = 2e-5 if nx == (24, 16, 12) else 1e-8
     assert max(err) < tol, err
+    if nx == (24, 16, 12):
+        scale = np.nanmax(np.abs(b), axis=(0, 1, 2))
+        nflip = int((np.abs(a - b) / scale > 1e-8).any(axis=-1).sum())
+        print(f"N_flip (zones beyond 1e-8) = {nflip} of {a[..., 0].size}, max {max(err):.2e}, strict={strict}")
+        assert nflip <= 64                      # ~1 % of the zones, around the planet; every other zone holds 1e-8
     g.close()
 
 
@@ -345,7 +352,10 @@ def test_from_developed_reference_state(aa, lib, name, strict, tol, ion_path):
             # the 32^3 sphere has a planet 3 zones in radius beside a 1e5 density jump: with fused
             # multiply-adds a limiter / Roe->HLLE decision flips in a few dozen zones by the third step
             # (the strict build of the same sources matches to 1e-9, in fact bit for bit); everywhere
-            # else the default build stays at rounding level
+            # else the default build stays at rounding level.  tests/test_conditioning.py: the ORACLE itself, started
+            # from the same state moved by one unit in the last place, spreads by 6e-5 on 25 zones in these 3 steps.
+            nflip = int((err > 1e-9).any(axis=-1).sum())
+            print(f"N_flip (zones beyond 1e-9) = {nflip} of {err[..., 0].size}, max {err.max():.2e}")
             assert (err > 1e-9).any(axis=-1).mean() < 0.005
     g.close()
 

@@ -57,12 +57,15 @@ def test_slabs_inside_the_library_equal_one_grid(problem, nx, nsteps, nslab, int
         if "ef" in one:
             assert np.array_equal(many["ef"], one["ef"])
     else:
-        assert abs(many["dt"] / one["dt"] - 1) < 1e-13
+        # (the sphere cases put a planet a few zones across beside a 1e5 density jump: NaN etas, Roe->HLLE switches --
+        #  a changed last bit grows to 1e-9 there within two steps, tests/test_conditioning.py)
+        tol = 1e-8 if problem == "ioniz_sphere" else 1e-13
+        assert abs(many["dt"] / one["dt"] - 1) < tol
         scale = np.nanmax(np.abs(one["U"]), axis=(0, 1, 2)); scale[scale == 0] = 1
-        assert (np.nanmax(np.abs(many["U"] - one["U"]), axis=(0, 1, 2)) / scale).max() < 1e-13
+        assert (np.nanmax(np.abs(many["U"] - one["U"]), axis=(0, 1, 2)) / scale).max() < tol
         if "ef" in one:
-            assert np.allclose(many["ef"], one["ef"], rtol=1e-12, atol=1e-12 * np.abs(one["ef"]).max())
-    assert np.allclose(many["hist"], one["hist"], rtol=1e-13, equal_nan=True)      # sums over slabs: a different summation order
+            assert np.allclose(many["ef"], one["ef"], rtol=1e-12 if tol < 1e-12 else tol, atol=1e-12 * np.abs(one["ef"]).max())
+    assert np.allclose(many["hist"], one["hist"], rtol=1e-13 if strict or problem != "ioniz_sphere" else 1e-8, equal_nan=True)      # sums over slabs: a different summation order
 
 
 def test_too_thin_slabs_are_refused():
