@@ -337,6 +337,8 @@ int aa_add_radplane_3d(aa_grid *g, int dir, double flux)
   return 0;
 }
 
+int aa_has_radplane(const aa_grid *g) { return (g->p.ion && g->nradplane > 0) ? 1 : 0; }   // main.c:546: the ion step runs iff nradplane > 0
+
 // ---- per-step call sites ------------------------------------------------------------------
 int aa_bvals_mhd(aa_grid *g)
 {

@@ -34,6 +34,7 @@
 // (differences ~1e-16, below those of device exp vs glibc exp, which no implementation can avoid).  The
 // tile kernel of ion_kernels.hip keeps the serial order and remains the path for short rays (Nx1 < 64).
 #include "ion_dev.h"
+#include "ion_tables.h"
 
 namespace aa {
 
@@ -96,57 +97,59 @@ AA_DEV Real fsqrt_n(Real x)
   return fma(fma(-y, y, x), 0.5*r, y);          // one correction of the root itself
 }
 
-// exp of N arguments at once.  OCML's exp(double) is 42 vector instructions of which 19 only move the polynomial's
-// coefficients into registers (FP64 operands cannot be literals), and a zone needs four exponentials per phase: here
-// the N Horner chains run side by side and share each coefficient.  n = rint(x log2 e), r = x - n ln2 (two-part ln2:
-// exact product for |n| < 2^20), Taylor polynomial of degree 13 on |r| <= ln2/2 (truncation 4e-18), ldexp.
-// |error| <= 1 ulp on the arguments met here; NaN -> NaN; x <= -746 -> 0 (v_ldexp_f64 underflows cleanly).
+// exp of N arguments at once, table-driven.  OCML's exp(double) is 42 vector instructions of which 19 only move the
+// polynomial's coefficients into registers (FP64 operands cannot be literals), and a zone needs four exponentials per
+// phase: here the N Horner chains run side by side and share each coefficient, and a 32-entry table of 2^(j/32) shortens
+// them: k = rint(32 x / ln2) = 32 n + j, r = x - k ln2/32 (two-part constant: exact product for |k| < 2^21), |r| <= ln2/64,
+// exp(x) = 2^n T[j] (1 + (e^r - 1)) with e^r - 1 by a degree-6 series (truncation 3e-18), one fma onto T[j], ldexp.
+// 16 instructions + one LDS read per exponential.  |error| <= 1 ulp; NaN -> NaN; x <= -746 -> 0 (v_ldexp_f64 underflows cleanly).
 template <int N>
-AA_DEV void exp_n(const Real (&x)[N], Real (&y)[N])
+AA_DEV void exp_n(const Real (&x)[N], Real (&y)[N], const Real *tE)
 {
 #ifdef STUB_EXP
   for (int k = 0; k < N; k++) y[k] = x[k]; return;
 #endif
-  Real nf[N], r[N], pl[N];
+  Real kf[N], r[N], q[N];
 #pragma unroll
   for (int k = 0; k < N; k++) {
-    nf[k] = __builtin_rint(x[k]*1.4426950408889634);
-    r[k] = fma(-nf[k], 6.93147180369123816490e-01, x[k]);
-    r[k] = fma(-nf[k], 1.90821492927058770002e-10, r[k]);
-    pl[k] = 1.0/6227020800.0;
+    kf[k] = __builtin_rint(x[k]*46.166241308446828384);
+    r[k] = fma(-kf[k], 6.93147180369123816490e-01/32.0, x[k]);
+    r[k] = fma(-kf[k], 1.90821492927058770002e-10/32.0, r[k]);
+    q[k] = fma(r[k], 1.0/720.0, 1.0/120.0);
   }
-  const Real cf[13] = {1.0/479001600.0, 1.0/39916800.0, 1.0/3628800.0, 1.0/362880.0, 1.0/40320.0, 1.0/5040.0, 1.0/720.0,
-                       1.0/120.0, 1.0/24.0, 1.0/6.0, 0.5, 1.0, 1.0};
+  const Real cf[4] = {1.0/24.0, 1.0/6.0, 0.5, 1.0};
 #pragma unroll
-  for (int c = 0; c < 13; c++)
+  for (int c = 0; c < 4; c++)
 #pragma unroll
-    for (int k = 0; k < N; k++) pl[k] = fma(pl[k], r[k], cf[c]);
+    for (int k = 0; k < N; k++) q[k] = fma(q[k], r[k], cf[c]);
 #pragma unroll
-  for (int k = 0; k < N; k++) y[k] = __builtin_ldexp(pl[k], (int)nf[k]);
+  for (int k = 0; k < N; k++) {
+    const int ki = (int)kf[k];
+    const Real t = tE[ki & 31];
+    y[k] = __builtin_ldexp(fma(t, q[k]*r[k], t), ki >> 5);
+  }
 }
 
-// ln x for positive normal x (temperatures): m = mantissa in [sqrt(1/2), sqrt(2)), s = (m-1)/(m+1),
-// ln m = 2 atanh(s) = 2s (1 + s^2/3 + ... + s^20/21), |s| <= 0.172 (truncation 2e-17); ln x = e ln2 + ln m with the
-// two-part ln2.  |error| <= 2 ulp; NaN -> NaN.  (OCML's log: 98 instructions, double-double throughout.)
-AA_DEV Real log_pos(Real x)
+// ln x for positive normal x (temperatures), table-driven: x = m 2^e with m in [1,2); the top 7 mantissa bits pick
+// one of 128 intervals with centre c_j; r = (m - c_j)/c_j (the difference is exact, 1/c_j from the table), |r| <= 1/256;
+// ln m = ln c_j + log1p(r) with a degree-7 series (truncation 2e-18 r); ln x = e ln2 + ln m with the two-part ln2.
+// 24 vector instructions + two LDS reads (OCML's log: 98, double-double throughout; a 20-term atanh series without
+// tables: 56).  |error| <= 2 ulp for |ln x| >= 0.5 (every temperature above the floor), <= 3e-16 absolute below that
+// (x just under a power of two: e ln2 and ln m cancel); NaN -> NaN.
+AA_DEV Real log_pos(Real x, const Real *tR, const Real *tL)
 {
 #ifdef STUB_LOG
   return x;
 #endif
-  Real m = __builtin_amdgcn_frexp_mant(x);
-  int e = __builtin_amdgcn_frexp_exp(x);
-  const bool lo = m < 0.70710678118654752;
-  m = lo ? 2.0*m : m; e = lo ? e - 1 : e;
-  const Real f = m - 1.0, dd = 2.0 + f;
-  Real rr = __builtin_amdgcn_rcp(dd);                        // dd in [1.7, 2.42]
-  Real er = fma(-dd, rr, 1.0); rr = fma(er, rr, rr);
-  er = fma(-dd, rr, 1.0); rr = fma(er, rr, rr);
-  const Real s = f*rr, z = s*s;
-  Real q = 1.0/21.0;
-  q = fma(q, z, 1.0/19.0); q = fma(q, z, 1.0/17.0); q = fma(q, z, 1.0/15.0); q = fma(q, z, 1.0/13.0);
-  q = fma(q, z, 1.0/11.0); q = fma(q, z, 1.0/9.0); q = fma(q, z, 1.0/7.0); q = fma(q, z, 1.0/5.0); q = fma(q, z, 1.0/3.0);
-  const Real s2 = 2.0*s;
-  const Real lm = fma(s2*z, q, s2);
+  const Real m = 2.0*__builtin_amdgcn_frexp_mant(x);
+  const int e = __builtin_amdgcn_frexp_exp(x) - 1;
+  int j = (int)((m - 1.0)*128.0);
+  j = j < 0 ? 0 : (j > 127 ? 127 : j);
+  const Real c = fma((Real)j + 0.5, 1.0/128.0, 1.0);
+  const Real r = (m - c)*tR[j];
+  Real q = fma(r, 1.0/7.0, -1.0/6.0);
+  q = fma(q, r, 0.2); q = fma(q, r, -0.25); q = fma(q, r, 1.0/3.0); q = fma(q, r, -0.5);
+  const Real lm = tL[j] + fma(r*r, q, r);
   const Real ef = (Real)e;
   return fma(ef, 6.93147180369123816490e-01, fma(ef, 1.90821492927058770002e-10, lm));
 }
@@ -155,15 +158,15 @@ AA_DEV Real log_pos(Real x)
 // the recombination coefficient 2.59e-13 (T/1e4)^-0.7 (or its floor value; ionrad_chemistry.c:111), and the factors
 // T^-0.89 and exp(-118348/T) of the cooling rates (:137, :350); T^y = exp(y ln T) with one shared log
 struct Therm { Real etau, rec, e89, elya, arg; bool cold; };
-AA_DEV Therm zone_therm(const IonQ &q, Real tau, const IonPar &p)
+AA_DEV Therm zone_therm(const IonQ &q, Real tau, const IonPar &p, const Real *tR, const Real *tL, const Real *tE)
 {
   Therm th;
   th.cold = (q.T < p.tfloor);
-  const Real lnT = th.cold ? 0.0 : log_pos(q.T);
+  const Real lnT = th.cold ? 0.0 : log_pos(q.T, tR, tL);
   th.arg = 118348*frcp_n(q.T);
   const Real x[4] = {-tau, -0.7*(lnT - 9.210340371976184), -0.89*lnT, -th.arg};
   Real y[4];
-  exp_n<4>(x, y);
+  exp_n<4>(x, y, tE);
   th.etau = y[0];
   th.rec = th.cold ? p.rec_floor : 2.59e-13*y[1];
   th.e89 = y[2]; th.elya = y[3];
@@ -275,18 +278,24 @@ AA_DEV Real zone_ph(Real fin, Real etau, Real n_H, Real inv_len)      // ionradp
 struct Ops { Real d, ke, E, s, fp, e0, x0, vm; unsigned short sg; };
 
 #ifndef AA_ION_PREFETCH
-#define AA_ION_PREFETCH 1            /* next tile's operands in flight during this tile's arithmetic */
+#define AA_ION_PREFETCH 0            /* 1: next tile's operands in flight during this tile's arithmetic (17 more VGPRs) */
 #endif
 #ifndef AA_ION_PAR_LDS
 #define AA_ION_PAR_LDS 1
 #endif
+// waves per SIMD the register budget is cut for.  With OCML's exp / log and IEEE divisions the full pass needed 3 waves
+// plus a software prefetch of the next tile (157 VGPRs); with the table-driven exp / log it fits 4 waves without the
+// prefetch (127 VGPRs, no spills) and the fourth wave hides more latency than the prefetch did: 2.63 against 2.98 ms
 #ifndef AA_ION_PASS_WAVES
-#define AA_ION_PASS_WAVES 3          /* waves per SIMD the register budget is cut for */
+#define AA_ION_PASS_WAVES 4
+#endif
+#ifndef AA_ION_PASS_WAVES_HALF
+#define AA_ION_PASS_WAVES_HALF 4     /* the first / closing passes (sweep + rates only, update only) */
 #endif
 // BEG: the first pass of an ion step also does the step's entry -- floors, save_energy_and_x, the frozen kinetic
 // energy and max|v| (ionrad_3d.c:896-905; k_ion_begin16's arithmetic, bit for bit) -- on the zones it reads anyway
 template <bool UPD, bool SWP, bool BEG>
-__global__ void __launch_bounds__(256, AA_ION_PASS_WAVES)
+__global__ void __launch_bounds__(256, (UPD && SWP) ? AA_ION_PASS_WAVES : AA_ION_PASS_WAVES_HALF)
 k_ion_pass(DevGrid g, IonPar p_arg, Real flux0, int from_edgeflux, const DevScalars *sc, int cur, IonPart *part, int only_if_hit)
 {
   // an updating pass is launched in both forms -- with and without the sweep of a further sub-cycle -- and the one
@@ -296,16 +305,17 @@ k_ion_pass(DevGrid g, IonPar p_arg, Real flux0, int from_edgeflux, const DevScal
   // build spilled 58 of them, partly to scratch): the parameter block lives in LDS and is re-read per tile through a
   // pointer the compiler cannot see through, i.e. as short-lived vector registers next to their uses
   __shared__ IonPar s_par;
+  __shared__ Real s_logR[128], s_logL[128], s_expT[32];          // tables of log_pos and exp_n
   if (threadIdx.x == 0) s_par = p_arg;
+  if (threadIdx.x < 128) { s_logR[threadIdx.x] = c_log_R[threadIdx.x]; s_logL[threadIdx.x] = c_log_L[threadIdx.x]; }
+  if (threadIdx.x < 32) s_expT[threadIdx.x] = c_exp_T[threadIdx.x];
   __syncthreads();
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const long nrays = (long)g.Nx2*g.Nx3;
   const long nwaves = (long)gridDim.x*4;        // (rays per Grid stay below 2^31)
   const int ntile = (g.Nx1 + 63) >> 6;
   const Real dt = UPD ? sc->dt_sel : 0.0;
-  // the step was cut back to what is left of the hydro step / coarse time: this pass ends the loop, the sweep and the
-  // rates of a further sub-cycle are not wanted (the host does not know yet: it reads back once per sub-cycle)
-  const bool sweep = SWP && !(UPD && sc->limit_hit);
+  constexpr bool sweep = SWP;     // (whether a sweep is wanted after an update is settled by which of the two launches stays)
   const Real *fprev = g.fin[cur];
   Real *fnext = g.fin[cur ^ 1];
   const long efp = (long)(g.Nx1 + 1), efrow = (long)(g.Nx2 + 1)*efp;
@@ -386,7 +396,7 @@ k_ion_pass(DevGrid g, IonPar p_arg, Real flux0, int from_edgeflux, const DevScal
     }
     const Real di = frcp_n(c.d);
     IonQ q; Therm th;
-    { PAR_HERE(p); q = zone_q(c, di, p, g.Gamma_1); th = zone_therm(q, p.sigma_ph * q.n_H * dx1, p); }
+    { PAR_HERE(p); q = zone_q(c, di, p, g.Gamma_1); th = zone_therm(q, p.sigma_ph * q.n_H * dx1, p, s_logR, s_logL, s_expT); }
     if (UPD) {
       // the photoionization rate the previous sweep gave this zone: same expression, same operands
       Real php;
@@ -396,7 +406,7 @@ k_ion_pass(DevGrid g, IonPar p_arg, Real flux0, int from_edgeflux, const DevScal
       { PAR_HERE(p);
         q = zone_q(c, di, p, g.Gamma_1);
         if (zone_floors(c, q, p, g.Gamma_1)) q = zone_q(c, di, p, g.Gamma_1);
-        if (sweep) th = zone_therm(q, p.sigma_ph * q.n_H * dx1, p); }
+        if (sweep) th = zone_therm(q, p.sigma_ph * q.n_H * dx1, p, s_logR, s_logL, s_expT); }
       PAR_HERE(p);
       if (in) {
         if (out_of_range(c, q, php, o.e0, o.x0, p)) cnt++;
@@ -573,12 +583,16 @@ k_ion_begin16(DevGrid g, IonPar p)
 // function-level test of this file's exp / log (tests/test_gpu_ion_pass.py): y = exp_n<4> of x (lanes of four), l = log_pos(|x|)
 __global__ void k_test_explog(int n, const Real *x, Real *ye, Real *yl)
 {
+  __shared__ Real s_logR[128], s_logL[128], s_expT[32];
+  if (threadIdx.x < 128) { s_logR[threadIdx.x] = c_log_R[threadIdx.x]; s_logL[threadIdx.x] = c_log_L[threadIdx.x]; }
+  if (threadIdx.x < 32) s_expT[threadIdx.x] = c_exp_T[threadIdx.x];
+  __syncthreads();
   const int i = (blockIdx.x*blockDim.x + threadIdx.x)*4;
   if (i + 3 >= n) return;
   const Real a[4] = {x[i], x[i + 1], x[i + 2], x[i + 3]};
   Real y[4];
-  exp_n<4>(a, y);
-  for (int k = 0; k < 4; k++) { ye[i + k] = y[k]; yl[i + k] = log_pos(fabs(a[k])); }
+  exp_n<4>(a, y, s_expT);
+  for (int k = 0; k < 4; k++) { ye[i + k] = y[k]; yl[i + k] = log_pos(fabs(a[k]), s_logR, s_logL); }
 }
 void launch_test_explog(int n, const Real *x, Real *ye, Real *yl, hipStream_t st)
 { hipLaunchKernelGGL(k_test_explog, dim3((n/4 + 255)/256), dim3(256), 0, st, n, x, ye, yl); }

@@ -84,7 +84,7 @@ class HipEngine:
     def ion_finish(self): self.g.ion_finish()
     def host_syncs(self, reset=False): return self.g.host_syncs(reset)
     def set_mesh_state(self, time, dt, nstep): self.g.set_mesh_state(time, dt, nstep)
-    def has_radiation(self) -> bool: return bool(self.cfg.run.ion)
+    def has_radiation(self) -> bool: return self.g.has_radplane()      # main.c:546, as aa_step: the ion step runs iff nradplane > 0
     def step_local(self) -> int: return self.g.step()
     def start_local(self): self.g.start()
     def mesh_state(self): return self.g.mesh_state()
@@ -334,8 +334,7 @@ class HipMeshEngine:
         self.torch = torch
         self.cfg = cfg
         torch.cuda.set_device(device)
-        # (the multi-rank SMR loop still reduces the sub-cycle's scalars on the host: two-kernel sub-cycle)
-        self.mesh = lib.Mesh(cfg.levels, device, strict, links=cfg.links, ion_path=2)
+        self.mesh = lib.Mesh(cfg.levels, device, strict, links=cfg.links)
         if use_torch_stream:
             self.mesh.set_stream(torch.cuda.current_stream().cuda_stream)
         self.lev = self.mesh.lev
@@ -344,6 +343,11 @@ class HipMeshEngine:
         self.send = [[torch.empty(g.halo_doubles(), dtype=torch.float64, device=dev) for _ in range(2)] for g in self.lev]
         self.recv = [[torch.empty(g.halo_doubles(), dtype=torch.float64, device=dev) for _ in range(2)] for g in self.lev]
         self._fbuf = {}
+        # one-kernel radiation sub-cycle (levels with rays of 64 zones or more): this rank's reduction words of the level
+        # being stepped, and those of all ranks, in device memory
+        self.words = torch.zeros(lib.ION_WORDS, dtype=torch.float64, device=dev)
+        self.words_all = torch.zeros(lib.ION_WORDS * max(1, cfg.nranks), dtype=torch.float64, device=dev)
+        self.neutral = torch.tensor([1.7976931348623157e308, 1.7976931348623157e308, 0, 0, 0, 0, 0, 0], dtype=torch.float64, device=dev)
 
     nlev = property(lambda s: len(s.lev))
 
@@ -355,6 +359,24 @@ class HipMeshEngine:
     def ion_begin(self, l): self.lev[l].ion_begin()
     def ion_rates(self, l): return self.lev[l].ion_rates()
     def ion_update(self, l, dt): return self.lev[l].ion_update(dt)
+    def ion_is_fused(self, l): return self.lev[l].ion_is_fused()
+    def ion_pass(self, l, update, sweep): self.lev[l].ion_pass(update, sweep, self.words.data_ptr())
+    def ion_neutral_words(self): self.words.copy_(self.neutral)          # a rank that holds no zones of the level
+
+    def ion_gather(self, dist):
+        """all ranks' words of the level being stepped -> self.words_all (device); one collective per sub-cycle"""
+        if dist is None:
+            self.words_all[:self.words.numel()].copy_(self.words)
+        elif dist.get_backend() == "gloo":                       # rehearsal on one GPU: gloo moves host tensors
+            w = self.words.cpu(); wa = self.words_all.cpu()
+            dist.all_gather_into_tensor(wa, w)
+            self.words_all.copy_(wa)
+        else:
+            dist.all_gather_into_tensor(self.words_all, self.words)
+
+    def ion_pick(self, l, nranks, first, limit): self.lev[l].ion_pick(self.words_all.data_ptr(), nranks, first, limit)
+    def ion_fetch(self, l): return self.lev[l].ion_fetch()
+    def ion_finish(self, l): self.lev[l].ion_finish()
     def set_level_state(self, l, time, dt, nstep): self.lev[l].set_mesh_state(time, dt, nstep)
     def cfl_max_v(self, l): return self.lev[l].cfl_max_v()
     def has_radiation(self) -> bool: return bool(self.cfg.levels[0].run.ion)
@@ -406,7 +428,9 @@ class MeshDriver:
         import torch.distributed as dist
         self.torch, self.dist = torch, dist
         self.run, self.rank, self.nranks = run, rank, nranks
+        from .config import levels as _levels
         self.cfg = mesh_slabs(par, run, rank, nranks, cuts)
+        self.level_nx1 = [g.Nx[0] for g in _levels(par, run)]     # zones along the rays of every level (x3 slabs keep them)
         self.eng = engine_factory(self.cfg) if engine_factory else HipMeshEngine(self.cfg, device, strict)
         self.NL = len(self.cfg.table[0])                  # levels of the Mesh
         self.nl = len(self.cfg.levels)                    # levels present on this rank
@@ -521,9 +545,93 @@ class MeshDriver:
                 self.eng.set_level_state(l, self.time, self.dt, self.nstep)
 
     # ---- radiation ---------------------------------------------------------------------------------
+    def _level_fused(self, l: int) -> bool:
+        """whether level l runs the one-kernel sub-cycle: the same answer on every rank (x3 slabs keep Nx1), also on
+        ranks that hold no zones of the level"""
+        if not hasattr(self.eng, "ion_pass"):
+            return False
+        env = os.environ.get("AA_ION_FUSED")
+        if env is not None:
+            return env not in ("", "0")
+        return self.level_nx1[l] >= 64
+
+    def _ion_radtransfer_fused(self, l: int) -> int:
+        """ionrad_3d.c:862 on level l with the one-kernel sub-cycle (see Driver._ion_radtransfer_fused): one pass, ONE
+        all-gather of the ranks' reduction words and one read-back per sub-cycle.  A rank without zones of the level
+        contributes neutral words and follows the control flow from the gathered words (the arithmetic of k_ion_pick2)."""
+        e, has = self.eng, self.has(l)
+        dist = self.dist if self.distributed else None
+        nr = self.nranks if self.distributed else 1
+        fine = l != 0
+        if fine:
+            if has:
+                e.ionflux_prolong(l)
+        else:
+            self.tcoarse = 0.0
+        limit = self.tcoarse if fine else self.dtl[0]
+        if has:
+            e.set_level_state(l, self.time, self.dtl[l], self.nstep)
+            e.ion_begin(l)
+        mir = {"dt_sel": 0.0, "hit": False, "neg": False, "dt_done": 0.0}
+
+        def one_pass(update, first):
+            if has:
+                e.ion_pass(l, update, True)
+            else:
+                e.ion_neutral_words()
+            e.ion_gather(dist)
+            if has:
+                e.ion_pick(l, nr, first, limit)
+                return e.ion_fetch(l) if not first else None
+            W = e.words_all.tolist()                                   # this rank's one wait of the sub-cycle
+            n = len(W) // nr
+            dt_chem = min(W[0::n]); dt_therm = min(W[1::n]); max_dti = max(W[2::n]); count = sum(W[3::n]); neg = max(W[4::n]) != 0.0
+            out = None
+            if not first:
+                out = (mir["dt_sel"], mir["hit"], dt_chem, dt_therm, int(count), self.run.cour_no / max_dti if max_dti > 0 else float("inf"), mir["neg"])
+                mir["dt_done"] = mir["dt_done"] + mir["dt_sel"]
+            else:
+                mir["dt_done"] = 0.0
+            dt = dt_therm if dt_therm < dt_chem else dt_chem
+            hit = False
+            if mir["dt_done"] + dt > limit:
+                dt = limit - mir["dt_done"]; hit = True
+            mir["dt_sel"], mir["hit"], mir["neg"] = dt, hit, neg
+            return out
+
+        one_pass(False, True)
+        dt_done, niter = 0.0, 0
+        while True:
+            dt, hit, dt_chem, dt_therm, cellcount, dt_hydro, neg = one_pass(True, False)
+            if neg:
+                raise RuntimeError("[compute_chem_rates]: negative dt_chem")
+            dt_done += dt
+            niter += 1
+            if not fine:
+                if cellcount > MAXCELLCOUNT:
+                    self.dtl[0] = dt_done; break
+                if hit:
+                    break
+                if dt_hydro < dt_done:
+                    self.dtl[0] = dt_done; break
+            elif hit:
+                self.dtl[l] = dt_done; break
+        if has:
+            e.ion_finish(l)
+        if not fine:
+            if niter == self.run.maxiter:
+                self.dtl[0] = dt_done
+            self.tcoarse = dt_done
+        self.dt = self.dtl[l]                                   # ionrad_3d.c:1030 pMesh->dt = pGrid->dt
+        if has:
+            e.set_level_state(l, self.time, self.dtl[l], self.nstep)
+        return niter
+
     def ion_radtransfer(self, l: int) -> int:
         """ionrad_3d.c:862 on level l (all ranks take part in the reductions, with neutral values where
         the level is absent)."""
+        if self._level_fused(l):
+            return self._ion_radtransfer_fused(l)
         e, has = self.eng, self.has(l)
         fine = l != 0
         INF = float("inf")

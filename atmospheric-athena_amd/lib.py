@@ -91,7 +91,7 @@ def load(strict: bool | None = None) -> C.CDLL:
         "aa_set_static_grav_pot": (I, [P, GRAVPOT]),
         "aa_set_static_grav_tables": (I, [P, dp, dp, dp, dp]),
         "aa_set_pinned_cells": (I, [P, LL, llp, dp]), "aa_apply_pinned_cells": (I, [P]),
-        "aa_add_radplane_3d": (I, [P, I, D]),
+        "aa_add_radplane_3d": (I, [P, I, D]), "aa_has_radplane": (I, [P]),
         "aa_bvals_mhd": (I, [P]), "aa_bvals_mhd_side": (I, [P, I, I]), "aa_bvals_ionrad": (I, [P]), "aa_new_dt": (I, [P]),
         "aa_integrate_3d_ctu": (I, [P]), "aa_integrate_3d_vl": (I, [P]), "aa_ion_radtransfer_3d": (I, [P, ip]),
         "aa_start": (I, [P]), "aa_step": (I, [P, ip]),
@@ -249,6 +249,7 @@ class Grid:
                                              index.ctypes.data_as(C.POINTER(C.c_longlong)), _dp(values)))
 
     def add_radplane_3d(self, dir: int, flux: float): self._chk(self.L.aa_add_radplane_3d(self._h, dir, flux))
+    def has_radplane(self) -> bool: return bool(self.L.aa_has_radplane(self._h))
 
     # ---- call sites of the main loop ------------------------------------------------
     def bvals_mhd(self): self._chk(self.L.aa_bvals_mhd(self._h))

@@ -89,6 +89,7 @@ int aa_set_pinned_cells(aa_grid *g, long long n, const long long *index, const d
 int aa_apply_pinned_cells(aa_grid *g);
 /* ionradplane_3d.c:56 add_radplane_3d (called by problem()); dir must be -1 (+x1 rays) */
 int aa_add_radplane_3d(aa_grid *g, int dir, double flux);
+int aa_has_radplane(const aa_grid *g);   /* main.c:546 `radplanelist[0].nradplane > 0`: whether a step includes the ion step */
 
 /* ---- the reference's per-step call sites */
 int aa_bvals_mhd(aa_grid *g);                       /* bvals_mhd.c:174 (physical BCs only)        */

@@ -185,3 +185,42 @@ def test_restart_of_the_reference_driver_on_gpu_library():
     shutil.rmtree(tmp)
     assert a["nstep"] == c["nstep"] == 4 and a["time"] == c["time"] and a["dt"] == c["dt"]
     assert np.array_equal(a["U"][..., :5], c["U"][..., :5])
+
+
+@pytest.mark.parametrize("problem,nx,nlim,outdt", [("blast", (24, 16, 20), 9, 0.004), ("ioniz_sphere", (32, 32, 32), 7, 3.0e-5)])
+def test_auto_coherence_refreshes_the_host_exactly_when_main_reads_it(problem, nx, nlim, outdt):
+    """AA_COHERENCE=auto (the default): after two verified steps the host block is refreshed only when an <outputN> block
+    is due, the loop ends, or SIGTERM arrives.  A restart output every `outdt` of simulated time puts dumps in the
+    middle of the run: every dump must equal the one of AA_COHERENCE=step (same library, host kept in the loop every
+    step) bit for bit, and there must be several of them."""
+    if not os.path.exists(os.path.join(REFBIN, f"athena_{problem}_amd")):
+        pytest.skip("oracle/_ref drop-in executables not built (make -C oracle ref)")
+    from make_golden import read_rst
+    ion = problem != "blast"
+    dumps = {}
+    for mode in ("step", "auto"):
+        tmp = tempfile.mkdtemp(prefix="dropin_auto_")
+        deck = os.path.join(tmp, "athinput")
+        text = open(os.path.join(ROOT, "atmospheric-athena_amd", "decks", "athinput." + problem)).read()
+        text = text.replace("maxout      = 0", "maxout      = 1") + f"\n<output1>\nout_fmt = rst\ndt = {outdt!r}\n"
+        open(deck, "w").write(text)
+        env = dict(os.environ, AA_COHERENCE=mode)
+        pr = subprocess.run([os.path.join(REFBIN, f"athena_{problem}_amd"), "-i", deck, "-d", os.path.join(tmp, "run"),
+                             f"domain1/Nx1={nx[0]}", f"domain1/Nx2={nx[1]}", f"domain1/Nx3={nx[2]}", f"time/nlim={nlim}"],
+                            stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, cwd=tmp, env=env, timeout=600)
+        assert pr.returncode == 0, pr.stdout[-1500:] + pr.stderr[-1500:]
+        assert f"coherence={mode}" in pr.stderr
+        if mode == "auto":
+            assert "re-imposed on the device from now on" in pr.stderr          # the imprint was verified and adopted
+        rsts = sorted(f for f in os.listdir(os.path.join(tmp, "run")) if f.endswith(".rst"))
+        dumps[mode] = [read_rst(os.path.join(tmp, "run", f), nx, 1 if ion else 0, ion) for f in rsts]
+        shutil.rmtree(tmp)
+    a, b = dumps["step"], dumps["auto"]
+    assert len(a) == len(b) and len(a) >= 4, (len(a), len(b))                   # initial, >= 2 in the loop, final
+    mid = [d["nstep"] for d in a[1:-1]]
+    assert any(n > 2 for n in mid), mid                                         # at least one after auto took over
+    for x, y in zip(a, b):
+        assert x["nstep"] == y["nstep"] and x["time"] == y["time"] and x["dt"] == y["dt"]
+        assert np.array_equal(x["U"], y["U"], equal_nan=True)
+        if ion:
+            assert np.array_equal(x["edgeflux"], y["edgeflux"])

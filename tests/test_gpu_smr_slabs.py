@@ -47,6 +47,11 @@ def dom(n, nx, disp=None):
     ("ifront", ["job/num_domains=2"] + dom(1, (16, 8, 16)) + dom(2, (16, 8, 16), (8, 4, 8)), None, 3),
     # the refined level is lit through the coarse->fine hand-off (ifront's rays die in the first zone)
     ("ioniz_sphere", ["job/num_domains=2"] + dom(1, (32, 32, 32)) + dom(2, (32, 28, 24), (16, 18, 20)) + ["problem/rp=2.1e10"], None, 3),
+    # rays of 64 zones on both levels: the one-kernel sub-cycle, one all-gather of the ranks' reduction words per sub-cycle,
+    # a rank without zones of a level following the control flow from the gathered words (MeshDriver._ion_radtransfer_fused)
+    ("ifront", ["job/num_domains=2"] + dom(1, (64, 8, 16)) + dom(2, (64, 8, 16), (32, 4, 8)), None, 3),
+    ("ifront", ["job/num_domains=2"] + dom(1, (64, 8, 24)) + dom(2, (64, 8, 8), (32, 4, 4)), (0, 12, 24), 3),   # rank 1 holds no zones of level 1
+    ("ioniz_sphere", ["job/num_domains=2"] + dom(1, (64, 32, 32)) + dom(2, (64, 28, 24), (32, 18, 20)) + ["problem/rp=2.1e10"], None, 2),
 ])
 def test_two_slab_stacks_equal_one_mesh(problem, overrides, cuts, nsteps):
     import torch.multiprocessing as mp
