@@ -473,8 +473,11 @@ def main():
                 # this same command (profiles/r02_traffic.json); only valid for the workload it was taken on
                 traffic = None
                 try:
-                    tj = json.load(open(os.path.join(ROOT, "profiles", "r02_traffic.json")))
-                    if tj.get("workload") == f"{a.problem} {nx}x{nx}x{nx3}" and a.integrator == "ctu" and world == 1:
+                    # (the PMC passes were taken in the stationary regime and in the burst regime of `--spinup 19`)
+                    tf = "r02_traffic.json" if a.spinup == "auto" else ("r02_burst_traffic.json" if a.spinup == "19" else None)
+                    tj = json.load(open(os.path.join(ROOT, "profiles", tf)))
+                    if tj.get("workload", "").startswith(f"{a.problem} {nx}x{nx}x{nx3}") and a.integrator == "ctu" and a.order == 2 and world == 1 \
+                            and not a.ionized_slab and not a.strict:
                         traffic = tj["kernels"].get(dom)
                 except Exception:
                     pass
