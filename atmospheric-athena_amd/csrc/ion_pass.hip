@@ -280,6 +280,9 @@ struct Ops { Real d, ke, E, s, fp, e0, x0, vm; unsigned short sg; };
 #ifndef AA_ION_PREFETCH
 #define AA_ION_PREFETCH 0            /* 1: next tile's operands in flight during this tile's arithmetic (17 more VGPRs) */
 #endif
+#ifndef AA_ION_PREFETCH_HALF
+#define AA_ION_PREFETCH_HALF 0       /* the same for the first / closing passes (which have the registers to spare) */
+#endif
 #ifndef AA_ION_PAR_LDS
 #define AA_ION_PAR_LDS 1
 #endif
@@ -357,9 +360,8 @@ k_ion_pass(DevGrid g, IonPar p_arg, Real flux0, int from_edgeflux, const DevScal
     bool nhave = true;
     if (nt == ntile) { nt = 0; nray = ray + nwaves_u; nhave = nray < nrays_u; if (nhave) nrow = row_of(nray); }
     Ops no; long nm = 0; bool nin = false;
-#if AA_ION_PREFETCH
-    if (nhave) load(nrow, nt, no, nm, nin);                  // in flight during this tile's arithmetic
-#endif
+    constexpr bool PF = (UPD && SWP) ? (AA_ION_PREFETCH != 0) : (AA_ION_PREFETCH_HALF != 0);
+    if (PF && nhave) load(nrow, nt, no, nm, nin);            // in flight during this tile's arithmetic
 #if AA_ION_PAR_LDS
 #define PAR_HERE(name) int name##_off = 0; asm volatile("" : "+v"(name##_off)); \
                        const IonPar &name = *(const IonPar*)((const char*)&s_par + name##_off)
@@ -453,9 +455,7 @@ k_ion_pass(DevGrid g, IonPar p_arg, Real flux0, int from_edgeflux, const DevScal
       if (c.E != E0) Uq(g,4)[m] = c.E;
       if (c.s != s0) Uq(g,5)[m] = c.s;
     }
-#if !AA_ION_PREFETCH
-    if (nhave) load(nrow, nt, no, nm, nin);
-#endif
+    if (!PF && nhave) load(nrow, nt, no, nm, nin);
     ray = nray; t = nt; have = nhave; row = nrow; o = no; m = nm; in = nin;
   }
 

@@ -134,3 +134,29 @@ def test_restart_levels_round_trip(aa, tmp_path):
     R.write_rst(p, R.par_dump(par), 9, 2.5, 0.125, levels[0][0], levels[0][1])
     r1 = R.read_rst_levels(p, nxs[:1], 1, True)
     assert np.array_equal(r1["levels"][0][0], levels[0][0])
+
+
+def test_bench_helpers():
+    """bench.py's host-side bookkeeping: every kernel stage the library can report has a byte figure and a phase, the
+    dominant kernel is the argmax of total time, the MPI baseline splits ranks over x2 and x3 only."""
+    import sys
+    sys.path.insert(0, ROOT)
+    import bench
+    assert bench.kernel_class("correct_all") == "hydro" and bench.kernel_class("sweep_x3") == "hydro" and bench.kernel_class("vl_predict") == "hydro"
+    assert bench.kernel_class("ion_pass") == "subcycle" and bench.kernel_class("ion_pass_begin") == "subcycle" and bench.kernel_class("ray_sweep_rates") == "subcycle"
+    assert bench.kernel_class("ion_begin") == "ion_step" and bench.kernel_class("new_dt") == "other" and bench.kernel_class("bvals_mhd") == "other"
+    # the stage names api.hip / slabs.hip / smr.hip hand to the profiler
+    import re
+    names = set()
+    for f in ("api.hip", "slabs.hip", "smr.hip"):
+        names |= set(re.findall(r'Scope \w+\(\w+, "(\w+)"\)', open(os.path.join(ROOT, "atmospheric-athena_amd", "csrc", f)).read()))
+    names |= {"ion_pass", "ion_pass_last", "ion_pass_begin", "ion_pass_first"}          # chosen at run time in aa_ion_pass
+    unknown = {n for n in names if n not in bench.KERNEL_BYTES and not n.startswith("halo_") and not n.startswith("smr_")
+               and n not in ("restrict", "flux_correct", "prolongate", "ion_restrict", "ionflux_prolong")}
+    assert not unknown, unknown
+    prof = {"correct_all": (500.0, 20), "ion_pass": (900.0, 300), "bvals_mhd": (5000.0, 40), "ion_update": (100.0, 5)}
+    assert bench.dominant_kernel(prof) == "ion_pass"                      # bvals_mhd has no per-zone byte figure
+    assert bench.KERNEL_BYTES["ion_update"] > 0 and bench.KERNEL_BYTES["ion_rates"] > 0     # (round 1 lost these two to a trailing comment)
+    assert bench._rank_grid(16, 128) == (4, 4) and bench._rank_grid(8, 128) == (2, 4) and bench._rank_grid(1, 128) == (1, 1)
+    p2, p3 = bench._rank_grid(12, 96)
+    assert p2 * p3 <= 12 and 96 % p2 == 0 and 96 % p3 == 0
