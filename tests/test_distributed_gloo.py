@@ -68,14 +68,69 @@ class OracleEngine:
     def download(self): return self.s.U.copy()
 
 
-def _worker(rank, world, port, problem, overrides, nsteps, q):
+class OracleFusedEngine(OracleEngine):
+    """The pass / gather / pick / fetch protocol of the one-kernel radiation sub-cycle (include/athena_amd.h, aa_ion_pass
+    ...; driver.Driver._ion_radtransfer_fused) emulated on the oracle's phases: pass n applies update(n-1) with the step
+    the last pick chose and -- unless that step was cut back to the limit -- runs sweep(n) + rates(n); the slab's words go
+    through ONE all-gather; the pick folds them, books the applied update and chooses the next step.  What is tested is
+    the driver's control flow and its collectives, not the GPU's arithmetic."""
+    ion_fused = True
+    BIG = 1.7976931348623157e308
+
+    def __init__(self, grid):
+        super().__init__(grid)
+        t = self.torch
+        self.words = t.zeros(8, dtype=t.float64)
+        self.words_all = t.zeros(8 * grid.nranks, dtype=t.float64)
+        self.sc = dict(dt_sel=0.0, hit=False, dt_done=0.0, dt_applied=0.0, hit_applied=False, count=0, dt_hydro=self.BIG)
+
+    def ion_pass(self, update, sweep):
+        cnt, dth, dtc, dtt = 0, self.BIG, self.BIG, self.BIG
+        if update:
+            cnt, dth = OracleEngine.ion_update(self, self.sc["dt_sel"])
+            if self.sc["hit"]:
+                sweep = False                         # (on the device: the form of the pass without a further sweep stays)
+        if sweep:
+            dtc, dtt = self.s.ion_rates()
+        self.words[:] = self.torch.tensor([dtc, dtt, dth, float(cnt), 0, 0, 0, 0], dtype=self.torch.float64)
+
+    def ion_pick(self, dist, first, limit):
+        if dist is None:
+            self.words_all[:8] = self.words
+            n = 1
+        else:
+            dist.all_gather_into_tensor(self.words_all, self.words)
+            n = self.cfg.nranks
+        W = self.words_all.tolist()
+        dt_chem, dt_therm, dt_hydro, count = min(W[0::8][:n]), min(W[1::8][:n]), min(W[2::8][:n]), sum(W[3::8][:n])
+        sc = self.sc
+        if not first:
+            sc["dt_applied"], sc["hit_applied"] = sc["dt_sel"], sc["hit"]
+            sc["dt_done"] = sc["dt_done"] + sc["dt_sel"]
+        else:
+            sc["dt_done"] = 0.0
+        sc["count"], sc["dt_hydro"] = int(count), dt_hydro
+        dt = dt_therm if dt_therm < dt_chem else dt_chem
+        hit = False
+        if sc["dt_done"] + dt > limit:
+            dt = limit - sc["dt_done"]; hit = True
+        sc["dt_sel"], sc["hit"] = dt, hit
+
+    def ion_fetch(self):
+        sc = self.sc
+        return sc["dt_applied"], sc["hit_applied"], 0.0, 0.0, sc["count"], sc["dt_hydro"], False
+
+    def ion_finish(self): pass
+
+
+def _worker(rank, world, port, problem, overrides, nsteps, q, fused=False):
     import torch.distributed as dist
     dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
     aa = importlib.import_module("atmospheric-athena_amd")
     driver = importlib.import_module("atmospheric-athena_amd.driver")
     import orc
     run = aa.config.load(os.path.join(orc.DECKS, "athinput." + problem), overrides, problem)
-    d = driver.Driver(run, OracleEngine, rank, world)
+    d = driver.Driver(run, OracleFusedEngine if fused else OracleEngine, rank, world)
     d.start()
     its = [d.step() for _ in range(nsteps)]
     q.put((rank, d.grid.disp[2], d.grid.Nx[2], d.eng.download()[4:-4, 4:-4, 4:-4].copy(), its, d.time, d.dt, d.history()))
@@ -87,12 +142,12 @@ def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
 
-def run_slabs(problem, overrides, nsteps, world):
+def run_slabs(problem, overrides, nsteps, world, fused=False):
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    ps = [ctx.Process(target=_worker, args=(r, world, port, problem, overrides, nsteps, q)) for r in range(world)]
+    ps = [ctx.Process(target=_worker, args=(r, world, port, problem, overrides, nsteps, q, fused)) for r in range(world)]
     for p in ps:
         p.start()
     res = [q.get(timeout=300) for _ in range(world)]
@@ -102,23 +157,35 @@ def run_slabs(problem, overrides, nsteps, world):
     return sorted(res)
 
 
-@pytest.mark.parametrize("problem,nx,nsteps,world", [
-    ("blast", (12, 10, 16), 3, 2),        # periodic in x3: the 2-rank wrap sends both halos to one peer
-    ("blast", (10, 8, 18), 2, 3),         # periodic ring of 3, uneven split 6/6/6
-    ("ifront", (16, 8, 12), 3, 2),        # outflow x3 + ion radiation: reductions every sub-cycle
-    ("ifront", (8, 8, 14), 2, 3),         # remainder cells go to the first slabs: 5/5/4
+@pytest.mark.parametrize("problem,nx,nsteps,world,fused", [
+    ("blast", (12, 10, 16), 3, 2, False),        # periodic in x3: the 2-rank wrap sends both halos to one peer
+    ("blast", (10, 8, 18), 2, 3, False),         # periodic ring of 3, uneven split 6/6/6
+    ("ifront", (16, 8, 12), 3, 2, False),        # outflow x3 + ion radiation: reductions every sub-cycle
+    ("ifront", (8, 8, 14), 2, 3, False),         # remainder cells go to the first slabs: 5/5/4
+    ("ifront", (16, 8, 12), 3, 2, True),         # the same through the pass / all-gather / pick / fetch protocol
+    ("ifront", (8, 8, 14), 2, 3, True),
+    ("ioniz_sphere", (20, 20, 20), 2, 2, True),
 ])
-def test_slabs_equal_single_grid(problem, nx, nsteps, world):
+def test_slabs_equal_single_grid(problem, nx, nsteps, world, fused):
     import orc
     ov = [f"domain1/Nx{d + 1}={nx[d]}" for d in range(3)]
     ref = orc.make_sim(problem, ov).start()
     its_ref = [ref.step() for _ in range(nsteps)]
-    res = run_slabs(problem, ov, nsteps, world)
+    res = run_slabs(problem, ov, nsteps, world, fused)
     nv = 5 + ref.grid.run.nscal
     hist = importlib.import_module("atmospheric-athena_amd.history")
     href = hist.sums_from_block(ref.active, ref.grid.run.dx, ref.grid.run.nscal)
     for rank, disp, n3, U, its, t, dt, h in res:
         assert its == its_ref
+        if problem == "ioniz_sphere":
+            # a slab's MinX is accumulated (init_grid.c:104-111): positions -- hence potential and the Userwork core --
+            # differ in the last bit from the single Grid's, as in the reference under MPI
+            assert abs(dt / ref.dt - 1) < 1e-9
+            a, b = U[..., :nv], ref.active[disp:disp + n3, :, :, :nv]
+            assert np.array_equal(np.isnan(a), np.isnan(b))
+            scale = np.nanmax(np.abs(ref.active[..., :nv]), axis=(0, 1, 2))
+            assert (np.nanmax(np.abs(a - b), axis=(0, 1, 2)) / scale).max() < 1e-8
+            continue
         assert t == ref.time and dt == ref.dt
         assert np.array_equal(U[..., :nv], ref.active[disp:disp + n3, :, :, :nv]), f"slab {rank} differs"
         # history sums: SUM over slabs == the single-Grid integrals (to summation-order rounding)
