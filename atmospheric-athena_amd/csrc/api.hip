@@ -116,7 +116,7 @@ int aa_create(const aa_params *p, aa_grid **out)
   // one pool: U 6 | LR 36 | F 18 | eta 3 | dhalf 1 | phi 4 | ion 5 + sign(1) | edgeflux
   const size_t nc = (size_t)d.nc;
   const size_t nef = (size_t)(d.Nx1 + 1)*(d.Nx2 + 1)*(d.Nx3 + 1);
-  size_t n = nc*(6 + 36 + 18 + 3 + 1 + 4);
+  size_t n = nc*(6 + 36 + 18 + 5 + 1 + 4);       // eta: 3 + the two edge arrays of k_correct_all
   // the one-kernel sub-cycle wants whole wavefronts along the rays; AA_ION_FUSED forces either path
   { const char *e = getenv("AA_ION_BEGIN_FUSED"); g->ion_begin_fused = e ? atoi(e) != 0 : true; }
   { const char *e = getenv("AA_ION_FUSED");
@@ -134,7 +134,7 @@ int aa_create(const aa_params *p, aa_grid **out)
   g->bytes = (long long)(n*sizeof(Real));
   hipMemset(g->pool, 0, n*sizeof(Real));
   Real *q = g->pool + (pitch_align ? 12 : 0);
-  d.U = q; q += 6*nc; d.LR = q; q += 36*nc; d.F = q; q += 18*nc; d.eta = q; q += 3*nc; d.dhalf = q; q += nc;
+  d.U = q; q += 6*nc; d.LR = q; q += 36*nc; d.F = q; q += 18*nc; d.eta = q; q += 5*nc; d.dhalf = q; q += nc;
   d.phi = q; q += 4*nc;
   if (p->order == 3) { d.slope = q; q += 18*nc; }
   if (p->ion) {

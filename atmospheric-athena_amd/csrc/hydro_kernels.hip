@@ -515,18 +515,21 @@ k_correct_all(DevGrid g, Real dt, int kchunk)
   __shared__ Real s_l[CA_TJ][64];
   constexpr int NV = 5 + NS;
   const int lane = threadIdx.x, row = threadIdx.y;
-  // zones s-1 .. e+1 in every direction get their face states; a block's lane 0 / row 0 is the zone of
-  // the previous block's lane 63 / row CA_TJ-1
-  const int i = g.is - 1 + blockIdx.x*63 + lane, j = g.js - 1 + blockIdx.y*(CA_TJ - 1) + row;
+  // Zones s-1 .. e+1 in every direction get their face states.  Tiles do NOT overlap in x1 / x2 (round 1's did by one
+  // provider lane / row: 64x4 threads for 63x3 zones, 35 % more threads, loads and arithmetic than zones) and start on a
+  // 128-byte line (zone is - 16: the rows' first active zone is line-aligned).  What a tile cannot do alone is the eta of
+  // its own lowest x1 / x2 faces (lane 0, row 0), which needs lambda_l of the zone in the tile before: there the zone
+  // stores its lambda_r in the face's eta slot, the zone before (lane 63 / row CA_TJ-1) its lambda_l in an edge array,
+  // and k_eta_edges turns the pairs into etas afterwards (1/64 + 1/CA_TJ of the faces, < 10 B/zone).
+  const int i = g.is - 16 + blockIdx.x*64 + lane, j = g.js - 1 + blockIdx.y*CA_TJ + row;
   const int k0 = g.ks - 1 + blockIdx.z*kchunk;
   int k1 = k0 + kchunk - 1; if (k1 > g.ke + 1) k1 = g.ke + 1;
   const int kstart = (blockIdx.z == 0) ? k0 : k0 - 1;          // one provider plane below a later chunk
   // idle threads beyond the Grid keep valid addresses (their neighbours may read what they load)
-  const int ic = (i <= g.ie + 2) ? i : g.ie + 2, jc = (j <= g.je + 2) ? j : g.je + 2;
+  const int ic = (i <= g.ie + 2) ? (i < 0 ? 0 : i) : g.ie + 2, jc = (j <= g.je + 2) ? j : g.je + 2;
   const long mcol = (long)jc*g.sJ + ic;
-  const bool in = (i <= g.ie + 1) && (j <= g.je + 1);
-  const bool full_lane = (lane > 0) || (blockIdx.x == 0), full_row = (row > 0) || (blockIdx.y == 0);
-  const bool do1 = in && full_row, do2 = in && full_lane, do3 = in && full_lane && full_row;
+  const bool in = (i >= g.is - 1) && (i <= g.ie + 1) && (j <= g.je + 1);
+  const bool do1 = in, do2 = in, do3 = in;
   Real q[3];
 #pragma unroll
   for (int d = 0; d < 3; d++) q[d] = 0.5*(dt/g.dx[d]);
@@ -576,9 +579,13 @@ k_correct_all(DevGrid g, Real dt, int kchunk)
         for (int n = 0; n < 6; n++) { wm[n] = __shfl_up(ws[n], 1); wp[n] = __shfl_down(ws[n], 1); }
         if (lane == 0)  load_prim_sweep<NS, 0>(g, m - 1, wm);
         if (lane == 63) load_prim_sweep<NS, 0>(g, m + 1, wp);
-        if (do1) cell_states<NS, 0, GRAV, ORD>(g, m, dt, q, cf, wm, ws, wp, full_lane, ll, lr);   // a provider lane's states were stored by the block before
+        if (do1) cell_states<NS, 0, GRAV, ORD>(g, m, dt, q, cf, wm, ws, wp, true, ll, lr);
         const Real lprev = __shfl_up(ll, 1);
-        if (do1 && lane > 0) Ef(g, 0)[m] = 0.5*fabs(lr - lprev);
+        if (do1) {
+          if (lane > 0) { if (i > g.is - 1) Ef(g, 0)[m] = 0.5*fabs(lr - lprev); }
+          else Ef(g, 0)[m] = lr;                        // tile edge: k_eta_edges finishes this face
+          if (lane == 63) Ef(g, 3)[m] = ll;
+        }
       }
       __builtin_amdgcn_sched_barrier(0);
       {   // ---- x2: neighbours through LDS ----
@@ -599,10 +606,14 @@ k_correct_all(DevGrid g, Real dt, int kchunk)
           for (int n = 0; n < NV; n++) wp[n] = s_w[row + 1][n][lane];
           if (!NS) wp[5] = 0.0;
         }
-        if (do2) cell_states<NS, 1, GRAV, ORD>(g, m, dt, q, cf, wm, ws, wp, full_row, ll, lr);    // ... likewise a provider row's
+        if (do2) cell_states<NS, 1, GRAV, ORD>(g, m, dt, q, cf, wm, ws, wp, true, ll, lr);
         s_l[row][lane] = ll;
         __syncthreads();
-        if (do2 && row > 0) Ef(g, 1)[m] = 0.5*fabs(lr - s_l[row - 1][lane]);
+        if (do2) {
+          if (row > 0) Ef(g, 1)[m] = 0.5*fabs(lr - s_l[row - 1][lane]);
+          else if (j > g.js - 1) Ef(g, 1)[m] = lr;      // tile edge, as for x1
+          if (row == CA_TJ - 1) Ef(g, 4)[m] = ll;
+        }
       }
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -616,6 +627,30 @@ k_correct_all(DevGrid g, Real dt, int kchunk)
         g.dhalf[m] = wc[0] - q[0]*cf.dF[0][0] - q[1]*cf.dF[1][0] - q[2]*cf.dF[2][0];
     }
   }
+}
+
+// eta of the faces on the tile edges of k_correct_all: the face's slot holds lambda_r of the zone above it, the edge
+// array lambda_l of the zone below (same expression as inside the tile: integrate_3d_ctu.c:2300-2343)
+template <int D>
+__global__ void __launch_bounds__(256)
+k_eta_edges(DevGrid g)
+{
+  // faces along D at the tile origins after the first; all zones s-1 .. e+1 of the other two directions
+  const int n1 = g.ie - g.is + 3, n2 = g.je - g.js + 3, n3 = g.ke - g.ks + 3;
+  const int nb = (D == 0) ? (g.ie + 1 - (g.is - 16))/64 : (g.je + 1 - (g.js - 1))/CA_TJ;      // tile origins 1 .. nb
+  const long lin = (long)blockIdx.x*blockDim.x + threadIdx.x;
+  int i, j, k;
+  if (D == 0) {
+    if (lin >= (long)nb*n2*n3) return;
+    i = g.is - 16 + 64*(1 + (int)(lin % nb)); j = g.js - 1 + (int)((lin / nb) % n2); k = g.ks - 1 + (int)(lin / ((long)nb*n2));
+  } else {
+    if (lin >= (long)n1*nb*n3) return;
+    i = g.is - 1 + (int)(lin % n1); j = g.js - 1 + CA_TJ*(1 + (int)((lin / n1) % nb)); k = g.ks - 1 + (int)(lin / ((long)n1*nb));
+  }
+  if (i > g.ie + 1 || j > g.je + 1) return;
+  const long m = (long)k*g.sK + (long)j*g.sJ + i, sD = stride<D>(g);
+  Real *e = Ef(g, D);
+  e[m] = 0.5*fabs(e[m] - Ef(g, 3 + D)[m - sD]);
 }
 
 // ---- steps 9b-d: second-pass fluxes with the H-correction -----------------------------------
@@ -1335,9 +1370,12 @@ static void correct_all_impl(const DevGrid &g, Real dt, hipStream_t st)
   const int ni = g.ie - g.is + 3, nj = g.je - g.js + 3, nk = g.ke - g.ks + 3;    // zones s-1 .. e+1
   int kc = 32;
   while (kc > 4 && (long)nblk(ni - 1, 63)*nblk(nj - 1, CA_TJ - 1)*((nk + kc - 1)/kc) < 1024) kc >>= 1;
-  dim3 grid(nblk(ni - 1, 63), nblk(nj - 1, CA_TJ - 1), (nk + kc - 1)/kc), blk(64, CA_TJ);
+  dim3 grid(nblk(ni + 15, 64), nblk(nj, CA_TJ), (nk + kc - 1)/kc), blk(64, CA_TJ);
   if (g.slope) hipLaunchKernelGGL((k_correct_all<NS, GRAV, 3>), grid, blk, 0, st, g, dt, kc);
   else         hipLaunchKernelGGL((k_correct_all<NS, GRAV, 2>), grid, blk, 0, st, g, dt, kc);
+  const long nb1 = (g.ie + 1 - (g.is - 16))/64, nb2 = (g.je + 1 - (g.js - 1))/CA_TJ;
+  if (nb1 > 0) hipLaunchKernelGGL((k_eta_edges<0>), dim3(nblk(nb1*nj*nk, 256)), dim3(256), 0, st, g);
+  if (nb2 > 0) hipLaunchKernelGGL((k_eta_edges<1>), dim3(nblk((long)ni*nb2*nk, 256)), dim3(256), 0, st, g);
 }
 void launch_correct_all(const DevGrid &g, int nscal, Real dt, bool grav, hipStream_t st)
 {

@@ -77,3 +77,14 @@ def test_two_ranks_rehearsed_on_one_gpu(strong):
     assert d["config"]["zones_per_gpu"] == (64 ** 3 // 2 if strong else 64 ** 3)
     assert d["state_check"]["ok"] is True
     assert d["host_syncs_per_subcycle"] <= 1.0 + 1e-9, d["host_syncs_per_subcycle"]
+
+
+def test_two_ranks_rehearsed_on_one_gpu_smr():
+    """bench.py --smr --gpus 2 (BASELINE configs[4] across GPUs: every level cut at the same root planes, MeshDriver), both
+    ranks on cuda:0 over gloo: the code path the driver would run on a multi-GPU node."""
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    d = run_bench("--gpus", "2", "--smr", "--nx", "64", "--steps", "2", "--warmup", "1", env={"AA_BENCH_REHEARSAL": "1"},
+                  launcher=("-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                            "--master-port", str(port)))
+    assert d["n_gpus"] == 2 and d["value"] > 0 and "2-level SMR" in d["config"]["workload"]
+    assert all(len(t) == 2 and min(t) >= 1 for t in d["config"]["subcycle_trace_per_level"])
