@@ -409,10 +409,41 @@ int aa_new_dt(aa_grid *g)
   return 0;
 }
 
+// The part of the step that needs none of the x3 neighbours' planes: the first-pass x1 and x2 sweeps of the k-planes
+// ks .. ke (a pencil along x1 or x2 lies in one plane).  A multi-GPU caller posts the x3 halo, calls this, waits for the
+// halo, unpacks it and calls aa_integrate_3d_ctu, which then sweeps only the four ghost planes in x1 / x2: the messages
+// travel under ~10 ms of kernels at 512^3.  Same bits as without the call.  Does nothing (returns 0) where the split
+// does not apply: composite Grids, third order (the slope arrays come first), the unfused correct / update chains, VL.
+int aa_integrate_begin(aa_grid *g)
+{
+  if (!g->slab.empty() || g->p.integrator != 0 || g->d.slope || !g->correct_all || !g->fused_update || g->inner_swept) return 0;
+  const DevGrid &d = g->d; const int ns = g->p.nscal; const Real dt = g->dt;
+  const int nk = d.ke - d.ks + 1;
+  { Scope s(g, "sweep_x2"); launch_sweep(d, ns, 1, dt, g->grav, g->st, 2, nk); }
+  { Scope s(g, "sweep_x1"); launch_sweep(d, ns, 0, dt, g->grav, g->st, 2, nk); }
+  g->inner_swept = true;
+  g->inner_dt = dt;
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
 int aa_integrate_3d_ctu(aa_grid *g)
 {
   if (!g->slab.empty()) return slabs_integrate(g, 0);
   const DevGrid &d = g->d; const int ns = g->p.nscal; const Real dt = g->dt;
+  if (g->inner_swept) {      // aa_integrate_begin did the planes ks .. ke: the two ghost planes either side remain
+    if (g->inner_dt != dt) return fail(-1, "[aa_integrate_3d_ctu]: dt changed after aa_integrate_begin");
+    g->inner_swept = false;
+    const int nk = d.ke - d.ks + 1;
+    { Scope s(g, "sweep_x2"); launch_sweep(d, ns, 1, dt, g->grav, g->st, 0, 2); launch_sweep(d, ns, 1, dt, g->grav, g->st, 2 + nk, 2); }
+    { Scope s(g, "sweep_x1"); launch_sweep(d, ns, 0, dt, g->grav, g->st, 0, 2); launch_sweep(d, ns, 0, dt, g->grav, g->st, 2 + nk, 2); }
+    { Scope s(g, "sweep_x3"); launch_sweep(d, ns, 2, dt, g->grav, g->st); }
+    { Scope s(g, "correct_all"); launch_correct_all(d, ns, dt, g->grav, g->st); }
+    Scope s(g, "flux2_update");
+    launch_flux2_update(d, ns, dt, g->grav, g->keep_flux ? &g->keep : nullptr, g->st);
+    HIPCHK(hipGetLastError());
+    return 0;
+  }
   if (d.slope) { Scope s(g, "ppm_slopes"); for (int dir = 0; dir < 3; dir++) launch_slopes(d, ns, dir, g->st); }
   // x2 and x3 first, so that the x1 sweep can do its first pass and its correct pass in one go
   { Scope s(g, "sweep_x2"); launch_sweep(d, ns, 1, dt, g->grav, g->st); }

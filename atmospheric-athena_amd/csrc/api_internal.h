@@ -28,6 +28,8 @@ struct aa_grid {
   int rad_dir = 0, nradplane = 0; aa::Real flux_i = 0;
   int level = 0;                       // DomainS.Level: > 0 only as a level of an aa_mesh
   bool fused_update = false;           // second-pass fluxes + update in one kernel (AA_FUSED_UPDATE=0 at aa_create: the unfused chain)
+  bool inner_swept = false;            // aa_integrate_begin has done the first-pass x1 / x2 sweeps of the planes ks .. ke
+  double inner_dt = 0.0;               //   ... with this dt
   bool correct_all = false;            // the three correct passes in one kernel (k_correct_all): Grids of 2^21 zones or more, or AA_CORRECT_ALL
   bool fused_rates = false;            // rates evaluated inside the ray sweep (k_ray_sweep<true>): 2^17 rays or more, or AA_FUSED_RATES
   bool ion_fused = false;              // one-kernel radiation sub-cycle with the scan sweep (ion_pass.hip): rays of 64 zones or more, or AA_ION_FUSED

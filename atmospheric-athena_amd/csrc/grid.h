@@ -86,7 +86,8 @@ struct IonPart { Real dt_chem, dt_therm, max_dti, cellcount, neg; };
 
 // ---- launch wrappers (hydro_kernels.hip) ------------------------------------------
 void launch_slopes(const DevGrid &g, int nscal, int dir, hipStream_t st);          // order 3: before the sweeps of a step
-void launch_sweep(const DevGrid &g, int nscal, int dir, Real dt, bool grav, hipStream_t st);
+// first-pass sweep of one direction; for dir 0 / 1 optionally only the k-planes ks-2+koff .. +kcnt-1 (kcnt < 0: to the end)
+void launch_sweep(const DevGrid &g, int nscal, int dir, Real dt, bool grav, hipStream_t st, int koff = 0, int kcnt = -1);
 void launch_correct(const DevGrid &g, int nscal, int dir, Real dt, bool grav, hipStream_t st);
 void launch_sweep_correct_x1(const DevGrid &g, int nscal, Real dt, bool grav, hipStream_t st);
 void launch_correct_all(const DevGrid &g, int nscal, Real dt, bool grav, hipStream_t st);   // the three correct passes in one kernel

@@ -224,12 +224,14 @@ AA_DEV bool decode_zone(const Order o, int ni, int nj, int nk, int &i, int &j, i
 // consecutive in i.  Cells reconstructed: l..u = s-2..e+2; interfaces l+1..u (:179-184).
 template <int NS, int D, bool GRAV, int MODE, int ORD>
 __global__ void __launch_bounds__(256, 3)      // 3 waves per SIMD (168 VGPRs): the kernel is VALU-bound and sits right at that edge
-k_sweep_march(DevGrid g, const Real *src, Real dt, int chunk)
+k_sweep_march(DevGrid g, const Real *src, Real dt, int chunk, int toff, int tcnt)
 {
   static_assert(D == 1 || D == 2, "march kernel is for the strided directions");
   const int ni = g.ie - g.is + 5;                              // i in [is-2, ie+2]
-  const int tlo = (D == 1 ? g.ks : g.js) - 2;
-  const int nt  = (D == 1 ? g.ke - g.ks : g.je - g.js) + 5;
+  // transverse lines toff .. toff+tcnt-1 of the (D == 1 ? ke - ks : je - js) + 5 (the launcher passes all of them, or
+  // for x2 a range of k-planes: see launch_sweep)
+  const int tlo = (D == 1 ? g.ks : g.js) - 2 + toff;
+  const int nt  = tcnt;
   const long lin = (long)blockIdx.x*blockDim.x + threadIdx.x;
   if (lin >= (long)ni*nt) return;
   const int i = g.is - 2 + (int)(lin % ni);
@@ -342,11 +344,11 @@ k_sweep_tile(DevGrid g, const Real *src, Real dt)
 // interfaces between them; blocks overlap by one cell.
 template <int NS, bool GRAV, int MODE, int ORD>
 __global__ void __launch_bounds__(256, 4)
-k_sweep_x1(DevGrid g, const Real *src, Real dt)
+k_sweep_x1(DevGrid g, const Real *src, Real dt, int koff)
 {
   extern __shared__ Real sm[];
   const int B = blockDim.x, t = threadIdx.x;
-  const int j = g.js - 2 + blockIdx.y, k = g.ks - 2 + blockIdx.z;
+  const int j = g.js - 2 + blockIdx.y, k = g.ks - 2 + koff + blockIdx.z;
   const int c0 = g.is - 2 + blockIdx.x*(B - 1);
   const int c = c0 + t;
   const long row = (long)k*g.sK + (long)j*g.sJ;
@@ -521,6 +523,9 @@ k_correct_all(DevGrid g, Real dt, int kchunk)
   // its own lowest x1 / x2 faces (lane 0, row 0), which needs lambda_l of the zone in the tile before: there the zone
   // stores its lambda_r in the face's eta slot, the zone before (lane 63 / row CA_TJ-1) its lambda_l in an edge array,
   // and k_eta_edges turns the pairs into etas afterwards (1/64 + 1/CA_TJ of the faces, < 10 B/zone).
+  // (Tried and dropped: an XCD-aware blockIdx -> tile map that gives each XCD one contiguous run of tiles, so that the tiles
+  //  either side of an edge share an L2.  Measured ABAB at 512^3: 21.3 vs 20.3 ms here, 15.1 vs 14.9 ms in k_flux2_update —
+  //  the plain map, which spreads neighbouring tiles over all eight XCDs and memory channels, is the faster one.)
   const int i = g.is - 16 + blockIdx.x*64 + lane, j = g.js - 1 + blockIdx.y*CA_TJ + row;
   const int k0 = g.ks - 1 + blockIdx.z*kchunk;
   int k1 = k0 + kchunk - 1; if (k1 > g.ke + 1) k1 = g.ke + 1;
@@ -1311,17 +1316,22 @@ unsigned reduce_blocks(long n)
 static inline unsigned nblk8(long n, int b) { unsigned x = nblk(n, b); return ((x + 7u)/8u)*8u; }   // for xcd_block()
 
 template <int NS, bool GRAV, int MODE, int ORD>
-static void sweep_impl_o(const DevGrid &g, const Real *src, int dir, Real dt, hipStream_t st)
+static void sweep_impl_o(const DevGrid &g, const Real *src, int dir, Real dt, hipStream_t st, int koff = 0, int kcnt = -1)
 {
+  // (koff, kcnt): for the x1 and x2 sweeps, the k-planes ks-2+koff .. +kcnt-1 only (every pencil is on its own: any
+  // partition of the planes gives the same bits)
+  const int nk_all = g.ke - g.ks + 5;
+  if (kcnt < 0) kcnt = nk_all - koff;
+  if (kcnt <= 0) return;
   if (dir == 0) {
     const int nfaces = (g.ie - g.is + 1) + 3;          // interfaces l+1..u
     int nb = (nfaces + 254)/255;
     int B = (nfaces + nb - 1)/nb + 1;                  // B-1 interfaces per block
     B = ((B + 63)/64)*64; if (B > 256) B = 256;
     nb = (nfaces + (B - 1) - 1)/(B - 1);
-    dim3 grid(nb, g.je - g.js + 5, g.ke - g.ks + 5);
+    dim3 grid(nb, g.je - g.js + 5, kcnt);
     size_t lds = (size_t)(5 + NS)*(B + 2)*sizeof(Real);
-    hipLaunchKernelGGL((k_sweep_x1<NS, GRAV, MODE, ORD>), grid, dim3(B), lds, st, g, src, dt);
+    hipLaunchKernelGGL((k_sweep_x1<NS, GRAV, MODE, ORD>), grid, dim3(B), lds, st, g, src, dt, koff);
   } else if constexpr (MODE == MODE_CORR) {
     constexpr int BT = 8;     // 8 beats 16 (12.0 ms) despite the 10-rows-for-7-faces halo: more blocks in flight
     const long ni = g.ie - g.is + 5;
@@ -1333,7 +1343,8 @@ static void sweep_impl_o(const DevGrid &g, const Real *src, int dir, Real dt, hi
     else          hipLaunchKernelGGL((k_sweep_tile<NS, 2, GRAV, MODE, BT, ORD>), grid, blk, lds, st, g, src, dt);
   } else if constexpr (MODE == MODE_FLUX1 || MODE == MODE_VL) {
     const long ni = g.ie - g.is + 5;
-    const long nt = (dir == 1 ? g.ke - g.ks : g.je - g.js) + 5;
+    const long nt = (dir == 1 ? kcnt : g.je - g.js + 5);
+    const int toff = (dir == 1 ? koff : 0);
     const int nfaces = (dir == 1 ? g.je - g.js : g.ke - g.ks) + 1 + 3;
     // 32 interfaces per thread amortise the 3-cell start-up of a chunk on big Grids; small Grids need the
     // parallelism more (80^3 has only 110 wavefronts of columns): halve the chunk until the launch has
@@ -1341,16 +1352,16 @@ static void sweep_impl_o(const DevGrid &g, const Real *src, int dir, Real dt, hi
     int chunk = 32;
     while (chunk > 4 && (long)nblk(ni*nt, 64)*((nfaces + chunk - 1)/chunk) < 4096) chunk >>= 1;
     dim3 grid(nblk(ni*nt, 64), (nfaces + chunk - 1)/chunk);
-    if (dir == 1) hipLaunchKernelGGL((k_sweep_march<NS, 1, GRAV, MODE, ORD>), grid, dim3(64), 0, st, g, src, dt, chunk);
-    else          hipLaunchKernelGGL((k_sweep_march<NS, 2, GRAV, MODE, ORD>), grid, dim3(64), 0, st, g, src, dt, chunk);
+    if (dir == 1) hipLaunchKernelGGL((k_sweep_march<NS, 1, GRAV, MODE, ORD>), grid, dim3(64), 0, st, g, src, dt, chunk, toff, (int)nt);
+    else          hipLaunchKernelGGL((k_sweep_march<NS, 2, GRAV, MODE, ORD>), grid, dim3(64), 0, st, g, src, dt, chunk, toff, (int)nt);
   }
 }
 template <int NS, bool GRAV, int MODE>
-static void sweep_impl(const DevGrid &g, const Real *src, int dir, Real dt, hipStream_t st)
+static void sweep_impl(const DevGrid &g, const Real *src, int dir, Real dt, hipStream_t st, int koff = 0, int kcnt = -1)
 {
   // the van Leer integrator is second order only (MODE_VL never sees a slope array)
-  if (MODE != MODE_VL && g.slope) sweep_impl_o<NS, GRAV, MODE, (MODE == MODE_VL ? 2 : 3)>(g, src, dir, dt, st);
-  else sweep_impl_o<NS, GRAV, MODE, 2>(g, src, dir, dt, st);
+  if (MODE != MODE_VL && g.slope) sweep_impl_o<NS, GRAV, MODE, (MODE == MODE_VL ? 2 : 3)>(g, src, dir, dt, st, koff, kcnt);
+  else sweep_impl_o<NS, GRAV, MODE, 2>(g, src, dir, dt, st, koff, kcnt);
 }
 template <int NS>
 static void slopes_impl(const DevGrid &g, int dir, hipStream_t st)
@@ -1386,10 +1397,10 @@ void launch_correct_all(const DevGrid &g, int nscal, Real dt, bool grav, hipStre
 void launch_slopes(const DevGrid &g, int nscal, int dir, hipStream_t st)
 { if (nscal) slopes_impl<1>(g, dir, st); else slopes_impl<0>(g, dir, st); }
 
-void launch_sweep(const DevGrid &g, int nscal, int dir, Real dt, bool grav, hipStream_t st)
+void launch_sweep(const DevGrid &g, int nscal, int dir, Real dt, bool grav, hipStream_t st, int koff, int kcnt)
 {
-  if (nscal) { if (grav) sweep_impl<1, true, MODE_FLUX1>(g, g.U, dir, dt, st); else sweep_impl<1, false, MODE_FLUX1>(g, g.U, dir, dt, st); }
-  else       { if (grav) sweep_impl<0, true, MODE_FLUX1>(g, g.U, dir, dt, st); else sweep_impl<0, false, MODE_FLUX1>(g, g.U, dir, dt, st); }
+  if (nscal) { if (grav) sweep_impl<1, true, MODE_FLUX1>(g, g.U, dir, dt, st, koff, kcnt); else sweep_impl<1, false, MODE_FLUX1>(g, g.U, dir, dt, st, koff, kcnt); }
+  else       { if (grav) sweep_impl<0, true, MODE_FLUX1>(g, g.U, dir, dt, st, koff, kcnt); else sweep_impl<0, false, MODE_FLUX1>(g, g.U, dir, dt, st, koff, kcnt); }
 }
 // x1 first pass + x1 correct pass in one sweep (must run after the x2 and x3 first passes)
 void launch_sweep_correct_x1(const DevGrid &g, int nscal, Real dt, bool grav, hipStream_t st)

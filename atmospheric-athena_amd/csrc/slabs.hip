@@ -34,6 +34,13 @@ struct SlabLink {
   std::vector<Real*> send[2], recv[2];     // halo buffers on every slab's device
   std::vector<hipEvent_t> packed, copied;  // slab's send buffers are full / slab has pulled its neighbours' buffers
   std::vector<bool> copied_valid;
+  // The peer copies run on a stream of their own beside the slab's kernels, and the unpack is left to whoever reads
+  // the ghost planes next (halo_finish): the integrator first sweeps the planes that hold no neighbour data
+  // (aa_integrate_begin), the ion step and new_dt never read them.
+  std::vector<hipStream_t> xfer;
+  std::vector<hipEvent_t> unpacked;        // slab's recv buffers have been unpacked (free for the next copy)
+  std::vector<bool> unpacked_valid;
+  bool halo_due = false;                   // messages posted, ghost planes not yet written
   double *hwords = nullptr;                // pinned: n x AA_ION_WORDS
   DevScalars *hsc = nullptr;               // pinned: n
   std::vector<Real*> dwords_all;           // device: n x AA_ION_WORDS on every slab
@@ -41,6 +48,8 @@ struct SlabLink {
 };
 
 #define SLAB_DEV(L, s) HIPCHK(hipSetDevice((L)->dev[s]))
+static int halo_finish(aa_grid *g);          // the ghost planes of a posted exchange are written before anything reads them
+#define HALO_FLUSH(g) do { int rc_ = halo_finish(g); if (rc_) return rc_; } while (0)
 
 void slabs_push_state(aa_grid *g)
 { for (aa_grid *c : g->slab) { c->time = g->time; c->dt = g->dt; c->nstep = g->nstep; } }
@@ -87,6 +96,7 @@ int slabs_create(const aa_params *p, int nslab, aa_grid **out)
   for (aa_grid *c : g->slab) if (c->ion_fused != g->ion_fused) { aa_destroy(g); return aa_fail(-1, "[aa_create]: slabs disagree on the sub-cycle path"); }
   L->halo = (size_t)aa_halo_doubles(g->slab[0]);
   L->packed.resize(nslab); L->copied.resize(nslab); L->copied_valid.assign(nslab, false);
+  L->xfer.assign(nslab, nullptr); L->unpacked.resize(nslab); L->unpacked_valid.assign(nslab, false);
   L->dwords_all.assign(nslab, nullptr);
   for (int w = 0; w < 2; w++) { L->send[w].assign(nslab, nullptr); L->recv[w].assign(nslab, nullptr); }
   for (int s = 0; s < nslab; s++) {
@@ -98,6 +108,8 @@ int slabs_create(const aa_params *p, int nslab, aa_grid **out)
     HIPCHK(hipMalloc(&L->dwords_all[s], (size_t)nslab*AA_ION_WORDS*sizeof(Real)));
     HIPCHK(hipEventCreateWithFlags(&L->packed[s], hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&L->copied[s], hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&L->unpacked[s], hipEventDisableTiming));
+    HIPCHK(hipStreamCreateWithFlags(&L->xfer[s], hipStreamNonBlocking));
     for (int o : {L->lo[s], L->hi[s]})
       if (o >= 0 && L->dev[o] != L->dev[s]) {
         int can = 0;
@@ -121,6 +133,7 @@ void slabs_destroy(aa_grid *g)
   for (size_t s = 0; s < g->slab.size(); s++) {
     hipSetDevice(L->dev[s]);
     hipStreamSynchronize(g->slab[s]->st);
+    if (s < L->xfer.size() && L->xfer[s]) { hipStreamSynchronize(L->xfer[s]); hipStreamDestroy(L->xfer[s]); hipEventDestroy(L->unpacked[s]); }
     if (s < L->send[0].size()) for (int w = 0; w < 2; w++) { if (L->send[w][s]) hipFree(L->send[w][s]); if (L->recv[w][s]) hipFree(L->recv[w][s]); }
     if (s < L->dwords_all.size() && L->dwords_all[s]) hipFree(L->dwords_all[s]);
     if (s < L->packed.size() && L->packed[s]) { hipEventDestroy(L->packed[s]); hipEventDestroy(L->copied[s]); }
@@ -136,6 +149,7 @@ void slabs_destroy(aa_grid *g)
 
 int slabs_sync(aa_grid *g)
 {
+  HALO_FLUSH(g);
   SlabLink *L = g->link;
   for (int s = 0; s < L->n; s++) { SLAB_DEV(L, s); HIPCHK(hipStreamSynchronize(g->slab[s]->st)); }
   return 0;
@@ -145,6 +159,7 @@ long long slabs_device_bytes(const aa_grid *g) { return g->bytes; }
 // ---- host transfers: k-plane ranges of the caller's block --------------------------------------------
 int slabs_upload_cons(aa_grid *g, const double *U)
 {
+  HALO_FLUSH(g);
   SlabLink *L = g->link;
   const size_t pl = (size_t)(g->p.Nx[0] + 2*AA_NGHOST)*(g->p.Nx[1] + 2*AA_NGHOST)*(5 + g->p.nscal);
   for (int s = 0; s < L->n; s++) {
@@ -156,6 +171,7 @@ int slabs_upload_cons(aa_grid *g, const double *U)
 }
 int slabs_download_cons(aa_grid *g, double *U)
 {
+  HALO_FLUSH(g);
   SlabLink *L = g->link;
   const size_t pl = (size_t)(g->p.Nx[0] + 2*AA_NGHOST)*(g->p.Nx[1] + 2*AA_NGHOST)*(5 + g->p.nscal);
   for (int s = 0; s < L->n; s++) {
@@ -206,6 +222,7 @@ int slabs_set_grav_tables(aa_grid *g, const double *pc, const double *p1, const 
 
 int slabs_set_pinned_cells(aa_grid *g, long long n, const long long *index, const double *values)
 {
+  HALO_FLUSH(g);
   SlabLink *L = g->link;
   const int nvar = 5 + g->p.nscal;
   const long long pl = (long long)(g->p.Nx[0] + 2*AA_NGHOST)*(g->p.Nx[1] + 2*AA_NGHOST);
@@ -230,6 +247,7 @@ int slabs_set_pinned_cells(aa_grid *g, long long n, const long long *index, cons
 }
 int slabs_apply_pinned_cells(aa_grid *g)
 {
+  HALO_FLUSH(g);
   SlabLink *L = g->link;
   for (int s = 0; s < L->n; s++) { SLAB_DEV(L, s); int rc = aa_apply_pinned_cells(g->slab[s]); if (rc) return rc; }
   return 0;
@@ -249,13 +267,39 @@ int slabs_bvals_ionrad(aa_grid *g)
 }
 
 // ---- ghost zones: bvals_mhd.c:423-493 between slabs ---------------------------------------------------
-static int exchange_x3(aa_grid *g)
+// MPI_Waitall + unpack_ix3 / unpack_ox3: the slab's kernel stream waits for its copies and writes its ghost planes
+static int halo_finish(aa_grid *g)
 {
   SlabLink *L = g->link;
+  if (!L->halo_due) return 0;
+  L->halo_due = false;
+  const int nvar = 5 + g->p.nscal;
+  for (int r = 0; r < L->n; r++) {
+    if (L->lo[r] < 0 && L->hi[r] < 0) continue;
+    SLAB_DEV(L, r);
+    aa_grid *c = g->slab[r];
+    HIPCHK(hipStreamWaitEvent(c->st, L->copied[r], 0));
+    if (L->lo[r] >= 0) launch_unpack_x3(c->d, nvar, c->d.ks - AA_NGHOST, L->recv[0][r], c->st);
+    if (L->hi[r] >= 0) launch_unpack_x3(c->d, nvar, c->d.ke + 1, L->recv[1][r], c->st);
+    HIPCHK(hipEventRecord(L->unpacked[r], c->st));
+    L->unpacked_valid[r] = true;
+  }
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+// pack_ix3 / pack_ox3 + the messages (MPI_Isend / MPI_Irecv): packed on the kernel streams, pulled by the receivers on
+// their copy streams
+static int halo_post(aa_grid *g)
+{
+  SlabLink *L = g->link;
+  HALO_FLUSH(g);
   const int nvar = 5 + g->p.nscal;
   const size_t bytes = L->halo*sizeof(Real);
+  bool any = false;
   for (int s = 0; s < L->n; s++) {
     if (L->lo[s] < 0 && L->hi[s] < 0) continue;
+    any = true;
     SLAB_DEV(L, s);
     aa_grid *c = g->slab[s];
     // my send buffers are free once both neighbours have pulled the previous exchange out of them
@@ -267,22 +311,22 @@ static int exchange_x3(aa_grid *g)
   for (int r = 0; r < L->n; r++) {
     if (L->lo[r] < 0 && L->hi[r] < 0) continue;
     SLAB_DEV(L, r);
-    aa_grid *c = g->slab[r];
+    hipStream_t x = L->xfer[r];
+    if (L->unpacked_valid[r]) HIPCHK(hipStreamWaitEvent(x, L->unpacked[r], 0));     // my recv buffers are free
     if (L->lo[r] >= 0) {         // the lower neighbour's upper planes fill my lower ghost planes
       const int o = L->lo[r];
-      HIPCHK(hipStreamWaitEvent(c->st, L->packed[o], 0));
-      HIPCHK(hipMemcpyPeerAsync(L->recv[0][r], L->dev[r], L->send[1][o], L->dev[o], bytes, c->st));
-      launch_unpack_x3(c->d, nvar, c->d.ks - AA_NGHOST, L->recv[0][r], c->st);
+      HIPCHK(hipStreamWaitEvent(x, L->packed[o], 0));
+      HIPCHK(hipMemcpyPeerAsync(L->recv[0][r], L->dev[r], L->send[1][o], L->dev[o], bytes, x));
     }
     if (L->hi[r] >= 0) {
       const int o = L->hi[r];
-      HIPCHK(hipStreamWaitEvent(c->st, L->packed[o], 0));
-      HIPCHK(hipMemcpyPeerAsync(L->recv[1][r], L->dev[r], L->send[0][o], L->dev[o], bytes, c->st));
-      launch_unpack_x3(c->d, nvar, c->d.ke + 1, L->recv[1][r], c->st);
+      HIPCHK(hipStreamWaitEvent(x, L->packed[o], 0));
+      HIPCHK(hipMemcpyPeerAsync(L->recv[1][r], L->dev[r], L->send[0][o], L->dev[o], bytes, x));
     }
-    HIPCHK(hipEventRecord(L->copied[r], c->st));
+    HIPCHK(hipEventRecord(L->copied[r], x));
     L->copied_valid[r] = true;
   }
+  L->halo_due = any;
   HIPCHK(hipGetLastError());
   return 0;
 }
@@ -290,8 +334,9 @@ static int exchange_x3(aa_grid *g)
 int slabs_bvals_mhd(aa_grid *g)
 {
   SlabLink *L = g->link;
+  HALO_FLUSH(g);
   for (int s = 0; s < L->n; s++) { SLAB_DEV(L, s); int rc = aa_bvals_mhd(g->slab[s]); if (rc) return rc; }   // x1, x2, physical x3
-  return exchange_x3(g);        // after x1 and x2, all i and j incl. ghosts: the corners travel (bvals_mhd.c:170)
+  return halo_post(g);          // after x1 and x2, all i and j incl. ghosts: the corners travel (bvals_mhd.c:170)
 }
 
 // one (*BCFun)(pGrid) call of bvals_mhd.c:196-420 for drivers that interleave user boundary functions: the slabs'
@@ -299,6 +344,7 @@ int slabs_bvals_mhd(aa_grid *g)
 int slabs_bvals_mhd_side(aa_grid *g, int dir, int side)
 {
   SlabLink *L = g->link;
+  HALO_FLUSH(g);
   if (dir < 2) {
     for (int s = 0; s < L->n; s++) { SLAB_DEV(L, s); int rc = aa_bvals_mhd_side(g->slab[s], dir, side); if (rc) return rc; }
     return 0;
@@ -306,7 +352,7 @@ int slabs_bvals_mhd_side(aa_grid *g, int dir, int side)
   const int s = side ? L->n - 1 : 0;
   SLAB_DEV(L, s);
   int rc = aa_bvals_mhd_side(g->slab[s], dir, side); if (rc) return rc;
-  return side == 0 ? exchange_x3(g) : 0;
+  return side == 0 ? halo_post(g) : 0;
 }
 
 // ---- time step: new_dt.c:72-177 ----------------------------------------------------------------------
@@ -353,6 +399,10 @@ int slabs_integrate(aa_grid *g, int vl)
 {
   SlabLink *L = g->link;
   slabs_push_state(g);
+  if (L->halo_due) {     // the ghost planes are still on their way: first the sweeps that do not read them
+    if (!vl) for (int s = 0; s < L->n; s++) { SLAB_DEV(L, s); int rc = aa_integrate_begin(g->slab[s]); if (rc) return rc; }
+    HALO_FLUSH(g);
+  }
   for (int s = 0; s < L->n; s++) {
     SLAB_DEV(L, s);
     int rc = vl ? aa_integrate_3d_vl(g->slab[s]) : aa_integrate_3d_ctu(g->slab[s]);

@@ -61,6 +61,7 @@ class HipEngine:
     def bvals_ionrad(self): self.g.bvals_ionrad()
     def new_dt_local(self) -> float: return self.g.new_dt_local()
     def integrate(self): self.g.integrate()
+    def integrate_begin(self): self.g.integrate_begin()
     def userwork(self): self.g.apply_pinned_cells()
     def ion_begin(self): self.g.ion_begin()
     def ion_rates(self): return self.g.ion_rates()
@@ -112,6 +113,7 @@ class Driver:
         self.eng = engine_factory(self.grid) if engine_factory else HipEngine(self.grid, device, strict)
         self.time, self.dt, self.nstep = 0.0, 0.0, 0
         self.niter_trace: List[int] = []
+        self._halo = None         # x3 messages in flight (post_x3 .. finish_x3)
         self._py_syncs = 0        # host round trips of collectives issued from here (bench: host_syncs_per_step)
         # AA_FORCE_DISTRIBUTED=1 runs the Python-orchestrated loop (with its collectives) even on one
         # rank: used to rehearse the N>1 code path on a single GPU
@@ -160,6 +162,14 @@ class Driver:
 
     def exchange_x3(self):
         """bvals_mhd.c:423-493 for the x3 direction."""
+        self.post_x3()
+        self.finish_x3()
+
+    def post_x3(self):
+        """The sends and receives of bvals_mhd.c:423-493 (pack_ix3 / pack_ox3, MPI_Isend / MPI_Irecv) without the wait.
+        With RCCL the messages travel on the communicator's stream from here on; finish_x3() makes the kernel stream
+        wait for them and unpacks.  What is queued in between must not touch the x3 ghost planes or the buffers."""
+        assert self._halo is None
         if not self.distributed or (self.grid.lx3 < 0 and self.grid.rx3 < 0):
             return
         g, dist = self.grid, self.dist
@@ -192,7 +202,15 @@ class Driver:
             if g.rx3 >= 0:
                 ops.append(dist.P2POp(dist.isend, out(1), g.rx3, tag=1))
                 ops.append(dist.P2POp(dist.irecv, inn(1), g.rx3, tag=0))
-        for w in dist.batch_isend_irecv(ops):
+        self._halo = (dist.batch_isend_irecv(ops), rbuf)
+
+    def finish_x3(self):
+        """MPI_Waitall + unpack_ix3 / unpack_ox3 of bvals_mhd.c:423-493."""
+        if self._halo is None:
+            return
+        works, rbuf = self._halo
+        self._halo = None
+        for w in works:
             w.wait()
         for side in (0, 1):
             if side in rbuf:
@@ -202,10 +220,12 @@ class Driver:
                 self.eng.unpack_x3(side)
 
     # ---- the reference's call sites ---------------------------------------------------------
-    def bvals_mhd(self, exchange: bool = True):
+    def bvals_mhd(self, exchange: bool = True, wait: bool = True):
         self.eng.bvals_local()      # x1, x2 and physical x3 faces
         if exchange:
-            self.exchange_x3()
+            self.post_x3()
+            if wait:
+                self.finish_x3()
 
     def new_dt(self):               # new_dt.c:169-185
         dtc = self._min(self.eng.new_dt_local())[0] if self.distributed else self.eng.new_dt_local()
@@ -308,7 +328,12 @@ class Driver:
         niter = 0
         if self.eng.has_radiation():
             niter = self.ion_radtransfer()
-            self.bvals_mhd()
+            # the x3 halo travels while the first-pass x1 / x2 sweeps of the planes ks..ke run (they read no
+            # neighbour data: aa_integrate_begin); the rest of the integrator follows the unpack
+            self.bvals_mhd(wait=False)
+            if hasattr(self.eng, "integrate_begin"):
+                self.eng.integrate_begin()
+            self.finish_x3()
         self.eng.integrate()
         self.eng.userwork()
         self.nstep += 1

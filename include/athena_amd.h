@@ -106,6 +106,10 @@ int aa_step(aa_grid *g, int *niter);                /* one pass of main.c:519-66
 
 /* ---- phases, for drivers that interleave neighbour exchange / global reductions
  *      (the places where the reference calls MPI)                          */
+/* The part of integrate_3d_ctu that reads none of the x3 neighbours' planes (the first-pass x1 / x2 sweeps of the
+ * planes ks..ke, integrate_3d_ctu.c:196-620): call it between posting the x3 halo (bvals_mhd.c:423-493) and waiting
+ * for it; aa_integrate_3d_ctu then does the rest.  Same bits with or without; a no-op where the split does not apply. */
+int aa_integrate_begin(aa_grid *g);
 int aa_new_dt_local(aa_grid *g, double *dt_cfl);                /* new_dt.c:72-170 before Allreduce */
 int aa_ion_begin(aa_grid *g);                                   /* ionrad_3d.c:896-905            */
 int aa_ion_rates(aa_grid *g, double *dt_chem, double *dt_therm);/* :922-938 before Allreduce      */

@@ -96,3 +96,30 @@ def test_every_fused_kernel_on_against_every_one_off_strict(problem, n, nstep, m
     a, b = out
     assert a[2] == b[2] and a[3] == b[3]
     assert np.array_equal(a[0], b[0], equal_nan=True) and np.array_equal(a[1], b[1], equal_nan=True)
+
+
+@pytest.mark.parametrize("strict", [True, False])
+@pytest.mark.parametrize("problem,ov", [(c[0], c[1]) for c in CASES])
+def test_integrate_begin_changes_no_bit(problem, ov, strict, monkeypatch):
+    """aa_integrate_begin (the first-pass x1 / x2 sweeps of the planes ks..ke, for a driver that has the x3 halo in
+    flight) followed by aa_integrate_3d_ctu against aa_integrate_3d_ctu alone: every pencil of those sweeps is on
+    its own, so the split must not change a bit in either build."""
+    aa = importlib.import_module("atmospheric-athena_amd")
+    lib = importlib.import_module("atmospheric-athena_amd.lib")
+    monkeypatch.setenv("AA_FUSED_UPDATE", "1")
+    monkeypatch.setenv("AA_CORRECT_ALL", "1")
+    out = []
+    for split in (False, True):
+        run = aa.config.load(os.path.join(DECKS, "athinput." + problem), ov, problem)
+        g = lib.setup_problem(aa.config.slab(run), 0, strict)
+        g.start()
+        for _ in range(2):
+            if split:
+                g.integrate_begin()
+            g.integrate_3d_ctu()
+            g.bvals_mhd()
+            g.new_dt()
+        out.append((g.download(), g.mesh_state()))
+        g.close()
+    assert out[0][1] == out[1][1]
+    assert np.array_equal(out[0][0], out[1][0], equal_nan=True)

@@ -68,6 +68,21 @@ def test_slabs_inside_the_library_equal_one_grid(problem, nx, nsteps, nslab, int
     assert np.allclose(many["hist"], one["hist"], rtol=1e-13 if strict or problem != "ioniz_sphere" else 1e-8, equal_nan=True)      # sums over slabs: a different summation order
 
 
+@pytest.mark.parametrize("problem,nx,nsteps,nslab", [("blast", (24, 16, 32), 3, 2), ("ioniz_sphere", (64, 20, 20), 2, 4),
+                                                      ("ifront", (70, 9, 13), 3, 3)])
+def test_slabs_with_the_big_grid_kernels(problem, nx, nsteps, nslab, monkeypatch):
+    """The kernels big Grids use, forced on at a small size (AA_CORRECT_ALL): with them the composite Grid sweeps the
+    planes ks..ke of every slab in x1 / x2 while the ghost planes are still being copied (aa_integrate_begin, the
+    copies on the slabs' copy streams) and the rest after the unpack.  Strict build: bit for bit the one-Grid run."""
+    monkeypatch.setenv("AA_CORRECT_ALL", "1")
+    one = _run(problem, nx, nsteps, 1, "ctu", True)
+    many = _run(problem, nx, nsteps, nslab, "ctu", True)
+    assert many["its"] == one["its"] and many["time"] == one["time"] and many["dt"] == one["dt"]
+    assert np.array_equal(many["U"], one["U"], equal_nan=True)
+    if "ef" in one:
+        assert np.array_equal(many["ef"], one["ef"])
+
+
 def test_too_thin_slabs_are_refused():
     aa = importlib.import_module("atmospheric-athena_amd")
     lib = importlib.import_module("atmospheric-athena_amd.lib")
