@@ -88,3 +88,19 @@ def test_two_ranks_rehearsed_on_one_gpu_smr():
                             "--master-port", str(port)))
     assert d["n_gpus"] == 2 and d["value"] > 0 and "2-level SMR" in d["config"]["workload"]
     assert all(len(t) == 2 and min(t) >= 1 for t in d["config"]["subcycle_trace_per_level"])
+
+
+def test_one_rank_over_rccl():
+    """The multi-rank loop of bench.py on ONE rank with the real backend ("nccl" = RCCL): communicator creation with
+    the device id, the barrier, new_dt's all-reduce and the sub-cycle's all_gather of the reduction words from device
+    memory all go through RCCL (the point-to-point halo needs a second GPU and stays unrehearsed on this backend).
+    Same answer as the plain one-GPU run."""
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    args = ("--nx", "64", "--steps", "2", "--warmup", "1", "--spinup", "2", "--no-cpu-baseline")
+    d = run_bench(*args, env={"AA_FORCE_DISTRIBUTED": "1", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "RANK": "0",
+                              "WORLD_SIZE": "1", "LOCAL_RANK": "0"})
+    one = run_bench(*args)
+    assert d["n_gpus"] == 1 and d["state_check"]["ok"] is True
+    assert d["config"]["subcycle_trace"] == one["config"]["subcycle_trace"] and d["config"]["final_dt"] == one["config"]["final_dt"]
+    assert d["state_check"]["mass_after"] == one["state_check"]["mass_after"]
+    assert d["host_syncs_per_subcycle"] <= 1.0 + 1e-9
