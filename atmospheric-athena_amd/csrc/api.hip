@@ -102,6 +102,11 @@ int aa_create(const aa_params *p, aa_grid **out)
   // (80^3: +7 %): same results bit for bit, so the choice follows the size unless AA_CORRECT_ALL forces it
   { const char *e = getenv("AA_CORRECT_ALL");
     g->correct_all = e ? atoi(e) != 0 : ((long long)p->Nx[0]*p->Nx[1]*p->Nx[2] >= (1LL << 21)); }
+  // k_correct_all also does the x3 first pass (no k_sweep_march<2> launch, those fluxes never in HBM): -3.1 ms of a 512^3
+  // blast step, -4.2 ms ifront, -4.4 / -2.0 ms third order without / with gravity.  The one combination it does not pay
+  // for is second order + passive scalar + gravity (ioniz_sphere: the kernel is bound by its own instruction stream
+  // there, 249 VGPRs at 2 waves per SIMD, and the step gets 0.6-0.9 ms slower): left to the sweep kernel.  Same bits.
+  { const char *e = getenv("AA_X3_FUSED"); g->x3_fused_mode = e ? (atoi(e) != 0) : -1; }    // (the potential arrives after aa_create)
   // rates inside the ray sweep: one block per 64 rays, so it needs many rays to fill the chip (512^2 rays:
   // -2.9 ms per step; 80^2 rays: +6 %); same results either way
   { const char *e = getenv("AA_FUSED_RATES"); g->fused_rates = e ? atoi(e) != 0 : ((long long)p->Nx[1]*p->Nx[2] >= (1LL << 17)); }
@@ -409,6 +414,13 @@ int aa_new_dt(aa_grid *g)
   return 0;
 }
 
+// k_correct_all also does the x3 first pass (no k_sweep_march<2> launch, those fluxes never in HBM): -3.1 ms of a 512^3
+// blast step, -4.2 ms ifront, -4.4 / -2.0 ms third order without / with gravity.  The one combination it does not pay for
+// is second order + passive scalar + gravity (ioniz_sphere: the kernel is bound by its own instruction stream there,
+// 249 VGPRs at 2 waves per SIMD, and the step gets 0.6-0.9 ms slower): left to the sweep kernel.  Same bits either way.
+static bool x3_fused(const aa_grid *g)
+{ return g->x3_fused_mode >= 0 ? g->x3_fused_mode != 0 : !(g->p.nscal > 0 && g->grav && !g->d.slope); }
+
 // The part of the step that needs none of the x3 neighbours' planes: the first-pass x1 and x2 sweeps of the k-planes
 // ks .. ke (a pencil along x1 or x2 lies in one plane).  A multi-GPU caller posts the x3 halo, calls this, waits for the
 // halo, unpacks it and calls aa_integrate_3d_ctu, which then sweeps only the four ghost planes in x1 / x2: the messages
@@ -437,8 +449,8 @@ int aa_integrate_3d_ctu(aa_grid *g)
     const int nk = d.ke - d.ks + 1;
     { Scope s(g, "sweep_x2"); launch_sweep(d, ns, 1, dt, g->grav, g->st, 0, 2); launch_sweep(d, ns, 1, dt, g->grav, g->st, 2 + nk, 2); }
     { Scope s(g, "sweep_x1"); launch_sweep(d, ns, 0, dt, g->grav, g->st, 0, 2); launch_sweep(d, ns, 0, dt, g->grav, g->st, 2 + nk, 2); }
-    { Scope s(g, "sweep_x3"); launch_sweep(d, ns, 2, dt, g->grav, g->st); }
-    { Scope s(g, "correct_all"); launch_correct_all(d, ns, dt, g->grav, g->st); }
+    if (!x3_fused(g)) { Scope s(g, "sweep_x3"); launch_sweep(d, ns, 2, dt, g->grav, g->st); }
+    { Scope s(g, "correct_all"); launch_correct_all(d, ns, dt, g->grav, x3_fused(g), g->st); }
     Scope s(g, "flux2_update");
     launch_flux2_update(d, ns, dt, g->grav, g->keep_flux ? &g->keep : nullptr, g->st);
     HIPCHK(hipGetLastError());
@@ -447,10 +459,10 @@ int aa_integrate_3d_ctu(aa_grid *g)
   if (d.slope) { Scope s(g, "ppm_slopes"); for (int dir = 0; dir < 3; dir++) launch_slopes(d, ns, dir, g->st); }
   // x2 and x3 first, so that the x1 sweep can do its first pass and its correct pass in one go
   { Scope s(g, "sweep_x2"); launch_sweep(d, ns, 1, dt, g->grav, g->st); }
-  { Scope s(g, "sweep_x3"); launch_sweep(d, ns, 2, dt, g->grav, g->st); }
+  if (!(g->correct_all && x3_fused(g))) { Scope s(g, "sweep_x3"); launch_sweep(d, ns, 2, dt, g->grav, g->st); }
   if (g->correct_all) {
     { Scope s(g, "sweep_x1"); launch_sweep(d, ns, 0, dt, g->grav, g->st); }
-    { Scope s(g, "correct_all"); launch_correct_all(d, ns, dt, g->grav, g->st); }
+    { Scope s(g, "correct_all"); launch_correct_all(d, ns, dt, g->grav, x3_fused(g), g->st); }
   } else {
     { Scope s(g, "sweep_correct_x1"); launch_sweep_correct_x1(d, ns, dt, g->grav, g->st); }
     { Scope s(g, "correct_x2"); launch_correct(d, ns, 1, dt, g->grav, g->st); }

@@ -28,6 +28,7 @@ struct aa_grid {
   int rad_dir = 0, nradplane = 0; aa::Real flux_i = 0;
   int level = 0;                       // DomainS.Level: > 0 only as a level of an aa_mesh
   bool fused_update = false;           // second-pass fluxes + update in one kernel (AA_FUSED_UPDATE=0 at aa_create: the unfused chain)
+  int x3_fused_mode = -1;              // k_correct_all also does the x3 first pass: -1 by configuration (api.hip), AA_X3_FUSED=0/1 forces
   bool inner_swept = false;            // aa_integrate_begin has done the first-pass x1 / x2 sweeps of the planes ks .. ke
   double inner_dt = 0.0;               //   ... with this dt
   bool correct_all = false;            // the three correct passes in one kernel (k_correct_all): Grids of 2^21 zones or more, or AA_CORRECT_ALL

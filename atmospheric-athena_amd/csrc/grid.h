@@ -90,7 +90,8 @@ void launch_slopes(const DevGrid &g, int nscal, int dir, hipStream_t st);       
 void launch_sweep(const DevGrid &g, int nscal, int dir, Real dt, bool grav, hipStream_t st, int koff = 0, int kcnt = -1);
 void launch_correct(const DevGrid &g, int nscal, int dir, Real dt, bool grav, hipStream_t st);
 void launch_sweep_correct_x1(const DevGrid &g, int nscal, Real dt, bool grav, hipStream_t st);
-void launch_correct_all(const DevGrid &g, int nscal, Real dt, bool grav, hipStream_t st);   // the three correct passes in one kernel
+// the three correct passes in one kernel; x3f: and the x3 first pass (then launch_sweep(.., 2, ..) is not needed)
+void launch_correct_all(const DevGrid &g, int nscal, Real dt, bool grav, bool x3f, hipStream_t st);
 void launch_flux2(const DevGrid &g, int nscal, int dir, hipStream_t st);
 void launch_update(const DevGrid &g, int nscal, const Real *dhalf, Real dt, bool grav, hipStream_t st);
 // face planes (index along the normal, incl. ghost offset) whose second-pass fluxes the fused kernel also

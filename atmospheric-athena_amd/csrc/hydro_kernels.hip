@@ -462,23 +462,28 @@ struct CellFlux {            // first-pass fluxes across one zone
   Real gm[3], ge[3];         // gravity: q_e (phi_r - phi_l) d   and   q_e (F_lo (phi_c - phi_l) + F_hi (phi_r - phi_c))
 };
 
-// one zone along D: reconstruction, gravity kick, conversion, transverse correction, face states stored;
-// returns the wave speeds eta needs: lam_l of the left state it gave to its UPPER face, lam_r of the
-// right state it gave to its LOWER face
+// one zone along D, first half: reconstruction + gravity kick = the primitive states the FIRST pass solves its Riemann
+// problems with (face_work): the left state belongs to the zone's upper face, the right state to its lower one
 template <int NS, int D, bool GRAV, int ORD>
-AA_DEV void cell_states(const DevGrid &g, long m, Real dt, const Real q[3], const CellFlux &cf, const Real wm[6], const Real w[6],
-                        const Real wp[6], bool store, Real &lam_l, Real &lam_r)
+AA_DEV void cell_recon(const DevGrid &g, long m, Real dt, const Real wm[6], const Real w[6], const Real wp[6], Real wl[6], Real wr[6])
 {
-  constexpr int NV = 5 + NS;
   const Real dtodx = dt/g.dx[D];
   const long sD = stride<D>(g);
-  Real wl[6], wr[6];
   recon_cell<NS, true, ORD, D>(g, m, wm, w, wp, dtodx, wl, wr);
-  if (GRAV) {   // face_work: the left state belongs to the upper face, the right state to the lower one
+  if (GRAV) {
     const Real phic = Pf(g, 0)[m], phi_up = Pf(g, 1 + D)[m + sD], phi_lo = Pf(g, 1 + D)[m];
     wl[1] -= dtodx*(phi_up - phic);
     wr[1] -= dtodx*(phic - phi_lo);
   }
+}
+// second half: conversion, transverse correction, face states stored; returns the wave speeds eta needs: lam_l of the
+// left state the zone gave to its UPPER face, lam_r of the right state it gave to its LOWER face
+template <int NS, int D, bool GRAV>
+AA_DEV void cell_finish(const DevGrid &g, long m, const Real q[3], const CellFlux &cf, const Real wl[6], const Real wr[6],
+                        bool store, Real &lam_l, Real &lam_r)
+{
+  constexpr int NV = 5 + NS;
+  const long sD = stride<D>(g);
   Real sl[6], sr[6], ul[6], ur[6];
   prim_to_cons<NS>(wl, sl, g.Gamma_1);
   prim_to_cons<NS>(wr, sr, g.Gamma_1);
@@ -508,13 +513,39 @@ AA_DEV void cell_states(const DevGrid &g, long m, Real dt, const Real q[3], cons
   lam_r = sr[1]/sr[0] + cfr;
   lam_l = sl[1]/sl[0] - cfl;
 }
+template <int NS, int D, bool GRAV, int ORD>
+AA_DEV void cell_states(const DevGrid &g, long m, Real dt, const Real q[3], const CellFlux &cf, const Real wm[6], const Real w[6],
+                        const Real wp[6], bool store, Real &lam_l, Real &lam_r)
+{
+  Real wl[6], wr[6];
+  cell_recon<NS, D, GRAV, ORD>(g, m, dt, wm, w, wp, wl, wr);
+  cell_finish<NS, D, GRAV>(g, m, q, cf, wl, wr, store, lam_l, lam_r);
+}
 
-template <int NS, bool GRAV, int ORD>
-__global__ void __launch_bounds__(64*CA_TJ)
+#ifndef CA_PARK
+#define CA_PARK 1
+#endif
+#ifndef CA_X3FIRST
+#define CA_X3FIRST 1
+#endif
+#ifndef CA_LB2SEL
+#define CA_LB2SEL 1
+#endif
+#ifndef CA_FEARLY
+#define CA_FEARLY 0
+#endif
+#ifndef CA_SB
+#define CA_SB 1
+#endif
+template <int NS, bool GRAV, int ORD, bool X3F>
+__global__ void __launch_bounds__(64*CA_TJ, (CA_LB2SEL == 2 || (CA_LB2SEL == 1 && X3F && NS && GRAV)) ? 2 : 1)
 k_correct_all(DevGrid g, Real dt, int kchunk)
 {
   __shared__ Real s_w[CA_TJ][6][64];
   __shared__ Real s_l[CA_TJ][64];
+  // X3F: the x3 states of zone k+1 wait here while zone k is corrected (each thread its own slots, no barrier): 24
+  // registers that the 6-variable gravity kernel does not have at 2 waves per SIMD (it spilled 16 to scratch)
+  __shared__ Real s_park[(X3F && CA_PARK) ? 12 : 1][CA_TJ][64];
   constexpr int NV = 5 + NS;
   const int lane = threadIdx.x, row = threadIdx.y;
   // Zones s-1 .. e+1 in every direction get their face states.  Tiles do NOT overlap in x1 / x2 (round 1's did by one
@@ -539,32 +570,98 @@ k_correct_all(DevGrid g, Real dt, int kchunk)
 #pragma unroll
   for (int d = 0; d < 3; d++) q[d] = 0.5*(dt/g.dx[d]);
 
-  Real wm3[6], wc[6], wn[6], pc0, pc1, pn0, pn1, f3[6], lam3 = 0.0;
-  load_prim3<NS>(g, (long)(kstart - 1)*g.sK + mcol, wc, pn0, pn1);
-  load_prim3<NS>(g, (long)kstart*g.sK + mcol, wn, pn0, pn1);
+  // X3F: the x3 FIRST pass rides on the march (k_sweep_march<2> is not launched, its fluxes never reach HBM): the
+  // transverse differences a zone needs of the x3 first-pass flux are those of its own column, and the reconstruction
+  // + gravity kick of a zone along x3 is the same for the first pass and for the correct pass.  Iteration k
+  // reconstructs zone k+1 (A), solves face k+1 from the left state zone k kept and the right state of zone k+1 (B),
+  // and then corrects zone k in all three directions (C).  A chunk starts two planes early with A only, then A + B: one
+  // instance of every piece of arithmetic, whatever the chunking (see k_sweep_march).
+  // The window: wc = zone k, wn = k+1 (and wm3 = k-1 without X3F, wn2 = k+2 with it).
+  Real wm3[6], wc[6], wn[6], wn2[6], pc0 = 0.0, pc1 = 0.0, pn0, pn1, pn20 = 0.0, pn21 = 0.0, f3[6], lam3 = 0.0;
+  Real wl3[6], wr3[6];                                          // X3F: kicked x3 states of zone k (left -> face k+1, right -> face k)
+  const int kbeg = X3F ? kstart - 2 : kstart;
+  if (X3F) {
+    load_prim3<NS>(g, (long)kbeg*g.sK + mcol, wn, pn0, pn1);
+    load_prim3<NS>(g, (long)(kbeg + 1)*g.sK + mcol, wn2, pn20, pn21);
 #pragma unroll
-  for (int v = 0; v < 6; v++) f3[v] = (v < NV) ? Ff(g, 2, v)[(long)kstart*g.sK + mcol] : 0.0;
+    for (int v = 0; v < 6; v++) { f3[v] = 0.0; wl3[v] = 1.0; wr3[v] = 1.0; wc[v] = 1.0; }
+  } else {
+    load_prim3<NS>(g, (long)(kstart - 1)*g.sK + mcol, wc, pn0, pn1);
+    load_prim3<NS>(g, (long)kstart*g.sK + mcol, wn, pn0, pn1);
+#pragma unroll
+    for (int v = 0; v < 6; v++) f3[v] = (v < NV) ? Ff(g, 2, v)[(long)kstart*g.sK + mcol] : 0.0;
+  }
 #pragma nounroll
-  for (int k = kstart; k <= k1; k++) {
+  for (int k = kbeg; k <= k1; k++) {
     long m = (long)k*g.sK + mcol;
     asm volatile("" : "+v"(m));                   // one index for all fields (see k_flux2_update)
     const bool full = (k >= k0);                  // block-uniform; the provider plane does x3 only
+    const bool zone = (k >= kstart);              // block-uniform; X3F: the two planes before do the first pass only
+    Real f3n[6], wlN[6], wrN[6];
 #pragma unroll
-    for (int n = 0; n < 6; n++) { wm3[n] = wc[n]; wc[n] = wn[n]; }
-    pc0 = pn0; pc1 = pn1;
-    load_prim3<NS>(g, m + g.sK, wn, pn0, pn1);
+    for (int v = 0; v < 6; v++) { f3n[v] = 0.0; wlN[v] = 1.0; wrN[v] = 1.0; }
     // first-pass fluxes across the zone
     CellFlux cf;
 #pragma unroll
     for (int v = 0; v < 6; v++) { cf.dF[0][v] = 0.0; cf.dF[1][v] = 0.0; cf.dF[2][v] = 0.0; }
     Real mlo[3], mhi[3];
+#if CA_FEARLY
+    if (X3F && zone) {      // requested before the first-pass work of this iteration, consumed after it
 #pragma unroll
-    for (int v = 0; v < NV; v++) {
-      const Real a0 = Ff(g, 0, v)[m], a1 = Ff(g, 0, v)[m + 1], b0 = Ff(g, 1, v)[m], b1 = Ff(g, 1, v)[m + g.sJ];
-      const Real c0 = f3[v], c1 = Ff(g, 2, v)[m + g.sK];
-      cf.dF[0][v] = a1 - a0; cf.dF[1][v] = b1 - b0; cf.dF[2][v] = c1 - c0;
-      if (v == 0) { mlo[0] = a0; mhi[0] = a1; mlo[1] = b0; mhi[1] = b1; mlo[2] = c0; mhi[2] = c1; }
-      f3[v] = c1;
+      for (int v = 0; v < NV; v++) {
+        const Real a0 = Ff(g, 0, v)[m], a1 = Ff(g, 0, v)[m + 1], b0 = Ff(g, 1, v)[m], b1 = Ff(g, 1, v)[m + g.sJ];
+        cf.dF[0][v] = a1 - a0; cf.dF[1][v] = b1 - b0;
+        if (v == 0) { mlo[0] = a0; mhi[0] = a1; mlo[1] = b0; mhi[1] = b1; }
+      }
+    }
+#endif
+    if (X3F) {
+#pragma unroll
+      for (int n = 0; n < 6; n++) { wc[n] = wn[n]; wn[n] = wn2[n]; }
+      pc0 = pn0; pc1 = pn1; pn0 = pn20; pn1 = pn21;
+      load_prim3<NS>(g, m + 2*g.sK, wn2, pn20, pn21);
+      if (do3) {
+        {   // (A) zone k+1 along x3
+          Real wm[6], ws[6], wp[6];
+          to_sweep<2>(wc, wc[4], wm); to_sweep<2>(wn, wn[4], ws); to_sweep<2>(wn2, wn2[4], wp);
+          cell_recon<NS, 2, GRAV, ORD>(g, m + g.sK, dt, wm, ws, wp, wlN, wrN);
+        }
+        if (k >= kstart - 1) {   // (B) first-pass flux of face k+1 (face_work<MODE_FLUX1>), sweep frame -> global variables
+          Real ul[6], ur[6], f[6];
+          prim_to_cons<NS>(wl3, ul, g.Gamma_1);
+          prim_to_cons<NS>(wrN, ur, g.Gamma_1);
+          flux_roe<NS>(ul, ur, wl3, wrN, 0.0, g.Gamma, g.Gamma_1, f);
+#pragma unroll
+          for (int n = 0; n < NV; n++) f3n[gv<2>(n)] = f[n];
+        }
+      }
+#if CA_PARK
+#pragma unroll
+      for (int n = 0; n < NV; n++) { s_park[n][row][lane] = wlN[n]; s_park[6 + n][row][lane] = wrN[n]; }
+#endif
+#if CA_SB
+      __builtin_amdgcn_sched_barrier(0);
+#endif
+    } else {
+#pragma unroll
+      for (int n = 0; n < 6; n++) { wm3[n] = wc[n]; wc[n] = wn[n]; }
+      pc0 = pn0; pc1 = pn1;
+      load_prim3<NS>(g, m + g.sK, wn, pn0, pn1);
+    }
+    if (zone) {
+    if (X3F && CA_FEARLY) {
+#pragma unroll
+      for (int v = 0; v < NV; v++) cf.dF[2][v] = f3n[v] - f3[v];
+      mlo[2] = f3[0]; mhi[2] = f3n[0];
+    } else {
+#pragma unroll
+      for (int v = 0; v < NV; v++) {
+        const Real a0 = Ff(g, 0, v)[m], a1 = Ff(g, 0, v)[m + 1], b0 = Ff(g, 1, v)[m], b1 = Ff(g, 1, v)[m + g.sJ];
+        const Real c0 = f3[v], c1 = X3F ? f3n[v] : Ff(g, 2, v)[m + g.sK];
+        cf.dF[0][v] = a1 - a0; cf.dF[1][v] = b1 - b0; cf.dF[2][v] = c1 - c0;
+        if (v == 0) { mlo[0] = a0; mhi[0] = a1; mlo[1] = b0; mhi[1] = b1; mlo[2] = c0; mhi[2] = c1; }
+        if (!X3F) f3[v] = c1;
+      }
     }
     if (GRAV) {
       const Real dc = wc[0], phic = Pf(g, 0)[m];
@@ -574,6 +671,14 @@ k_correct_all(DevGrid g, Real dt, int kchunk)
         cf.gm[e] = q[e]*(phir - phil)*dc;
         cf.ge[e] = q[e]*(mlo[e]*(phic - phil) + mhi[e]*(phir - phic));
       }
+    }
+    if (X3F && CA_X3FIRST && do3) {   // ---- x3 first: the states zone k kept are dead afterwards (24 registers less under x1 / x2) ----
+      Real ll, lr;
+      cell_finish<NS, 2, GRAV>(g, m, q, cf, wl3, wr3, full, ll, lr);
+      if (full && k > g.ks - 1) Ef(g, 2)[m] = 0.5*fabs(lr - lam3);      // lam3 = lambda_l the zone below gave to this zone's lower face
+      lam3 = ll;
+      if (GRAV && full)   // d^{n+1/2}, :2104-2125
+        g.dhalf[m] = wc[0] - q[0]*cf.dF[0][0] - q[1]*cf.dF[1][0] - q[2]*cf.dF[2][0];
     }
     if (full) {
       __builtin_amdgcn_sched_barrier(0);
@@ -622,14 +727,31 @@ k_correct_all(DevGrid g, Real dt, int kchunk)
       }
       __builtin_amdgcn_sched_barrier(0);
     }
-    if (do3) {   // ---- x3: the register window; lam3 = lambda_l the zone below gave to this zone's lower face ----
-      Real wm[6], ws[6], wp[6], ll, lr;
-      to_sweep<2>(wm3, wm3[4], wm); to_sweep<2>(wc, wc[4], ws); to_sweep<2>(wn, wn[4], wp);
-      cell_states<NS, 2, GRAV, ORD>(g, m, dt, q, cf, wm, ws, wp, full, ll, lr);
+    if (!(X3F && CA_X3FIRST) && do3) {   // ---- x3: the register window; lam3 = lambda_l the zone below gave to this zone's lower face ----
+      Real ll, lr;
+      if (X3F) cell_finish<NS, 2, GRAV>(g, m, q, cf, wl3, wr3, full, ll, lr);
+      else {
+        Real wm[6], ws[6], wp[6];
+        to_sweep<2>(wm3, wm3[4], wm); to_sweep<2>(wc, wc[4], ws); to_sweep<2>(wn, wn[4], wp);
+        cell_states<NS, 2, GRAV, ORD>(g, m, dt, q, cf, wm, ws, wp, full, ll, lr);
+      }
       if (full && k > g.ks - 1) Ef(g, 2)[m] = 0.5*fabs(lr - lam3);
       lam3 = ll;
       if (GRAV && full)   // d^{n+1/2}, :2104-2125
         g.dhalf[m] = wc[0] - q[0]*cf.dF[0][0] - q[1]*cf.dF[1][0] - q[2]*cf.dF[2][0];
+    }
+    }
+    if (X3F) {
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int n = 0; n < 6; n++) {
+#if CA_PARK
+        wl3[n] = (n < NV) ? s_park[n][row][lane] : 0.0; wr3[n] = (n < NV) ? s_park[6 + n][row][lane] : 0.0;
+#else
+        wl3[n] = wlN[n]; wr3[n] = wrN[n];
+#endif
+        f3[n] = f3n[n];
+      }
     }
   }
 }
@@ -1376,22 +1498,27 @@ static void slopes_impl(const DevGrid &g, int dir, hipStream_t st)
 }
 // the correct passes of all three directions in one kernel (after the three first passes)
 template <int NS, bool GRAV>
-static void correct_all_impl(const DevGrid &g, Real dt, hipStream_t st)
+static void correct_all_impl(const DevGrid &g, Real dt, bool x3f, hipStream_t st)
 {
   const int ni = g.ie - g.is + 3, nj = g.je - g.js + 3, nk = g.ke - g.ks + 3;    // zones s-1 .. e+1
   int kc = 32;
   while (kc > 4 && (long)nblk(ni - 1, 63)*nblk(nj - 1, CA_TJ - 1)*((nk + kc - 1)/kc) < 1024) kc >>= 1;
   dim3 grid(nblk(ni + 15, 64), nblk(nj, CA_TJ), (nk + kc - 1)/kc), blk(64, CA_TJ);
-  if (g.slope) hipLaunchKernelGGL((k_correct_all<NS, GRAV, 3>), grid, blk, 0, st, g, dt, kc);
-  else         hipLaunchKernelGGL((k_correct_all<NS, GRAV, 2>), grid, blk, 0, st, g, dt, kc);
+  if (x3f) {
+    if (g.slope) hipLaunchKernelGGL((k_correct_all<NS, GRAV, 3, true>), grid, blk, 0, st, g, dt, kc);
+    else         hipLaunchKernelGGL((k_correct_all<NS, GRAV, 2, true>), grid, blk, 0, st, g, dt, kc);
+  } else {
+    if (g.slope) hipLaunchKernelGGL((k_correct_all<NS, GRAV, 3, false>), grid, blk, 0, st, g, dt, kc);
+    else         hipLaunchKernelGGL((k_correct_all<NS, GRAV, 2, false>), grid, blk, 0, st, g, dt, kc);
+  }
   const long nb1 = (g.ie + 1 - (g.is - 16))/64, nb2 = (g.je + 1 - (g.js - 1))/CA_TJ;
   if (nb1 > 0) hipLaunchKernelGGL((k_eta_edges<0>), dim3(nblk(nb1*nj*nk, 256)), dim3(256), 0, st, g);
   if (nb2 > 0) hipLaunchKernelGGL((k_eta_edges<1>), dim3(nblk((long)ni*nb2*nk, 256)), dim3(256), 0, st, g);
 }
-void launch_correct_all(const DevGrid &g, int nscal, Real dt, bool grav, hipStream_t st)
+void launch_correct_all(const DevGrid &g, int nscal, Real dt, bool grav, bool x3f, hipStream_t st)
 {
-  if (nscal) { if (grav) correct_all_impl<1, true>(g, dt, st); else correct_all_impl<1, false>(g, dt, st); }
-  else       { if (grav) correct_all_impl<0, true>(g, dt, st); else correct_all_impl<0, false>(g, dt, st); }
+  if (nscal) { if (grav) correct_all_impl<1, true>(g, dt, x3f, st); else correct_all_impl<1, false>(g, dt, x3f, st); }
+  else       { if (grav) correct_all_impl<0, true>(g, dt, x3f, st); else correct_all_impl<0, false>(g, dt, x3f, st); }
 }
 
 void launch_slopes(const DevGrid &g, int nscal, int dir, hipStream_t st)

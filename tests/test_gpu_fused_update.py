@@ -19,11 +19,14 @@ DECKS = os.path.join(ROOT, "atmospheric-athena_amd", "decks")
 
 
 def run_gpu(problem, ov, strict, fused, nstep, monkeypatch, order=2):
-    """fused: False = separate kernels; True = k_flux2_update; "all" = k_correct_all + k_flux2_update"""
+    """fused: False = separate kernels; True = k_flux2_update; "all" = k_correct_all + k_flux2_update; "all+x3" = the
+    same with the x3 first pass inside k_correct_all (AA_X3_FUSED; the library's default for every configuration but
+    second order + scalar + gravity, forced either way here)"""
     aa = importlib.import_module("atmospheric-athena_amd")
     lib = importlib.import_module("atmospheric-athena_amd.lib")
     monkeypatch.setenv("AA_FUSED_UPDATE", "1" if fused else "0")
-    monkeypatch.setenv("AA_CORRECT_ALL", "1" if fused == "all" else "0")
+    monkeypatch.setenv("AA_CORRECT_ALL", "1" if fused in ("all", "all+x3") else "0")
+    monkeypatch.setenv("AA_X3_FUSED", "1" if fused == "all+x3" else "0")
     run = aa.config.load(os.path.join(DECKS, "athinput." + problem), ov, problem)
     run.order = order
     g = lib.setup_problem(aa.config.slab(run), 0, strict)
@@ -42,7 +45,7 @@ CASES = [("blast", ["domain1/Nx1=70", "domain1/Nx2=23", "domain1/Nx3=37"], 3),
 
 
 @pytest.mark.parametrize("order", [2, 3])
-@pytest.mark.parametrize("mode", [True, "all"])
+@pytest.mark.parametrize("mode", [True, "all", "all+x3"])
 @pytest.mark.parametrize("problem,ov,nstep", CASES)
 def test_fused_equals_unfused_bitwise_strict(problem, ov, nstep, mode, order, monkeypatch):
     a, ia, sa = run_gpu(problem, ov, True, False, nstep, monkeypatch, order)
@@ -51,7 +54,7 @@ def test_fused_equals_unfused_bitwise_strict(problem, ov, nstep, mode, order, mo
     assert np.array_equal(a, b, equal_nan=True)
 
 
-@pytest.mark.parametrize("mode", [True, "all"])
+@pytest.mark.parametrize("mode", [True, "all", "all+x3"])
 @pytest.mark.parametrize("problem,ov,nstep", CASES[:2])
 def test_fused_vs_oracle_bitwise(problem, ov, nstep, mode, monkeypatch):
     U, its, st = run_gpu(problem, ov, True, mode, nstep, monkeypatch)
@@ -62,7 +65,7 @@ def test_fused_vs_oracle_bitwise(problem, ov, nstep, mode, monkeypatch):
     assert np.array_equal(U[4:-4, 4:-4, 4:-4, :5], o.active[..., :5])
 
 
-@pytest.mark.parametrize("mode", [True, "all"])
+@pytest.mark.parametrize("mode", [True, "all", "all+x3"])
 @pytest.mark.parametrize("problem,ov,nstep", CASES)
 def test_fused_fast_build_within_rounding(problem, ov, nstep, mode, monkeypatch):
     a, ia, sa = run_gpu(problem, ov, False, False, nstep, monkeypatch)
@@ -85,7 +88,7 @@ def test_every_fused_kernel_on_against_every_one_off_strict(problem, n, nstep, m
     lib = importlib.import_module("atmospheric-athena_amd.lib")
     out = []
     for on in ("0", "1"):
-        for k in ("AA_FUSED_UPDATE", "AA_CORRECT_ALL", "AA_FUSED_RATES"):
+        for k in ("AA_FUSED_UPDATE", "AA_CORRECT_ALL", "AA_FUSED_RATES", "AA_X3_FUSED"):
             monkeypatch.setenv(k, on)
         run = aa.config.load(os.path.join(DECKS, "athinput." + problem), [f"domain1/Nx{d}={n}" for d in (1, 2, 3)], problem)
         g = lib.setup_problem(aa.config.slab(run), 0, True)
@@ -98,9 +101,10 @@ def test_every_fused_kernel_on_against_every_one_off_strict(problem, n, nstep, m
     assert np.array_equal(a[0], b[0], equal_nan=True) and np.array_equal(a[1], b[1], equal_nan=True)
 
 
+@pytest.mark.parametrize("x3", ["0", "1"])
 @pytest.mark.parametrize("strict", [True, False])
 @pytest.mark.parametrize("problem,ov", [(c[0], c[1]) for c in CASES])
-def test_integrate_begin_changes_no_bit(problem, ov, strict, monkeypatch):
+def test_integrate_begin_changes_no_bit(problem, ov, strict, x3, monkeypatch):
     """aa_integrate_begin (the first-pass x1 / x2 sweeps of the planes ks..ke, for a driver that has the x3 halo in
     flight) followed by aa_integrate_3d_ctu against aa_integrate_3d_ctu alone: every pencil of those sweeps is on
     its own, so the split must not change a bit in either build."""
@@ -108,6 +112,7 @@ def test_integrate_begin_changes_no_bit(problem, ov, strict, monkeypatch):
     lib = importlib.import_module("atmospheric-athena_amd.lib")
     monkeypatch.setenv("AA_FUSED_UPDATE", "1")
     monkeypatch.setenv("AA_CORRECT_ALL", "1")
+    monkeypatch.setenv("AA_X3_FUSED", x3)
     out = []
     for split in (False, True):
         run = aa.config.load(os.path.join(DECKS, "athinput." + problem), ov, problem)
