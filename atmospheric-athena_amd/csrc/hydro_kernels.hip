@@ -460,6 +460,7 @@ template <int D> AA_DEV void to_sweep(const Real wg[6], Real p, Real ws[6])
 struct CellFlux {            // first-pass fluxes across one zone
   Real dF[3][6];             // F_e(upper face) - F_e(lower face), global frame
   Real gm[3], ge[3];         // gravity: q_e (phi_r - phi_l) d   and   q_e (F_lo (phi_c - phi_l) + F_hi (phi_r - phi_c))
+  Real kl[3], kr[3];         // gravity kick of the zone's left / right state along e: dt/dx_e (phi_up - phi_c), dt/dx_e (phi_c - phi_lo)
 };
 
 // one zone along D, first half: reconstruction + gravity kick = the primitive states the FIRST pass solves its Riemann
@@ -475,6 +476,15 @@ AA_DEV void cell_recon(const DevGrid &g, long m, Real dt, const Real wm[6], cons
     wl[1] -= dtodx*(phi_up - phic);
     wr[1] -= dtodx*(phic - phi_lo);
   }
+}
+// the same with the kicks of the zone taken from its CellFlux (formed at the head of the iteration from the potential
+// values loaded there: a load inside the direction blocks would wait for the stores of the block before it)
+template <int NS, int D, bool GRAV, int ORD>
+AA_DEV void cell_recon(const DevGrid &g, long m, Real dt, const CellFlux &cf, const Real wm[6], const Real w[6], const Real wp[6],
+                       Real wl[6], Real wr[6])
+{
+  recon_cell<NS, true, ORD, D>(g, m, wm, w, wp, dt/g.dx[D], wl, wr);
+  if (GRAV) { wl[1] -= cf.kl[D]; wr[1] -= cf.kr[D]; }
 }
 // second half: conversion, transverse correction, face states stored; returns the wave speeds eta needs: lam_l of the
 // left state the zone gave to its UPPER face, lam_r of the right state it gave to its LOWER face
@@ -518,7 +528,7 @@ AA_DEV void cell_states(const DevGrid &g, long m, Real dt, const Real q[3], cons
                         const Real wp[6], bool store, Real &lam_l, Real &lam_r)
 {
   Real wl[6], wr[6];
-  cell_recon<NS, D, GRAV, ORD>(g, m, dt, wm, w, wp, wl, wr);
+  cell_recon<NS, D, GRAV, ORD>(g, m, dt, cf, wm, w, wp, wl, wr);
   cell_finish<NS, D, GRAV>(g, m, q, cf, wl, wr, store, lam_l, lam_r);
 }
 
@@ -546,6 +556,12 @@ k_correct_all(DevGrid g, Real dt, int kchunk)
   // X3F: the x3 states of zone k+1 wait here while zone k is corrected (each thread its own slots, no barrier): 24
   // registers that the 6-variable gravity kernel does not have at 2 waves per SIMD (it spilled 16 to scratch)
   __shared__ Real s_park[(X3F && CA_PARK) ? 12 : 1][CA_TJ][64];
+  // The zones a tile needs from its neighbours (lane 0's lower / lane 63's upper x1 neighbour, row 0's lower / row CA_TJ-1's
+  // upper x2 neighbour) are requested at the head of the iteration with everything else and wait here for their block: a load
+  // issued inside a block would have to wait for the face-state stores of the block before it (loads and stores retire
+  // through one counter).  s_h1: per wave, the 6 + 6 conserved variables of the two x1 neighbours, fetched by lanes 0..11.
+  __shared__ Real s_h1[CA_TJ][12];
+  __shared__ Real s_h2[2][6][64];
   constexpr int NV = 5 + NS;
   const int lane = threadIdx.x, row = threadIdx.y;
   // Zones s-1 .. e+1 in every direction get their face states.  Tiles do NOT overlap in x1 / x2 (round 1's did by one
@@ -564,6 +580,8 @@ k_correct_all(DevGrid g, Real dt, int kchunk)
   // idle threads beyond the Grid keep valid addresses (their neighbours may read what they load)
   const int ic = (i <= g.ie + 2) ? (i < 0 ? 0 : i) : g.ie + 2, jc = (j <= g.je + 2) ? j : g.je + 2;
   const long mcol = (long)jc*g.sJ + ic;
+  const int iW = i - lane, iE = i - lane + 63;                 // lane 0's and lane 63's zone, clamped like ic
+  const int icW = (iW <= g.ie + 2) ? (iW < 0 ? 0 : iW) : g.ie + 2, icE = (iE <= g.ie + 2) ? (iE < 0 ? 0 : iE) : g.ie + 2;
   const bool in = (i >= g.is - 1) && (i <= g.ie + 1) && (j <= g.je + 1);
   const bool do1 = in, do2 = in, do3 = in;
   Real q[3];
@@ -648,6 +666,21 @@ k_correct_all(DevGrid g, Real dt, int kchunk)
       pc0 = pn0; pc1 = pn1;
       load_prim3<NS>(g, m + g.sK, wn, pn0, pn1);
     }
+    Real hv1 = 0.0, hv2[6];
+#pragma unroll
+    for (int v = 0; v < 6; v++) hv2[v] = 0.0;
+    const bool edge_row = (row == 0) || (row == CA_TJ - 1);
+    if (full) {
+      if (lane < 12) {
+        const int v = lane % 6, east = lane / 6;
+        if (v < NV) hv1 = Uf(g, v)[(long)k*g.sK + (long)jc*g.sJ + (east ? icE + 1 : icW - 1)];
+      }
+      if (edge_row) {
+        const long m2 = (row == 0) ? m - g.sJ : m + g.sJ;
+#pragma unroll
+        for (int v = 0; v < NV; v++) hv2[v] = Uf(g, gv<1>(v))[m2];
+      }
+    }
     if (zone) {
     if (X3F && CA_FEARLY) {
 #pragma unroll
@@ -670,25 +703,44 @@ k_correct_all(DevGrid g, Real dt, int kchunk)
         const Real phir = Pf(g, 1 + e)[m + stride_rt(g, e)], phil = Pf(g, 1 + e)[m];
         cf.gm[e] = q[e]*(phir - phil)*dc;
         cf.ge[e] = q[e]*(mlo[e]*(phic - phil) + mhi[e]*(phir - phic));
+        const Real dtodx = dt/g.dx[e];
+        cf.kl[e] = dtodx*(phir - phic); cf.kr[e] = dtodx*(phic - phil);
       }
     }
-    if (X3F && CA_X3FIRST && do3) {   // ---- x3 first: the states zone k kept are dead afterwards (24 registers less under x1 / x2) ----
+    if (CA_X3FIRST && do3) {   // ---- x3 first: what only this block needs (the plane below / the states zone k kept) is dead under x1 / x2 ----
       Real ll, lr;
-      cell_finish<NS, 2, GRAV>(g, m, q, cf, wl3, wr3, full, ll, lr);
+      if (X3F) cell_finish<NS, 2, GRAV>(g, m, q, cf, wl3, wr3, full, ll, lr);
+      else {
+        Real wm[6], ws[6], wp[6];
+        to_sweep<2>(wm3, wm3[4], wm); to_sweep<2>(wc, wc[4], ws); to_sweep<2>(wn, wn[4], wp);
+        cell_states<NS, 2, GRAV, ORD>(g, m, dt, q, cf, wm, ws, wp, full, ll, lr);
+      }
       if (full && k > g.ks - 1) Ef(g, 2)[m] = 0.5*fabs(lr - lam3);      // lam3 = lambda_l the zone below gave to this zone's lower face
       lam3 = ll;
       if (GRAV && full)   // d^{n+1/2}, :2104-2125
         g.dhalf[m] = wc[0] - q[0]*cf.dF[0][0] - q[1]*cf.dF[1][0] - q[2]*cf.dF[2][0];
     }
     if (full) {
+      if (lane < 12) s_h1[row][lane] = hv1;
+      if (edge_row) {
+#pragma unroll
+        for (int v = 0; v < NV; v++) s_h2[row ? 1 : 0][v][lane] = hv2[v];
+      }
       __builtin_amdgcn_sched_barrier(0);
       {   // ---- x1: neighbours by shuffle ----
         Real wm[6], wp[6], ws[6], ll = 0.0, lr = 0.0;
         to_sweep<0>(wc, pc0, ws);
 #pragma unroll
         for (int n = 0; n < 6; n++) { wm[n] = __shfl_up(ws[n], 1); wp[n] = __shfl_down(ws[n], 1); }
-        if (lane == 0)  load_prim_sweep<NS, 0>(g, m - 1, wm);
-        if (lane == 63) load_prim_sweep<NS, 0>(g, m + 1, wp);
+        if (lane == 0 || lane == 63) {      // the neighbour zone of the tile before / after, exactly as the sweeps convert it
+          Real u[6];
+#pragma unroll
+          for (int v = 0; v < 6; v++) u[v] = (v < NV) ? s_h1[row][(lane ? 6 : 0) + v] : 0.0;
+          Real wh[6];
+          cons_to_prim<NS>(u, wh, g.Gamma_1);
+#pragma unroll
+          for (int v = 0; v < 6; v++) { if (lane == 0) wm[v] = wh[v]; else wp[v] = wh[v]; }
+        }
         if (do1) cell_states<NS, 0, GRAV, ORD>(g, m, dt, q, cf, wm, ws, wp, true, ll, lr);
         const Real lprev = __shfl_up(ll, 1);
         if (do1) {
@@ -704,14 +756,22 @@ k_correct_all(DevGrid g, Real dt, int kchunk)
 #pragma unroll
         for (int n = 0; n < NV; n++) s_w[row][n][lane] = ws[n];
         __syncthreads();
-        if (row == 0) load_prim_sweep<NS, 1>(g, m - g.sJ, wm);
-        else {
+        if (row == 0) {
+          Real u[6];
+#pragma unroll
+          for (int v = 0; v < 6; v++) u[v] = (v < NV) ? s_h2[0][v][lane] : 0.0;
+          cons_to_prim<NS>(u, wm, g.Gamma_1);
+        } else {
 #pragma unroll
           for (int n = 0; n < NV; n++) wm[n] = s_w[row - 1][n][lane];
           if (!NS) wm[5] = 0.0;
         }
-        if (row == CA_TJ - 1) load_prim_sweep<NS, 1>(g, m + g.sJ, wp);
-        else {
+        if (row == CA_TJ - 1) {
+          Real u[6];
+#pragma unroll
+          for (int v = 0; v < 6; v++) u[v] = (v < NV) ? s_h2[1][v][lane] : 0.0;
+          cons_to_prim<NS>(u, wp, g.Gamma_1);
+        } else {
 #pragma unroll
           for (int n = 0; n < NV; n++) wp[n] = s_w[row + 1][n][lane];
           if (!NS) wp[5] = 0.0;
@@ -727,7 +787,7 @@ k_correct_all(DevGrid g, Real dt, int kchunk)
       }
       __builtin_amdgcn_sched_barrier(0);
     }
-    if (!(X3F && CA_X3FIRST) && do3) {   // ---- x3: the register window; lam3 = lambda_l the zone below gave to this zone's lower face ----
+    if (!CA_X3FIRST && do3) {   // ---- x3: the register window; lam3 = lambda_l the zone below gave to this zone's lower face ----
       Real ll, lr;
       if (X3F) cell_finish<NS, 2, GRAV>(g, m, q, cf, wl3, wr3, full, ll, lr);
       else {
