@@ -969,17 +969,29 @@ __global__ void __launch_bounds__(64*FU_TJ)
 k_flux2_update(DevGrid g, const Real *dhalf, Real dt, int kchunk, KeepPlanes kp)
 {
   __shared__ Real s_f2[FU_TJ][6][64];
+  __shared__ Real s_f1e[FU_TJ - 1][6], s_f1s[FU_TJ - 1][6];
   const int lane = threadIdx.x, row = threadIdx.y;
-  const int i = g.is + blockIdx.x*63 + lane, j = g.js + blockIdx.y*(FU_TJ - 1) + row;
+  // Tiles of 64 x (FU_TJ - 1) zones; the rows start on a 128-byte line (zone is) and do not overlap in x1: with a stride
+  // of 63 zones every 512-byte row request touched a fifth line and 512 zones took 9 tiles (rocprofv3: 559 B/zone fetched
+  // for 400 needed).  Every lane solves the LOWER x1 face of its zone; the one face a row lacks, the upper face of lane
+  // 63, is solved by the wavefront of the last thread row (which owns no zones: it solves the x2 faces above the tile and
+  // would idle during the x1 phase), lane r for zone row r, with the same software pipeline, and handed over through LDS
+  // behind the barrier the x2 phase has anyway.
+  const int i0 = g.is + blockIdx.x*64;
+  const int i = i0 + lane, j0 = g.js + blockIdx.y*(FU_TJ - 1), j = j0 + row;
   const int k0 = g.ks + blockIdx.z*kchunk;
   int k1 = k0 + kchunk - 1; if (k1 > g.ke) k1 = g.ke;
   constexpr int NV = 5 + NS;
-  const bool cell = (lane < 63) && (row < FU_TJ - 1) && (i <= g.ie) && (j <= g.je);
-  const bool need1 = (row < FU_TJ - 1) && (j <= g.je) && (i <= g.ie + 1);      // lower x1 face of (i,j)
-  const bool need2 = (lane < 63) && (i <= g.ie) && (j <= g.je + 1);            // lower x2 face of (i,j)
+  const bool cell = (row < FU_TJ - 1) && (i <= g.ie) && (j <= g.je);
+  const bool edge = (row == FU_TJ - 1) && (lane < FU_TJ - 1) && (j0 + lane <= g.je) && (i0 + 64 <= g.ie + 1);   // x1 face i0+64 of row `lane`
+  const bool need1 = ((row < FU_TJ - 1) && (j <= g.je) && (i <= g.ie + 1)) || edge;     // lower x1 face of (i,j) / the edge face
+  const bool need2 = (i <= g.ie) && (j <= g.je + 1);                                     // lower x2 face of (i,j)
+  const bool last = (row < FU_TJ - 1) && (lane == 63) && (i < g.ie + 1);                 // its upper x1 face comes from the edge wavefront
   // clamp the column of idle threads into the Grid so that shuffles / barriers stay uniform
   const int ic = (i <= g.ie + 1) ? i : g.ie + 1, jc = (j <= g.je + 1) ? j : g.je + 1;
   const long mcol = (long)jc*g.sJ + ic;
+  // where this thread's x1 face is, relative to its zone: 0, or for the edge wavefront the hop to (i0 + 64, j0 + lane)
+  const long m1off = edge ? ((long)(j0 + lane)*g.sJ + (i0 + 64)) - mcol : 0L;
   Real dtodx[3];
 #pragma unroll
   for (int d = 0; d < 3; d++) dtodx[d] = dt/g.dx[d];
@@ -987,7 +999,7 @@ k_flux2_update(DevGrid g, const Real *dhalf, Real dt, int kchunk, KeepPlanes kp)
   Real f3lo[6], d1[6], d2[6], d3[6], m1lo = 0.0, m1hi = 0.0, m2lo = 0.0, m2hi = 0.0, m3hi = 0.0;
 #pragma unroll
   for (int n = 0; n < 6; n++) f3lo[n] = 0.0;
-  const bool keep1 = KEEP && need1 && on_plane(kp, 0, i), keep2 = KEEP && need2 && on_plane(kp, 1, j);
+  const bool keep1 = KEEP && need1 && on_plane(kp, 0, edge ? i0 + 64 : i), keep2 = KEEP && need2 && on_plane(kp, 1, j);
   if (cell) {                                                                   // face k0
     face_flux2<NS, 2>(g, (long)k0*g.sK + mcol, f3lo);
     if (KEEP && on_plane(kp, 2, k0)) store_sweep<2, NS>(Ff(g, 2, 0), g.nc, (long)k0*g.sK + mcol, f3lo);
@@ -997,7 +1009,7 @@ k_flux2_update(DevGrid g, const Real *dhalf, Real dt, int kchunk, KeepPlanes kp)
   // wavefronts per SIMD the memory pipe is not idle while a wavefront computes.
   FaceIn in1, in2;
   {
-    long m0 = (long)k0*g.sK + mcol;
+    long m0 = (long)k0*g.sK + mcol + m1off;
     asm volatile("" : "+v"(m0));
     if (need1) face_load<NS, 0>(g, m0, in1);
   }
@@ -1013,10 +1025,18 @@ k_flux2_update(DevGrid g, const Real *dhalf, Real dt, int kchunk, KeepPlanes kp)
 #pragma unroll
       for (int n = 0; n < 6; n++) f[n] = 0.0;
       if (need1) face_solve<NS>(g, in1, f);
-      if (keep1) store_sweep<0, NS>(Ff(g, 0, 0), g.nc, m, f);
+      if (keep1) store_sweep<0, NS>(Ff(g, 0, 0), g.nc, m + m1off, f);
 #pragma unroll
       for (int n = 0; n < NV; n++) d1[n] = __shfl_down(f[n], 1) - f[n];
       m1lo = f[0]; m1hi = __shfl_down(f[0], 1);
+      if (edge) {
+#pragma unroll
+        for (int n = 0; n < NV; n++) s_f1e[lane][n] = f[n];
+      }
+      if (last) {
+#pragma unroll
+        for (int n = 0; n < NV; n++) s_f1s[row][n] = f[n];
+      }
     }
     __builtin_amdgcn_sched_barrier(0);
     if (cell) face_load<NS, 2>(g, m + g.sK, in1);           // (in1 is free: reused for the x3 face)
@@ -1036,6 +1056,11 @@ k_flux2_update(DevGrid g, const Real *dhalf, Real dt, int kchunk, KeepPlanes kp)
         m2hi = s_f2[row + 1][0][lane];
       }
       m2lo = f[0];
+      if (last) {           // the same subtraction as in the other lanes, operands through LDS
+#pragma unroll
+        for (int n = 0; n < NV; n++) d1[n] = s_f1e[row][n] - s_f1s[row][n];
+        m1hi = s_f1e[row][0];
+      }
       __syncthreads();
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -1044,7 +1069,7 @@ k_flux2_update(DevGrid g, const Real *dhalf, Real dt, int kchunk, KeepPlanes kp)
     for (int n = 0; n < 6; n++) f3[n] = 0.0;
     if (cell) face_solve<NS>(g, in1, f3);
     __builtin_amdgcn_sched_barrier(0);
-    if (need1 && k < k1) face_load<NS, 0>(g, m + g.sK, in1);  // the next zone's x1 face
+    if (need1 && k < k1) face_load<NS, 0>(g, m + m1off + g.sK, in1);  // the next zone's x1 face
     __builtin_amdgcn_sched_barrier(0);
     if (cell) {
       if (KEEP && on_plane(kp, 2, k + 1)) store_sweep<2, NS>(Ff(g, 2, 0), g.nc, m + g.sK, f3);
@@ -1663,8 +1688,8 @@ void launch_flux2_update(const DevGrid &g, int nscal, Real dt, bool grav, const 
 {
   const int ni = g.ie - g.is + 1, nj = g.je - g.js + 1, nk = g.ke - g.ks + 1;
   int kc = 32;
-  while (kc > 4 && (long)nblk(ni, 63)*nblk(nj, FU_TJ - 1)*((nk + kc - 1)/kc) < 1024) kc >>= 1;
-  dim3 grid(nblk(ni, 63), nblk(nj, FU_TJ - 1), (nk + kc - 1)/kc), blk(64, FU_TJ);
+  while (kc > 4 && (long)nblk(ni, 64)*nblk(nj, FU_TJ - 1)*((nk + kc - 1)/kc) < 1024) kc >>= 1;
+  dim3 grid(nblk(ni, 64), nblk(nj, FU_TJ - 1), (nk + kc - 1)/kc), blk(64, FU_TJ);
   if (nscal) { if (grav) launch_fu<1, true>(g, dt, kc, grid, blk, keep, st); else launch_fu<1, false>(g, dt, kc, grid, blk, keep, st); }
   else       { if (grav) launch_fu<0, true>(g, dt, kc, grid, blk, keep, st); else launch_fu<0, false>(g, dt, kc, grid, blk, keep, st); }
 }
