@@ -97,6 +97,7 @@ KERNEL_BYTES = {
     "ion_begin": 8 * (6 + 6), "ion_finish": 8 * 2,
     "bvals_mhd": 0, "new_dt": 8 * 5, "pinned_cells": 0, "ppm_slopes": 3 * 8 * (6 + 6),
 }
+CORRECT_ALL_X3_BYTES = 8 * (6 + 12 + 4 + 36 + 3 + 1)   # k_correct_all with the x3 first pass inside (no x3 first-pass fluxes in HBM)
 HYDRO_KERNELS = ("sweep_", "sweep_correct_x1", "correct_", "flux2_", "update", "vl_", "ppm_slopes")
 SUBCYCLE_KERNELS = ("ray_sweep", "ray_sweep_rates", "ion_rates", "ion_update", "ion_pass", "ion_pass_first", "ion_pass_last", "ion_pass_begin",
                     "ion_pick")
@@ -284,7 +285,10 @@ def bench_smr(a, aa, torch, rank, world, local):
                 l, k, ms, n = dom
                 cfg = grids[l].cfg if hasattr(grids[l], "cfg") else lv[l]
                 ncell = cfg.Nx[0] * cfg.Nx[1] * cfg.Nx[2]
-                bpl = KERNEL_BYTES.get(k, 0) * ncell
+                kb = KERNEL_BYTES.get(k, 0)
+                if k == "correct_all" and f"L{l}.sweep_x3" not in prof:
+                    kb = CORRECT_ALL_X3_BYTES
+                bpl = kb * ncell
                 ach = bpl / (ms / n * 1e-3) / 1e9
                 out["roofline"] = {"bound": "hbm", "kernel": f"L{l}.{k}", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                    "frac": ach / HBM_PEAK_GBS, "traffic": None, "bytes_per_launch": bpl, "avg_launch_ms": ms / n}
@@ -467,7 +471,10 @@ def main():
             if dom:
                 ms, n = prof[dom]
                 scale = (nvar / 6.0) if kernel_class(dom) == "hydro" else 1.0
-                bpl = KERNEL_BYTES[dom] * zones_gpu * scale
+                kb = KERNEL_BYTES[dom]
+                if dom == "correct_all" and "sweep_x3" not in prof:
+                    kb = CORRECT_ALL_X3_BYTES       # the x3 first pass rides along: its fluxes are neither written nor read
+                bpl = kb * zones_gpu * scale
                 ach = bpl / (ms / n * 1e-3) / 1e9
                 # measured HBM bytes per launch of that kernel: from the committed rocprofv3 PMC passes of
                 # this same command (profiles/r02_traffic.json); only valid for the workload it was taken on
@@ -483,7 +490,7 @@ def main():
                     pass
                 out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                    "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "bytes_per_launch": bpl,
-                                   "bytes_basis": f"{KERNEL_BYTES[dom] * scale:g} B/zone: the distinct doubles this kernel must read + write (DESIGN.md section 3)",
+                                   "bytes_basis": f"{kb * scale:g} B/zone: the distinct doubles this kernel must read + write (DESIGN.md section 3)",
                                    "avg_launch_ms": ms / n}
             # 2. the phases of the step on SURVEY 8(d)'s algorithmic bytes: hydro chain 2*NVAR*8 B per
             #    cell-update, radiation 64 B per cell and sub-cycle
