@@ -416,7 +416,9 @@ k_sweep_x1(DevGrid g, const Real *src, Real dt, int koff)
 // passes U and the first-pass fluxes are read once instead of three / two times and no flux plane is
 // re-read; lane 0 and row 0 of a block repeat the last lane / row of the block before as providers.
 // Every expression is face_correct's, in the same order: bit-identical under -ffp-contract=off.
+#ifndef CA_TJ
 #define CA_TJ 4
+#endif
 // Primitive variables of one zone for all three sweeps.  cons_to_prim sums the squared momenta in the
 // order of the sweep frame, (Mx^2 + My^2) + Mz^2 with x = D, so the pressure differs in the last bit
 // between the frames: w (global frame d, V1, V2, V3, P, r) carries the pressure of the x3 sweep, p0 and
@@ -924,7 +926,9 @@ k_update(DevGrid g, const Real *dhalf, Real dt, Order ord)
 // order per zone are those of k_flux2 / k_update, so results are bit-identical to the unfused chain.
 // Levels of a Mesh (KEEP): RestrictCorrect reads the second-pass fluxes on the level boundaries, so the
 // faces on those planes (KeepPlanes: a few planes per direction) are stored as well.
+#ifndef FU_TJ
 #define FU_TJ 8
+#endif
 // operands of one second-pass Riemann problem: the corrected face states (sweep frame) and the 9 etas
 struct FaceIn { Real ul[6], ur[6], eta[9]; };
 template <int NS, int D>
