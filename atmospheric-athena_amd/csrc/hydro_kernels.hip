@@ -972,8 +972,10 @@ template <int NS, bool GRAV, bool KEEP>
 __global__ void __launch_bounds__(64*FU_TJ)
 k_flux2_update(DevGrid g, const Real *dhalf, Real dt, int kchunk, KeepPlanes kp)
 {
-  __shared__ Real s_f2[FU_TJ][6][64];
-  __shared__ Real s_f1e[FU_TJ - 1][6], s_f1s[FU_TJ - 1][6];
+  // (two copies of the exchange arrays, used in turn: ONE barrier per plane instead of a second one that only kept the
+  //  next plane's writers off this plane's readers -- 8 wavefronts, a whole CU, wait at every barrier of this block)
+  __shared__ Real s_f2[2][FU_TJ][6][64];
+  __shared__ Real s_f1e[2][FU_TJ - 1][6], s_f1s[2][FU_TJ - 1][6];
   const int lane = threadIdx.x, row = threadIdx.y;
   // Tiles of 64 x (FU_TJ - 1) zones; the rows start on a 128-byte line (zone is) and do not overlap in x1: with a stride
   // of 63 zones every 512-byte row request touched a fifth line and 512 zones took 9 tiles (rocprofv3: 559 B/zone fetched
@@ -1022,6 +1024,7 @@ k_flux2_update(DevGrid g, const Real *dhalf, Real dt, int kchunk, KeepPlanes kp)
     //  strength-reduced 64-bit induction variable and the kernel spills)
     long m = (long)k*g.sK + mcol;
     asm volatile("" : "+v"(m));
+    const int pb = k & 1;
     if (need2) face_load<NS, 1>(g, m, in2);
     __builtin_amdgcn_sched_barrier(0);
     {
@@ -1035,11 +1038,11 @@ k_flux2_update(DevGrid g, const Real *dhalf, Real dt, int kchunk, KeepPlanes kp)
       m1lo = f[0]; m1hi = __shfl_down(f[0], 1);
       if (edge) {
 #pragma unroll
-        for (int n = 0; n < NV; n++) s_f1e[lane][n] = f[n];
+        for (int n = 0; n < NV; n++) s_f1e[pb][lane][n] = f[n];
       }
       if (last) {
 #pragma unroll
-        for (int n = 0; n < NV; n++) s_f1s[row][n] = f[n];
+        for (int n = 0; n < NV; n++) s_f1s[pb][row][n] = f[n];
       }
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -1052,20 +1055,19 @@ k_flux2_update(DevGrid g, const Real *dhalf, Real dt, int kchunk, KeepPlanes kp)
       if (need2) face_solve<NS>(g, in2, f);
       if (keep2) store_sweep<1, NS>(Ff(g, 1, 0), g.nc, m, f);
 #pragma unroll
-      for (int n = 0; n < NV; n++) s_f2[row][n][lane] = f[n];
+      for (int n = 0; n < NV; n++) s_f2[pb][row][n][lane] = f[n];
       __syncthreads();
       if (row < FU_TJ - 1) {
 #pragma unroll
-        for (int n = 0; n < NV; n++) d2[n] = s_f2[row + 1][n][lane] - f[n];
-        m2hi = s_f2[row + 1][0][lane];
+        for (int n = 0; n < NV; n++) d2[n] = s_f2[pb][row + 1][n][lane] - f[n];
+        m2hi = s_f2[pb][row + 1][0][lane];
       }
       m2lo = f[0];
       if (last) {           // the same subtraction as in the other lanes, operands through LDS
 #pragma unroll
-        for (int n = 0; n < NV; n++) d1[n] = s_f1e[row][n] - s_f1s[row][n];
-        m1hi = s_f1e[row][0];
+        for (int n = 0; n < NV; n++) d1[n] = s_f1e[pb][row][n] - s_f1s[pb][row][n];
+        m1hi = s_f1e[pb][row][0];
       }
-      __syncthreads();
     }
     __builtin_amdgcn_sched_barrier(0);
     Real f3[6];
