@@ -106,6 +106,7 @@ int aa_create(const aa_params *p, aa_grid **out)
   // blast step, -4.2 ms ifront, -4.4 / -2.0 ms third order without / with gravity.  The one combination it does not pay
   // for is second order + passive scalar + gravity (ioniz_sphere: the kernel is bound by its own instruction stream
   // there, 249 VGPRs at 2 waves per SIMD, and the step gets 0.6-0.9 ms slower): left to the sweep kernel.  Same bits.
+  { const char *e = getenv("AA_CFL_FUSED"); g->cfl_step = e ? atoi(e) != 0 : true; }     // aa_step: new_dt's maxima from the update kernel
   { const char *e = getenv("AA_X3_FUSED"); g->x3_fused_mode = e ? (atoi(e) != 0) : -1; }    // (the potential arrives after aa_create)
   // rates inside the ray sweep: one block per 64 rays, so it needs many rays to fill the chip (512^2 rays:
   // -2.9 ms per step; 80^2 rays: +6 %); same results either way
@@ -195,6 +196,7 @@ void aa_destroy(aa_grid *g)
   if (g->ion_words) hipFree(g->ion_words);
   if (g->pin_idx) hipFree(g->pin_idx);
   if (g->pin_val) hipFree(g->pin_val);
+  if (g->pin_mask) hipFree(g->pin_mask);
   if (g->own_stream) hipStreamDestroy(g->st);
   delete g;
 }
@@ -213,6 +215,7 @@ long long aa_device_bytes(const aa_grid *g) { return g->slab.empty() ? g->bytes 
 // ---- state transfer: staging through the (idle) face-state area ---------------------------
 int aa_upload_cons(aa_grid *g, const double *U)
 {
+  g->cfl_ready = false;
   if (!g->slab.empty()) return slabs_upload_cons(g, U);
   const int nvar = 5 + g->p.nscal; const size_t n = (size_t)g->d.N1*g->d.N2*g->d.N3*nvar;
   HIPCHK(hipMemcpyAsync(g->d.LR, U, n*sizeof(Real), hipMemcpyHostToDevice, g->st));
@@ -307,13 +310,18 @@ int aa_set_pinned_cells(aa_grid *g, long long n, const long long *index, const d
   if (!g->slab.empty()) return slabs_set_pinned_cells(g, n, index, values);
   if (g->pin_idx) { hipFree(g->pin_idx); g->pin_idx = nullptr; }
   if (g->pin_val) { hipFree(g->pin_val); g->pin_val = nullptr; }
+  if (g->pin_mask) { hipFree(g->pin_mask); g->pin_mask = nullptr; }
   g->npin = 0;
+  g->cfl_ready = false;
   if (n <= 0) return 0;
   const int nvar = 5 + g->p.nscal;
   HIPCHK(hipMalloc(&g->pin_idx, (size_t)n*sizeof(long long)));
   HIPCHK(hipMalloc(&g->pin_val, (size_t)n*nvar*sizeof(Real)));
   HIPCHK(hipMemcpy(g->pin_idx, index, (size_t)n*sizeof(long long), hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(g->pin_val, values, (size_t)n*nvar*sizeof(Real), hipMemcpyHostToDevice));
+  HIPCHK(hipMalloc(&g->pin_mask, (size_t)g->d.nc));
+  HIPCHK(hipMemsetAsync(g->pin_mask, 0, (size_t)g->d.nc, g->st));
+  launch_pin_mask(g->d, n, g->pin_idx, g->pin_mask, g->st);
   g->npin = n;
   return 0;
 }
@@ -322,6 +330,7 @@ int aa_apply_pinned_cells(aa_grid *g)
   if (!g->slab.empty()) return slabs_apply_pinned_cells(g);
   Scope s(g, "pinned_cells");
   launch_pinned(g->d, 5 + g->p.nscal, g->npin, g->pin_idx, g->pin_val, g->st);
+  if (g->cfl_ready) launch_pinned_cfl(g->d, g->npin, g->pin_idx, g->sc, g->st);     // they were left out of the integrator's maxima
   return 0;
 }
 
@@ -384,7 +393,8 @@ int aa_fetch_scalars(aa_grid *g)
 int aa_new_dt_local(aa_grid *g, double *dt_cfl)
 {
   if (!g->slab.empty()) return slabs_new_dt_local(g, dt_cfl);
-  { Scope s(g, "new_dt");
+  if (g->cfl_ready) g->cfl_ready = false;        // the integrator (+ aa_apply_pinned_cells) has left the maxima in g->sc
+  else { Scope s(g, "new_dt");
     HIPCHK(hipMemsetAsync(g->sc->max_v, 0, 3*sizeof(unsigned long long), g->st));
     launch_cfl(g->d, g->sc, g->st); }
   int rc = fetch_scalars(g); if (rc) return rc;
@@ -397,7 +407,8 @@ int aa_new_dt_local(aa_grid *g, double *dt_cfl)
 int aa_cfl_max_v(aa_grid *g, double *v)      // new_dt.c:72-140 of this Grid: max(|v_d| + a) per direction
 {
   if (!g->slab.empty()) return slabs_cfl_max_v(g, v);
-  { Scope s(g, "new_dt");
+  if (g->cfl_ready) g->cfl_ready = false;        // the integrator (+ aa_apply_pinned_cells) has left the maxima in g->sc
+  else { Scope s(g, "new_dt");
     HIPCHK(hipMemsetAsync(g->sc->max_v, 0, 3*sizeof(unsigned long long), g->st));
     launch_cfl(g->d, g->sc, g->st); }
   int rc = fetch_scalars(g); if (rc) return rc;
@@ -418,6 +429,19 @@ int aa_new_dt(aa_grid *g)
 // blast step, -4.2 ms ifront, -4.4 / -2.0 ms third order without / with gravity.  The one combination it does not pay for
 // is second order + passive scalar + gravity (ioniz_sphere: the kernel is bound by its own instruction stream there,
 // 249 VGPRs at 2 waves per SIMD, and the step gets 0.6-0.9 ms slower): left to the sweep kernel.  Same bits either way.
+// aa_cfl_in_update: zero the maxima and let k_flux2_update fill them
+static void cfl_arm(aa_grid *g)
+{
+  g->cfl_ready = g->cfl_in_update && (g->npin == 0 || g->pin_mask);
+  if (g->cfl_ready) (void)hipMemsetAsync(g->sc->max_v, 0, 3*sizeof(unsigned long long), g->st);
+}
+int aa_cfl_in_update(aa_grid *g, int on)
+{
+  if (!g->slab.empty()) return 0;      // (composite Grids keep k_cfl)
+  g->cfl_in_update = on != 0; g->cfl_ready = false;
+  return 0;
+}
+
 static bool x3_fused(const aa_grid *g)
 { return g->x3_fused_mode >= 0 ? g->x3_fused_mode != 0 : !(g->p.nscal > 0 && g->grav && !g->d.slope); }
 
@@ -442,6 +466,7 @@ int aa_integrate_begin(aa_grid *g)
 int aa_integrate_3d_ctu(aa_grid *g)
 {
   if (!g->slab.empty()) return slabs_integrate(g, 0);
+  g->cfl_ready = false;
   const DevGrid &d = g->d; const int ns = g->p.nscal; const Real dt = g->dt;
   if (g->inner_swept) {      // aa_integrate_begin did the planes ks .. ke: the two ghost planes either side remain
     if (g->inner_dt != dt) return fail(-1, "[aa_integrate_3d_ctu]: dt changed after aa_integrate_begin");
@@ -452,7 +477,8 @@ int aa_integrate_3d_ctu(aa_grid *g)
     if (!x3_fused(g)) { Scope s(g, "sweep_x3"); launch_sweep(d, ns, 2, dt, g->grav, g->st); }
     { Scope s(g, "correct_all"); launch_correct_all(d, ns, dt, g->grav, x3_fused(g), g->st); }
     Scope s(g, "flux2_update");
-    launch_flux2_update(d, ns, dt, g->grav, g->keep_flux ? &g->keep : nullptr, g->st);
+    cfl_arm(g);
+    launch_flux2_update(d, ns, dt, g->grav, g->keep_flux ? &g->keep : nullptr, g->st, g->cfl_ready ? g->sc : nullptr, g->pin_mask);
     HIPCHK(hipGetLastError());
     return 0;
   }
@@ -469,7 +495,9 @@ int aa_integrate_3d_ctu(aa_grid *g)
     { Scope s(g, "correct_x3"); launch_correct(d, ns, 2, dt, g->grav, g->st); }
   }
   if (g->fused_update) {
-    Scope s(g, "flux2_update"); launch_flux2_update(d, ns, dt, g->grav, g->keep_flux ? &g->keep : nullptr, g->st);
+    Scope s(g, "flux2_update");
+    cfl_arm(g);
+    launch_flux2_update(d, ns, dt, g->grav, g->keep_flux ? &g->keep : nullptr, g->st, g->cfl_ready ? g->sc : nullptr, g->pin_mask);
   } else {
     { Scope s(g, "flux2_x1"); launch_flux2(d, ns, 0, g->st); }
     { Scope s(g, "flux2_x2"); launch_flux2(d, ns, 1, g->st); }
@@ -483,6 +511,7 @@ int aa_integrate_3d_ctu(aa_grid *g)
 int aa_integrate_3d_vl(aa_grid *g)
 {
   if (!g->slab.empty()) return slabs_integrate(g, 1);
+  g->cfl_ready = false;
   // integrate_3d_vl.c:96-: donor-cell fluxes -> U^{n+1/2} -> PLM (no tracing) + Roe -> update
   const DevGrid &d = g->d; const int ns = g->p.nscal; const Real dt = g->dt;
   // donor-cell fluxes + U^{n+1/2} in one marching kernel from 2^18 zones (512^3: 16.8 -> 9.7 ms; same at 80^3;
@@ -502,6 +531,7 @@ int aa_integrate_3d_vl(aa_grid *g)
 
 int aa_ion_begin(aa_grid *g)
 {
+  g->cfl_ready = false;
   if (!g->p.ion) return fail(-1, "[ion_radtransfer]: ion radiation is off");
   if (!g->slab.empty()) return slabs_ion_begin(g);
   if (g->ion_fused) {
@@ -548,6 +578,7 @@ int aa_ion_rates(aa_grid *g, double *dt_chem, double *dt_therm)
 
 int aa_ion_update(aa_grid *g, double dt, long long *cellcount, double *dt_hydro)
 {
+  g->cfl_ready = false;
   if (!g->slab.empty()) return slabs_ion_update(g, dt, cellcount, dt_hydro);
   if (g->ion_fused) return fail(-1, "[aa_ion_update]: this Grid runs the one-kernel sub-cycle (aa_ion_pass / aa_ion_pick / aa_ion_fetch)");
   HIPCHK(hipMemsetAsync(&g->sc->max_dti, 0, 2*sizeof(unsigned long long), g->st));
@@ -572,6 +603,7 @@ int aa_ion_arm(aa_grid *g)
 int aa_ion_subcycle(aa_grid *g, double dt_done, double limit, double *dt, int *limit_hit, double *dt_chem,
                     double *dt_therm, long long *cellcount, double *dt_hydro)
 {
+  g->cfl_ready = false;
   if (g->ion_fused) return fail(-1, "[aa_ion_subcycle]: this Grid runs the one-kernel sub-cycle");
   if (g->nradplane > 0) {
     const Real flux0 = g->flux_i*(5.*(erf((g->time - 1.2e5)/8e4)+1)+0.1);     // ionradplane_3d.c:265
@@ -601,6 +633,7 @@ int aa_ion_is_fused(const aa_grid *g) { return g->ion_fused ? 1 : 0; }
 // Grid's words of the reduction go to dev_words (DEVICE, AA_ION_WORDS doubles; NULL: kept in the Grid)
 int aa_ion_pass(aa_grid *g, int update, int sweep, double *dev_words)
 {
+  g->cfl_ready = false;
   if (!g->ion_fused) return fail(-1, "[aa_ion_pass]: this Grid runs the two-kernel sub-cycle (aa_ion_rates / aa_ion_update)");
   if (!g->slab.empty()) {
     if (dev_words) return fail(-1, "[aa_ion_pass]: a Grid cut into slabs reduces over its slabs itself");
@@ -729,6 +762,7 @@ static int ion_run_phased(aa_grid *g, bool fine, double limit, int *niter_out, d
 
 int aa_ion_run(aa_grid *g, int finegrid, double limit, int *niter_out, double *dt_done_out)
 {
+  g->cfl_ready = false;
   if (!g->slab.empty() && !g->ion_fused) return slabs_ion_run_phased(g, limit, niter_out, dt_done_out);
   return g->ion_fused ? ion_run_fused(g, finegrid != 0, limit, niter_out, dt_done_out)
                       : ion_run_phased(g, finegrid != 0, limit, niter_out, dt_done_out);
@@ -767,7 +801,12 @@ int aa_step(aa_grid *g, int *niter_out)
     if ((rc = aa_ion_radtransfer_3d(g, &niter))) return rc;
     if ((rc = aa_bvals_mhd(g))) return rc;
   }
-  if ((rc = (g->p.integrator == 1 ? aa_integrate_3d_vl(g) : aa_integrate_3d_ctu(g)))) return rc;   // :572-585
+  // (between the integrator and new_dt this loop only pins zones: the integrator may leave new_dt's maxima behind)
+  const bool keep_opt = g->cfl_in_update;
+  if (g->slab.empty() && g->cfl_step) g->cfl_in_update = true;
+  rc = (g->p.integrator == 1 ? aa_integrate_3d_vl(g) : aa_integrate_3d_ctu(g));                    // :572-585
+  g->cfl_in_update = keep_opt;
+  if (rc) return rc;
   if (g->npin > 0 && (rc = aa_apply_pinned_cells(g))) return rc;   // Userwork_in_loop :597
   g->nstep++; g->time += g->dt;                              // :618-626
   if ((rc = aa_new_dt(g))) return rc;                        // :629

@@ -24,6 +24,10 @@ struct aa_grid {
   aa::DevScalars *sc = nullptr;        // device
   aa::DevScalars *sc_host = nullptr;   // pinned
   long long *pin_idx = nullptr; aa::Real *pin_val = nullptr; long long npin = 0;
+  unsigned char *pin_mask = nullptr;   // 1 where a zone is pinned (k_flux2_update<CFL> leaves those to k_pinned_cfl)
+  bool cfl_in_update = false;          // aa_cfl_in_update: the integrator also leaves new_dt's maxima behind
+  bool cfl_step = true;                // aa_step does so by itself (AA_CFL_FUSED=0: k_cfl)
+  bool cfl_ready = false;              //   ... and has done so for the state as it is now
   bool grav = false;
   int rad_dir = 0, nradplane = 0; aa::Real flux_i = 0;
   int level = 0;                       // DomainS.Level: > 0 only as a level of an aa_mesh

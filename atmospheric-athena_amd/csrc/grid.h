@@ -97,7 +97,10 @@ void launch_update(const DevGrid &g, int nscal, const Real *dhalf, Real dt, bool
 // face planes (index along the normal, incl. ghost offset) whose second-pass fluxes the fused kernel also
 // stores: the level boundaries static mesh refinement reads back (smr.hip)
 struct KeepPlanes { int n; int p[3][4]; };
-void launch_flux2_update(const DevGrid &g, int nscal, Real dt, bool grav, const KeepPlanes *keep, hipStream_t st);   // flux2 x3 + update fused
+void launch_flux2_update(const DevGrid &g, int nscal, Real dt, bool grav, const KeepPlanes *keep, hipStream_t st,
+                         DevScalars *sc = nullptr, const unsigned char *pinmask = nullptr);   // sc: also new_dt's maxima (k_flux2_update<CFL>)
+void launch_pinned_cfl(const DevGrid &g, long long n, const long long *idx, DevScalars *sc, hipStream_t st);
+void launch_pin_mask(const DevGrid &g, long long n, const long long *idx, unsigned char *mask, hipStream_t st);   // flux2 x3 + update fused
 void launch_vl_flux1(const DevGrid &g, int nscal, int dir, hipStream_t st);
 void launch_vl_uhalf(const DevGrid &g, int nscal, Real dt, bool grav, hipStream_t st);
 void launch_vl_predict(const DevGrid &g, int nscal, Real dt, bool grav, hipStream_t st);   // vl_flux1 x3 + vl_uhalf fused

@@ -963,14 +963,30 @@ AA_DEV void face_flux2(const DevGrid &g, long m, Real f[6])
   face_solve<NS>(g, in, f);
 }
 
+// new_dt.c:72-140 for one zone: max(|v_d| + a) per direction (the operands and their order as in k_cfl)
+AA_DEV void cfl_zone(Real d, Real m1, Real m2, Real m3, Real e, Real Gamma, Real Gamma_1, Real mx[3])
+{
+  const Real di = 1.0/d;
+  const Real v1 = m1*di, v2 = m2*di, v3 = m3*di;
+  const Real qsq = v1*v1 + v2*v2 + v3*v3;
+  const Real p = rmax(Gamma_1*(e - 0.5*d*qsq), AA_TINY);
+  const Real a = sqrt(Gamma*p*di);
+  mx[0] = rmax(mx[0], fabs(v1) + a); mx[1] = rmax(mx[1], fabs(v2) + a); mx[2] = rmax(mx[2], fabs(v3) + a);
+}
+AA_DEV void atomic_max_pos(unsigned long long *addr, Real v)
+{ if (v == v) atomicMax(addr, (unsigned long long)__double_as_longlong(v)); }   // v >= 0; NaN skipped
+
 AA_DEV bool on_plane(const KeepPlanes &kp, int d, int x)
 {
   return x == kp.p[d][0] || x == kp.p[d][1] || x == kp.p[d][2] || x == kp.p[d][3];
 }
 
-template <int NS, bool GRAV, bool KEEP>
+// CFL: the zone's contribution to new_dt's maxima is taken from the updated state while it is in registers (k_cfl would
+// read the five fields again: 0.9 ms at 512^3); zones marked in `pinmask` are left out, the caller adds them after it
+// has overwritten them (k_pinned_cfl).
+template <int NS, bool GRAV, bool KEEP, bool CFL>
 __global__ void __launch_bounds__(64*FU_TJ)
-k_flux2_update(DevGrid g, const Real *dhalf, Real dt, int kchunk, KeepPlanes kp)
+k_flux2_update(DevGrid g, const Real *dhalf, Real dt, int kchunk, KeepPlanes kp, DevScalars *sc, const unsigned char *pinmask)
 {
   // (two copies of the exchange arrays, used in turn: ONE barrier per plane instead of a second one that only kept the
   //  next plane's writers off this plane's readers -- 8 wavefronts, a whole CU, wait at every barrier of this block)
@@ -1003,6 +1019,10 @@ k_flux2_update(DevGrid g, const Real *dhalf, Real dt, int kchunk, KeepPlanes kp)
   for (int d = 0; d < 3; d++) dtodx[d] = dt/g.dx[d];
   // per direction: flux differences (hi - lo) of all components + the two mass fluxes (gravity)
   Real f3lo[6], d1[6], d2[6], d3[6], m1lo = 0.0, m1hi = 0.0, m2lo = 0.0, m2hi = 0.0, m3hi = 0.0;
+  // CFL: the thread's running maxima live in LDS (its own three slots), not in registers carried round the loop: the
+  // 6-variable gravity kernel has none to spare (6 spilled, 16.1 against 14.0 ms)
+  __shared__ Real s_cmx[CFL ? 3 : 1][CFL ? FU_TJ : 1][CFL ? 64 : 1];
+  if (CFL) { s_cmx[0][row][lane] = 0.0; s_cmx[1][row][lane] = 0.0; s_cmx[2][row][lane] = 0.0; }
 #pragma unroll
   for (int n = 0; n < 6; n++) f3lo[n] = 0.0;
   const bool keep1 = KEEP && need1 && on_plane(kp, 0, edge ? i0 + 64 : i), keep2 = KEEP && need2 && on_plane(kp, 1, j);
@@ -1109,8 +1129,59 @@ k_flux2_update(DevGrid g, const Real *dhalf, Real dt, int kchunk, KeepPlanes kp)
       for (int n = 0; n < NV; n++) u[gv<2>(n)] -= dtodx[2]*d3[n];
 #pragma unroll
       for (int v = 0; v < NV; v++) Uf(g, v)[m] = u[v];
+      if (CFL) {
+        if (!pinmask || !pinmask[m]) {
+          Real cmx[3] = {s_cmx[0][row][lane], s_cmx[1][row][lane], s_cmx[2][row][lane]};
+          cfl_zone(u[0], u[1], u[2], u[3], u[4], g.Gamma, g.Gamma_1, cmx);
+          s_cmx[0][row][lane] = cmx[0]; s_cmx[1][row][lane] = cmx[1]; s_cmx[2][row][lane] = cmx[2];
+        }
+      }
     }
   }
+  if (CFL) {       // block maximum -> 3 atomics (MAX of non-negative doubles on their bit patterns: order-free)
+    Real *red = &s_cmx[0][0][0];           // [d][row][lane] = [d*64*FU_TJ + t]
+    const int t = row*64 + lane;
+    __syncthreads();
+    for (int w = 32*FU_TJ; w > 0; w >>= 1) {
+      if (t < w) {
+#pragma unroll
+        for (int d = 0; d < 3; d++) red[d*64*FU_TJ + t] = rmax(red[d*64*FU_TJ + t], red[d*64*FU_TJ + t + w]);
+      }
+      __syncthreads();
+    }
+    if (t == 0) for (int d = 0; d < 3; d++) atomic_max_pos(&sc->max_v[d], red[d*64*FU_TJ]);
+  }
+}
+
+// the zones Userwork has just overwritten (k_pinned) join the maxima k_flux2_update<CFL> left them out of
+__global__ void k_pinned_cfl(DevGrid g, long long n, const long long *idx, DevScalars *sc)
+{
+  const long lin = (long)blockIdx.x*blockDim.x + threadIdx.x;
+  Real mx[3] = {0.0, 0.0, 0.0};
+  if (lin < n) {
+    const long long c = idx[lin];
+    const int i = (int)(c % g.N1), j = (int)((c / g.N1) % g.N2), k = (int)(c / ((long)g.N1*g.N2));
+    if (i >= g.is && i <= g.ie && j >= g.js && j <= g.je && k >= g.ks && k <= g.ke) {      // new_dt looks at active zones only
+      const long m = (long)k*g.sK + (long)j*g.sJ + i;
+      cfl_zone(Uf(g, 0)[m], Uf(g, 1)[m], Uf(g, 2)[m], Uf(g, 3)[m], Uf(g, 4)[m], g.Gamma, g.Gamma_1, mx);
+    }
+  }
+  // one atomic per wavefront and direction (NaN maxima are dropped by atomic_max_pos, as in k_cfl)
+#pragma unroll
+  for (int d = 0; d < 3; d++) {
+    Real v = mx[d];
+    for (int o = 32; o > 0; o >>= 1) { const Real w = __shfl_xor(v, o); v = (w > v || v != v) ? w : v; }
+    if ((threadIdx.x & 63) == 0) atomic_max_pos(&sc->max_v[d], v);
+  }
+}
+// byte mask of the pinned zones over the device array
+__global__ void k_pin_mask(DevGrid g, long long n, const long long *idx, unsigned char *mask)
+{
+  const long lin = (long)blockIdx.x*blockDim.x + threadIdx.x;
+  if (lin >= n) return;
+  const long long c = idx[lin];
+  const int i = (int)(c % g.N1), j = (int)((c / g.N1) % g.N2), k = (int)(c / ((long)g.N1*g.N2));
+  mask[(long)k*g.sK + (long)j*g.sJ + i] = 1;
 }
 
 // ---- van Leer integrator (integrators/integrate_3d_vl.c, NO_H_CORRECTION) --------------------
@@ -1364,9 +1435,6 @@ __global__ void k_bc(DevGrid g, int nvar, int d, int side, int flag, int flag1)
 }
 
 // ---- CFL reduction: new_dt.c:72-170 -----------------------------------------------------
-AA_DEV void atomic_max_pos(unsigned long long *addr, Real v)
-{ if (v == v) atomicMax(addr, (unsigned long long)__double_as_longlong(v)); }   // v >= 0; NaN skipped
-
 __global__ void __launch_bounds__(256)
 k_cfl(DevGrid g, DevScalars *sc)
 {
@@ -1378,12 +1446,7 @@ k_cfl(DevGrid g, DevScalars *sc)
     const int j = g.js + (int)((lin / ni) % nj);
     const int k = g.ks + (int)(lin / ((long)ni*nj));
     const long m = (long)k*g.sK + (long)j*g.sJ + i;
-    Real d = Uf(g, 0)[m], di = 1.0/d;
-    Real v1 = Uf(g, 1)[m]*di, v2 = Uf(g, 2)[m]*di, v3 = Uf(g, 3)[m]*di;
-    Real qsq = v1*v1 + v2*v2 + v3*v3;
-    Real p = rmax(g.Gamma_1*(Uf(g, 4)[m] - 0.5*d*qsq), AA_TINY);
-    Real a = sqrt(g.Gamma*p*di);
-    mx[0] = rmax(mx[0], fabs(v1) + a); mx[1] = rmax(mx[1], fabs(v2) + a); mx[2] = rmax(mx[2], fabs(v3) + a);
+    cfl_zone(Uf(g, 0)[m], Uf(g, 1)[m], Uf(g, 2)[m], Uf(g, 3)[m], Uf(g, 4)[m], g.Gamma, g.Gamma_1, mx);
   }
   __shared__ Real red[3][256];
   for (int d = 0; d < 3; d++) red[d][threadIdx.x] = mx[d];
@@ -1684,20 +1747,30 @@ void launch_flux2(const DevGrid &g, int nscal, int dir, hipStream_t st)
 
 // fused second-pass fluxes + update (CTU); `keep`: the face planes whose fluxes are stored as well
 template <int NS, bool GRAV>
-static void launch_fu(const DevGrid &g, Real dt, int kc, dim3 grid, dim3 blk, const KeepPlanes *keep, hipStream_t st)
+static void launch_fu(const DevGrid &g, Real dt, int kc, dim3 grid, dim3 blk, const KeepPlanes *keep, DevScalars *sc, const unsigned char *pinmask,
+                      hipStream_t st)
 {
   KeepPlanes none = {0, {{0}}};
-  if (keep && keep->n) hipLaunchKernelGGL((k_flux2_update<NS, GRAV, true>), grid, blk, 0, st, g, g.dhalf, dt, kc, *keep);
-  else                 hipLaunchKernelGGL((k_flux2_update<NS, GRAV, false>), grid, blk, 0, st, g, g.dhalf, dt, kc, none);
+  if (sc) {
+    if (keep && keep->n) hipLaunchKernelGGL((k_flux2_update<NS, GRAV, true, true>), grid, blk, 0, st, g, g.dhalf, dt, kc, *keep, sc, pinmask);
+    else                 hipLaunchKernelGGL((k_flux2_update<NS, GRAV, false, true>), grid, blk, 0, st, g, g.dhalf, dt, kc, none, sc, pinmask);
+  } else {
+    if (keep && keep->n) hipLaunchKernelGGL((k_flux2_update<NS, GRAV, true, false>), grid, blk, 0, st, g, g.dhalf, dt, kc, *keep, sc, pinmask);
+    else                 hipLaunchKernelGGL((k_flux2_update<NS, GRAV, false, false>), grid, blk, 0, st, g, g.dhalf, dt, kc, none, sc, pinmask);
+  }
 }
-void launch_flux2_update(const DevGrid &g, int nscal, Real dt, bool grav, const KeepPlanes *keep, hipStream_t st)
+void launch_pinned_cfl(const DevGrid &g, long long n, const long long *idx, DevScalars *sc, hipStream_t st)
+{ if (n > 0) hipLaunchKernelGGL(k_pinned_cfl, dim3(nblk(n, 256)), dim3(256), 0, st, g, n, idx, sc); }
+void launch_pin_mask(const DevGrid &g, long long n, const long long *idx, unsigned char *mask, hipStream_t st)
+{ if (n > 0) hipLaunchKernelGGL(k_pin_mask, dim3(nblk(n, 256)), dim3(256), 0, st, g, n, idx, mask); }
+void launch_flux2_update(const DevGrid &g, int nscal, Real dt, bool grav, const KeepPlanes *keep, hipStream_t st, DevScalars *sc, const unsigned char *pinmask)
 {
   const int ni = g.ie - g.is + 1, nj = g.je - g.js + 1, nk = g.ke - g.ks + 1;
   int kc = 32;
   while (kc > 4 && (long)nblk(ni, 64)*nblk(nj, FU_TJ - 1)*((nk + kc - 1)/kc) < 1024) kc >>= 1;
   dim3 grid(nblk(ni, 64), nblk(nj, FU_TJ - 1), (nk + kc - 1)/kc), blk(64, FU_TJ);
-  if (nscal) { if (grav) launch_fu<1, true>(g, dt, kc, grid, blk, keep, st); else launch_fu<1, false>(g, dt, kc, grid, blk, keep, st); }
-  else       { if (grav) launch_fu<0, true>(g, dt, kc, grid, blk, keep, st); else launch_fu<0, false>(g, dt, kc, grid, blk, keep, st); }
+  if (nscal) { if (grav) launch_fu<1, true>(g, dt, kc, grid, blk, keep, sc, pinmask, st); else launch_fu<1, false>(g, dt, kc, grid, blk, keep, sc, pinmask, st); }
+  else       { if (grav) launch_fu<0, true>(g, dt, kc, grid, blk, keep, sc, pinmask, st); else launch_fu<0, false>(g, dt, kc, grid, blk, keep, sc, pinmask, st); }
 }
 
 void launch_update(const DevGrid &g, int nscal, const Real *dhalf, Real dt, bool grav, hipStream_t st)

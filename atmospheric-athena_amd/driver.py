@@ -45,6 +45,9 @@ class HipEngine:
             # run the kernels on torch's current stream so that torch.distributed collectives and
             # torch.cuda.Event timing are ordered with them
             self.g.set_stream(torch.cuda.current_stream().cuda_stream)
+        # Driver.step calls integrate -> userwork (pinned zones only) -> new_dt in that order: the update kernel may
+        # leave new_dt's maxima behind (aa_cfl_in_update; AA_CFL_FUSED=0 keeps the separate sweep over the Grid)
+        self.g.cfl_in_update(os.environ.get("AA_CFL_FUSED", "1") != "0")
         n = self.g.halo_doubles()
         dev = torch.device("cuda", device)
         # the one-kernel radiation sub-cycle leaves this slab's reduction words in device memory; with several

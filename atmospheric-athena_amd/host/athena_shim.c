@@ -369,6 +369,11 @@ void new_dt(MeshS *pM)
         if (iw_prev[l]) { free(iw_prev[l]); free(vw_prev[l]); iw_prev[l] = NULL; vw_prev[l] = NULL; }
       }
       learned = 1;
+#ifndef AA_SMR
+      /* from now on nothing but the pinned zones changes between Integrate() and new_dt(): new_dt's maxima can come
+       * out of the update kernel (AA_CFL_FUSED=0 keeps the separate sweep) */
+      { const char *e = getenv("AA_CFL_FUSED"); CHK(aa_cfl_in_update(G[0], !(e && atoi(e) == 0))); }
+#endif
       if (automode && !term_hooked) {              /* from here on the host block is only as fresh as host_read_due() makes it */
         void (*h)(int) = signal(SIGTERM, on_term);
         if (h != on_term) old_term = h;

@@ -93,7 +93,7 @@ def load(strict: bool | None = None) -> C.CDLL:
         "aa_set_pinned_cells": (I, [P, LL, llp, dp]), "aa_apply_pinned_cells": (I, [P]),
         "aa_add_radplane_3d": (I, [P, I, D]), "aa_has_radplane": (I, [P]),
         "aa_bvals_mhd": (I, [P]), "aa_bvals_mhd_side": (I, [P, I, I]), "aa_bvals_ionrad": (I, [P]), "aa_new_dt": (I, [P]),
-        "aa_integrate_3d_ctu": (I, [P]), "aa_integrate_begin": (I, [P]), "aa_integrate_3d_vl": (I, [P]), "aa_ion_radtransfer_3d": (I, [P, ip]),
+        "aa_integrate_3d_ctu": (I, [P]), "aa_integrate_begin": (I, [P]), "aa_cfl_in_update": (I, [P, I]), "aa_integrate_3d_vl": (I, [P]), "aa_ion_radtransfer_3d": (I, [P, ip]),
         "aa_start": (I, [P]), "aa_step": (I, [P, ip]),
         "aa_new_dt_local": (I, [P, dp]), "aa_ion_begin": (I, [P]), "aa_ion_rates": (I, [P, dp, dp]),
         "aa_ion_update": (I, [P, D, llp, dp]),
@@ -258,6 +258,7 @@ class Grid:
     def integrate_3d_ctu(self): self._chk(self.L.aa_integrate_3d_ctu(self._h))
     def integrate_3d_vl(self): self._chk(self.L.aa_integrate_3d_vl(self._h))
     def integrate_begin(self): self._chk(self.L.aa_integrate_begin(self._h))
+    def cfl_in_update(self, on: bool = True): self._chk(self.L.aa_cfl_in_update(self._h, 1 if on else 0))
 
     def integrate(self):
         """(*Integrate)(pD): the function pointer integrate_init() selected (integrate.c:63-75)."""

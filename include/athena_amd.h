@@ -110,6 +110,11 @@ int aa_step(aa_grid *g, int *niter);                /* one pass of main.c:519-66
  * planes ks..ke, integrate_3d_ctu.c:196-620): call it between posting the x3 halo (bvals_mhd.c:423-493) and waiting
  * for it; aa_integrate_3d_ctu then does the rest.  Same bits with or without; a no-op where the split does not apply. */
 int aa_integrate_begin(aa_grid *g);
+/* new_dt.c:72-140 inside the integrator: with on != 0 the caller promises that between aa_integrate_3d_ctu and the
+ * next aa_new_dt_local / aa_cfl_max_v nothing but aa_apply_pinned_cells changes the active zones (the order of main.c:572-629
+ * when Userwork_in_loop only pins zones); the update kernel then leaves max(|v_d| + a) behind while the new state is in
+ * registers and new_dt reads it instead of sweeping the Grid again.  aa_step does this by itself.                     */
+int aa_cfl_in_update(aa_grid *g, int on);
 int aa_new_dt_local(aa_grid *g, double *dt_cfl);                /* new_dt.c:72-170 before Allreduce */
 int aa_ion_begin(aa_grid *g);                                   /* ionrad_3d.c:896-905            */
 int aa_ion_rates(aa_grid *g, double *dt_chem, double *dt_therm);/* :922-938 before Allreduce      */

@@ -128,3 +128,32 @@ def test_integrate_begin_changes_no_bit(problem, ov, strict, x3, monkeypatch):
         g.close()
     assert out[0][1] == out[1][1]
     assert np.array_equal(out[0][0], out[1][0], equal_nan=True)
+
+
+@pytest.mark.parametrize("strict", [True, False])
+@pytest.mark.parametrize("problem,ov,nstep", [(c[0], c[1], 4) for c in CASES])
+def test_new_dt_maxima_from_the_update_kernel(problem, ov, nstep, strict, monkeypatch):
+    """AA_CFL_FUSED: k_flux2_update leaves max(|v_d| + a) of the zones it has just updated behind (pinned zones excepted,
+    which k_pinned_cfl adds after Userwork has overwritten them: ioniz_sphere's core), new_dt reads that instead of sweeping
+    the Grid with k_cfl.  MAX of the same non-negative doubles: the dt sequence and the state are the same, bit for bit, in
+    the strict build; in the default build the two kernels may contract one multiply-add differently (1e-15)."""
+    aa = importlib.import_module("atmospheric-athena_amd")
+    lib = importlib.import_module("atmospheric-athena_amd.lib")
+    monkeypatch.setenv("AA_FUSED_UPDATE", "1")
+    out = []
+    for on in ("0", "1"):
+        monkeypatch.setenv("AA_CFL_FUSED", on)
+        run = aa.config.load(os.path.join(DECKS, "athinput." + problem), ov, problem)
+        g = lib.setup_problem(aa.config.slab(run), 0, strict)
+        g.start()
+        its, dts = [], []
+        for _ in range(nstep):
+            its.append(g.step()); dts.append(g.dt)
+        out.append((g.download(), its, dts))
+        g.close()
+    assert out[0][1] == out[1][1]
+    if strict:
+        assert out[0][2] == out[1][2]
+        assert np.array_equal(out[0][0], out[1][0], equal_nan=True)
+    else:
+        assert np.allclose(out[0][2], out[1][2], rtol=1e-14, atol=0)
