@@ -125,11 +125,12 @@ int aa_create(const aa_params *p, aa_grid **out)
   size_t n = nc*(6 + 36 + 18 + 5 + 1 + 4);       // eta: 3 + the two edge arrays of k_correct_all
   // the one-kernel sub-cycle wants whole wavefronts along the rays; AA_ION_FUSED forces either path
   { const char *e = getenv("AA_ION_BEGIN_FUSED"); g->ion_begin_fused = e ? atoi(e) != 0 : true; }
+  { const char *e = getenv("AA_ION_SPECULATE"); g->ion_spec_on = e ? atoi(e) != 0 : true; }
   { const char *e = getenv("AA_ION_FUSED");
     g->ion_fused = p->ion && (p->ion_path ? p->ion_path == 1 : (e ? atoi(e) != 0 : p->Nx[0] >= 64)); }
   const size_t nrays = (size_t)d.Nx2*d.Nx3;
   if (p->ion) n += nc*6 + nef;
-  if (g->ion_fused) n += nc + 2*nrays;
+  if (g->ion_fused) n += 2*nc + 2*nrays;
   if (p->order != 0 && p->order != 2 && p->order != 3) { delete g; return fail(-1, "[aa_create]: order %d (2: PLM, 3: PPM)", p->order); }
   if (p->order == 3 && p->integrator == 1) { delete g; return fail(-1, "[aa_create]: order 3 is built for the CTU integrator only"); }
   if (p->order == 3) n += nc*18;
@@ -149,7 +150,7 @@ int aa_create(const aa_params *p, aa_grid **out)
     d.sign = (int2*)q; q += nc; d.edgeflux = q; q += nef;
     d.sg16 = (unsigned short*)d.sign;                  // the fused path keeps its 2-byte sign words in the same storage
     d.fin[0] = d.ph_rate; d.fin[1] = d.ph_rate;
-    if (g->ion_fused) { d.fin[1] = q; q += nc; d.raylast = q; q += 2*nrays; }
+    if (g->ion_fused) { d.fin[1] = q; q += nc; d.s_init = q; q += nc; d.raylast = q; q += 2*nrays; }
     IonPar &ip = g->ion;
     ip.sigma_ph = p->sigma_ph; ip.m_H = p->m_H; ip.mu = p->mu; ip.e_gamma = p->e_gamma; ip.alpha_C = p->alpha_C;
     ip.k_B = p->k_B; ip.time_unit = p->time_unit;
@@ -537,6 +538,7 @@ int aa_ion_begin(aa_grid *g)
   if (g->ion_fused) {
     // (a sweep of the previous ion step that nobody asked for is dropped here: its buffers are about to be reused)
     g->ion_cur = 0; g->ion_pending = false; g->ef_stale = false;
+    g->ion_spec_dt = -1.0; g->ion_spec_armed = false;
     if (g->ion_begin_fused) { g->ion_begin_due = true; return 0; }       // rides on the first pass
     Scope s(g, "ion_begin");
     launch_ion_begin16(g->d, g->ion, g->st);
@@ -652,11 +654,28 @@ int aa_ion_pass(aa_grid *g, int update, int sweep, double *dev_words)
   const bool begin = g->ion_begin_due;
   if (begin && update) return fail(-1, "[aa_ion_pass]: the first pass of an ion step cannot apply an update");
   g->ion_begin_due = false;
+  // aa_ion_speculate: the first pass also applies the first sub-cycle's update with the whole step (k_ion_pass)
+  const Real spec_dt = (begin && g->ion_spec_dt >= 0.0) ? g->ion_spec_dt : -1.0;
+  if (!update) g->ion_spec_armed = spec_dt >= 0.0;
+  g->ion_spec_dt = -1.0;
   { Scope s(g, update ? (sweep ? "ion_pass" : "ion_pass_last") : (begin ? "ion_pass_begin" : "ion_pass_first"));
     launch_ion_pass(g->d, g->ion, update != 0, sweep != 0, begin, flux0, g->level > 0 && g->nradplane > 0, g->sc, g->ion_cur,
-                    g->ion_part, dev_words ? dev_words : g->ion_words, g->st); }
+                    g->ion_part, dev_words ? dev_words : g->ion_words, g->st, spec_dt); }
   if (sweep) g->ion_pending = true;
   HIPCHK(hipGetLastError());
+  return 0;
+}
+
+// Before the first pass of an ion step (after aa_ion_begin): `limit` is the step the sub-cycles have to cover (the hydro
+// step, or what is left of the coarse time on a refined level -- the value aa_ion_pick will be given).  The first pass then
+// also applies the first sub-cycle's update with that whole step; where the reduction confirms it -- the stationary regime,
+// ONE sub-cycle per step -- the closing update pass has nothing left to do (k_ion_pass).  Results are the same bit for bit.
+int aa_ion_speculate(aa_grid *g, double limit)
+{
+  if (!g->ion_fused || !g->ion_spec_on) return 0;
+  if (!g->slab.empty()) { for (aa_grid *c : g->slab) { c->ion_spec_dt = c->ion_begin_due ? limit : -1.0; c->ion_spec_limit = limit; } return 0; }
+  g->ion_spec_dt = g->ion_begin_due ? limit : -1.0;      // (only the pass that also does the step's entry can speculate)
+  g->ion_spec_limit = limit;
   return 0;
 }
 
@@ -667,7 +686,11 @@ int aa_ion_pick(aa_grid *g, const double *dev_words_all, int nranks, int first, 
 {
   if (!g->ion_fused) return fail(-1, "[aa_ion_pick]: this Grid runs the two-kernel sub-cycle");
   if (!g->slab.empty()) return slabs_ion_pick(g, first, limit);
-  launch_ion_pick2(dev_words_all ? dev_words_all : g->ion_words, dev_words_all ? nranks : 1, g->sc, first, limit, g->st);
+  if (first && g->ion_spec_armed && limit != g->ion_spec_limit)
+    return fail(-1, "[aa_ion_pick]: limit %.17g, but aa_ion_speculate was told %.17g", limit, g->ion_spec_limit);
+  launch_ion_pick2(dev_words_all ? dev_words_all : g->ion_words, dev_words_all ? nranks : 1, g->sc, first, limit, g->st,
+                   first ? (g->ion_spec_armed ? 1 : 0) : 0);
+  if (!first) g->ion_spec_armed = false;
   HIPCHK(hipGetLastError());
   return 0;
 }
@@ -716,6 +739,7 @@ static int ion_run_fused(aa_grid *g, bool fine, double limit, int *niter_out, do
   long long cellcount = 0;
   int hit, neg, niter = 0, rc;
   if ((rc = aa_ion_begin(g))) return rc;
+  if ((rc = aa_ion_speculate(g, limit))) return rc;                          // (the first pass may already apply update(0) with the whole step)
   if ((rc = aa_ion_pass(g, 0, 1, nullptr))) return rc;                       // sweep(0) + rates(0)
   if ((rc = aa_ion_pick(g, nullptr, 1, 1, limit))) return rc;                // -> dt_0 (stays on the device)
   for (;;) {

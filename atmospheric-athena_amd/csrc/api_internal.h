@@ -26,6 +26,9 @@ struct aa_grid {
   long long *pin_idx = nullptr; aa::Real *pin_val = nullptr; long long npin = 0;
   unsigned char *pin_mask = nullptr;   // 1 where a zone is pinned (k_flux2_update<CFL> leaves those to k_pinned_cfl)
   bool cfl_in_update = false;          // aa_cfl_in_update: the integrator also leaves new_dt's maxima behind
+  bool ion_spec_on = true;             // AA_ION_SPECULATE=0: the first pass of an ion step never applies an update
+  double ion_spec_dt = -1.0, ion_spec_limit = 0.0;   // aa_ion_speculate: armed for the next first pass / what it was told
+  bool ion_spec_armed = false;         //   ... the first pass has speculated: aa_ion_pick(first) settles it
   bool cfl_step = true;                // aa_step does so by itself (AA_CFL_FUSED=0: k_cfl)
   bool cfl_ready = false;              //   ... and has done so for the state as it is now
   bool grav = false;

@@ -35,6 +35,7 @@ struct DevGrid {
   Real *slope;                    // --with-order=3 only: 18*nc, [dir][prim var] monotonised slopes (lr_states_ppm.c dWm)
   // ion
   Real *ph_rate, *kin, *vmax, *e_init, *x_init;   // kin (kinetic energy), vmax: frozen during the ion step
+  Real *s_init;                                   // one-kernel sub-cycle: the scalar after the entry floors (see k_ion_pass, speculation)
   int2 *sign;                     // .x = last_sign, .y = sign_count
   Real *edgeflux;
   // one-kernel sub-cycle (ion_pass.hip): flux entering every zone, double-buffered (the sweep after a
@@ -75,6 +76,10 @@ struct DevScalars {
   Real dt_done;                      // sum of the steps applied so far in this ion step
   Real dt_applied;                   // the step of the update the last pass applied
   int hit_applied, neg_applied;      // ... whether it was cut back to the limit; negative-dt_chem flag of the rates behind it
+  // the first pass of an ion step may already have applied the update with the whole step (k_ion_pass<BEG>, spec_dt):
+  // 1 = k_ion_pick2 found that step to be the one (the closing update pass has nothing left to do), 2 = it was not (the
+  // next pass starts again from e_init / s_init), 0 otherwise
+  int spec_state, pad2;
 };
 
 // what one block of k_ion_pass contributes to the reductions of a sub-cycle (all doubles: the record is
@@ -141,8 +146,8 @@ void launch_ion_begin16(const DevGrid &g, const IonPar &p, hipStream_t st);
 // [entry of the ion step: floors, save_energy_and_x, if `begin`;] update(n-1) with sc->dt_sel, then sweep(n) + rates(n)
 // into buffer cur^1; folds the records into `words`
 void launch_ion_pass(const DevGrid &g, const IonPar &p, bool update, bool sweep, bool begin, Real flux0, bool from_edgeflux,
-                     const DevScalars *sc, int cur, IonPart *part, Real *words, hipStream_t st);
-void launch_ion_pick2(const Real *words, int nranks, DevScalars *sc, int first, Real dt_limit, hipStream_t st);
+                     const DevScalars *sc, int cur, IonPart *part, Real *words, hipStream_t st, Real spec_dt = -1.0);
+void launch_ion_pick2(const Real *words, int nranks, DevScalars *sc, int first, Real dt_limit, hipStream_t st, int spec_armed = 0);
 void launch_ion_finish(const DevGrid &g, int cur, hipStream_t st);
 void launch_test_explog(int n, const Real *x, Real *ye, Real *yl, hipStream_t st);   // n a multiple of 4
 

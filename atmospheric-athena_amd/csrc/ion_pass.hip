@@ -299,11 +299,23 @@ struct Ops { Real d, ke, E, s, fp, e0, x0, vm; unsigned short sg; };
 // energy and max|v| (ionrad_3d.c:896-905; k_ion_begin16's arithmetic, bit for bit) -- on the zones it reads anyway
 template <bool UPD, bool SWP, bool BEG>
 __global__ void __launch_bounds__(256, (UPD && SWP) ? AA_ION_PASS_WAVES : AA_ION_PASS_WAVES_HALF)
-k_ion_pass(DevGrid g, IonPar p_arg, Real flux0, int from_edgeflux, const DevScalars *sc, int cur, IonPart *part, int only_if_hit)
+k_ion_pass(DevGrid g, IonPar p_arg, Real flux0, int from_edgeflux, const DevScalars *sc, int cur, IonPart *part, int only_if_hit, Real spec_dt)
 {
   // an updating pass is launched in both forms -- with and without the sweep of a further sub-cycle -- and the one
   // that does not match what the device picked (sc->limit_hit; the host has not read it yet) leaves at once
   if (UPD && only_if_hit >= 0 && (sc->limit_hit != 0) != (only_if_hit != 0)) return;
+  // Speculation (spec_dt >= 0, the first pass of an ion step only): where the ion step does not cut the hydro step -- the
+  // stationary regime of a long run -- the first sub-cycle's update uses the whole step, which is known before the
+  // reduction that would confirm it.  The first pass therefore applies that update right behind its sweep and rates
+  // (same operands, same expressions as the updating pass would use: the zone is still in registers) and counts its
+  // check_range / dt_hydro operands; k_ion_pick2 then finds out whether the step was the one.  If so (spec_state 1)
+  // the closing update pass finds nothing to do and leaves its predecessor's records in place, which are the ones
+  // k_ion_pick2 books; if not (2), the next pass starts from the state the entry saved (e_init, s_init) and writes
+  // every zone back.  One pass per step instead of two where the radiation is quiet.
+  const bool spec = BEG && spec_dt >= 0.0;
+  const int spec_state = UPD ? sc->spec_state : 0;
+  if (UPD && !SWP && spec_state == 1) return;
+  const bool from_init = UPD && spec_state == 2;
   // ~35 FP64 parameters on top of a dozen field pointers do not fit the 102 scalar registers of a wave (the first
   // build spilled 58 of them, partly to scratch): the parameter block lives in LDS and is re-read per tile through a
   // pointer the compiler cannot see through, i.e. as short-lived vector registers next to their uses
@@ -344,6 +356,7 @@ k_ion_pass(DevGrid g, IonPar p_arg, Real flux0, int from_edgeflux, const DevScal
       if (BEG) { o.fp = Uq(g,1)[m_]; o.e0 = Uq(g,2)[m_]; o.x0 = Uq(g,3)[m_]; }      // the momenta, in the slots UPD would use
       else { o.ke = g.kin[m_]; o.sg = g.sg16[m_]; }
       if (UPD) { o.fp = fprev[m_]; o.e0 = g.e_init[m_]; o.x0 = g.x_init[m_]; o.vm = g.vmax[m_]; }
+      if (from_init) { o.E = o.e0; o.s = g.s_init[m_]; }      // (U holds the update that turned out too long)
     }
   };
 
@@ -381,6 +394,7 @@ k_ion_pass(DevGrid g, IonPar p_arg, Real flux0, int from_edgeflux, const DevScal
     const Real E0 = c.E, s0 = c.s;
     int2 sg = sg_unpack(o.sg);
     bool sg_new = false;
+    Real e_here = 0.0, x_here = 0.0, vm_here = 0.0;          // BEG: what the entry stores as e_init, x_init, vmax
     if (BEG) {
       PAR_HERE(p);
       const Real M1 = o.fp, M2 = o.e0, M3 = o.x0, die = 1.0/c.d;
@@ -389,11 +403,14 @@ k_ion_pass(DevGrid g, IonPar p_arg, Real flux0, int from_edgeflux, const DevScal
       floors(c, p, g.Gamma_1, qb, floored);
       if (floored) qb = ion_q(c, p, g.Gamma_1);
       if (in) {
-        if (c.E != E0) Uq(g,4)[m] = c.E;
-        if (c.s != s0) Uq(g,5)[m] = c.s;
+        if (!spec) {
+          if (c.E != E0) Uq(g,4)[m] = c.E;
+          if (c.s != s0) Uq(g,5)[m] = c.s;
+        } else g.s_init[m] = c.s;
         g.e_init[m] = c.E; g.x_init[m] = qb.x; g.kin[m] = c.ke;
         g.vmax[m] = rmax(rmax(fabs(M1*die), fabs(M2*die)), fabs(M3*die));
       }
+      e_here = c.E; x_here = qb.x; vm_here = rmax(rmax(fabs(M1*die), fabs(M2*die)), fabs(M3*die));
       sg = make_int2(0, 0); sg_new = true;
     }
     const Real di = frcp_n(c.d);
@@ -449,11 +466,31 @@ k_ion_pass(DevGrid g, IonPar p_arg, Real flux0, int from_edgeflux, const DevScal
         fnext[m] = fin;
         if (sg_new || sg.x != sg0.x || sg.y != sg0.y) g.sg16[m] = sg_pack(sg);
       }
+      if (BEG && spec) {        // the update of the first sub-cycle with the whole step, as the UPD branch above would do it next pass
+        const Real e0 = e_here, x0 = x_here, vm = vm_here;    // = e_init, x_init, vmax of this zone (BEG keeps the momenta in o.fp, o.e0, o.x0)
+        zone_update(c, q, th, ph, sg.y, spec_dt, p);
+        q = zone_q(c, di, p, g.Gamma_1);
+        if (zone_floors(c, q, p, g.Gamma_1)) q = zone_q(c, di, p, g.Gamma_1);
+        if (in) {
+          if (out_of_range(c, q, ph, e0, x0, p)) cnt++;
+          const Real pp = rmax(g.Gamma_1*(c.E - c.ke), AA_TINY);
+          const Real a = fsqrt_n(g.Gamma*pp*di);
+          Real t3;
+          if (p.iso) t3 = (vm + a)*p.inv_dx[0];
+          else {
+            const Real v1 = fabs(o.fp*di), v2 = fabs(o.e0*di), v3 = fabs(o.x0*di);
+            t3 = rmax(rmax((v1 + a)*p.inv_dx[0], (v2 + a)*p.inv_dx[1]), (v3 + a)*p.inv_dx[2]);
+          }
+          if (t3 == t3) dti = rmax(dti, t3);
+          if (c.E != E0) Uq(g,4)[m] = c.E;
+          if (c.s != s0) Uq(g,5)[m] = c.s;
+        }
+      }
       if (t == ntile - 1 && lane == 0) g.raylast[(long)(cur ^ 1)*nrays + ray] = dead ? 0.0 : carry;   // :308
     }
     if (UPD && in) {
-      if (c.E != E0) Uq(g,4)[m] = c.E;
-      if (c.s != s0) Uq(g,5)[m] = c.s;
+      if (from_init || c.E != E0) Uq(g,4)[m] = c.E;
+      if (from_init || c.s != s0) Uq(g,5)[m] = c.s;
     }
     if (!PF && nhave) load(nrow, nt, no, nm, nin);
     ray = nray; t = nt; have = nhave; row = nrow; o = no; m = nm; in = nin;
@@ -515,7 +552,7 @@ k_ion_reduce(const IonPart *part, int n, Real *words)
 // Grid's own): dt = MIN(dt_therm, dt_chem) cut back to what is left of the hydro step (root) or of the
 // coarse time (refined level) -- the time covered so far is kept here, on the device -- and, for the host's ONE
 // read-back per sub-cycle, the step and the stop criteria's operands of the update the last pass applied
-__global__ void k_ion_pick2(const Real *words, int nranks, DevScalars *sc, int first, Real dt_limit)
+__global__ void k_ion_pick2(const Real *words, int nranks, DevScalars *sc, int first, Real dt_limit, int spec_armed)
 {
   Real dt_chem = DBL_MAX, dt_therm = DBL_MAX, max_dti = 0.0, count = 0.0, neg = 0.0;
   for (int r = 0; r < nranks; r++) {
@@ -536,6 +573,7 @@ __global__ void k_ion_pick2(const Real *words, int nranks, DevScalars *sc, int f
   int hit = 0;
   if (dt_done + dt > dt_limit) { dt = dt_limit - dt_done; hit = 1; }
   sc->dt_sel = dt; sc->limit_hit = hit;
+  sc->spec_state = (first && spec_armed) ? (hit ? 1 : 2) : 0;      // (see k_ion_pass)
   sc->dt_chem_out = dt_chem; sc->dt_therm_out = dt_therm; sc->neg_out = (neg != 0.0);
 }
 
@@ -613,22 +651,22 @@ void launch_ion_begin16(const DevGrid &g, const IonPar &p, hipStream_t st)
 { const long n = (long)g.Nx1*g.Nx2*g.Nx3; hipLaunchKernelGGL(k_ion_begin16, dim3(nblk(n, 256)), dim3(256), 0, st, g, p); }
 
 void launch_ion_pass(const DevGrid &g, const IonPar &p, bool update, bool sweep, bool begin, Real flux0, bool from_edgeflux,
-                     const DevScalars *sc, int cur, IonPart *part, Real *words, hipStream_t st)
+                     const DevScalars *sc, int cur, IonPart *part, Real *words, hipStream_t st, Real spec_dt)
 {
   const int nb = ion_pass_blocks(g);
   const dim3 grid(nb), blk(256);
   const int fe = from_edgeflux ? 1 : 0;
   if (update && sweep) {
-    hipLaunchKernelGGL((k_ion_pass<true, true, false>), grid, blk, 0, st, g, p, flux0, fe, sc, cur, part, 0);
-    hipLaunchKernelGGL((k_ion_pass<true, false, false>), grid, blk, 0, st, g, p, flux0, fe, sc, cur, part, 1);
+    hipLaunchKernelGGL((k_ion_pass<true, true, false>), grid, blk, 0, st, g, p, flux0, fe, sc, cur, part, 0, -1.0);
+    hipLaunchKernelGGL((k_ion_pass<true, false, false>), grid, blk, 0, st, g, p, flux0, fe, sc, cur, part, 1, -1.0);
   }
-  else if (sweep && begin) hipLaunchKernelGGL((k_ion_pass<false, true, true>), grid, blk, 0, st, g, p, flux0, fe, sc, cur, part, -1);
-  else if (sweep)      hipLaunchKernelGGL((k_ion_pass<false, true, false>), grid, blk, 0, st, g, p, flux0, fe, sc, cur, part, -1);
-  else                 hipLaunchKernelGGL((k_ion_pass<true, false, false>), grid, blk, 0, st, g, p, flux0, fe, sc, cur, part, -1);
+  else if (sweep && begin) hipLaunchKernelGGL((k_ion_pass<false, true, true>), grid, blk, 0, st, g, p, flux0, fe, sc, cur, part, -1, spec_dt);
+  else if (sweep)      hipLaunchKernelGGL((k_ion_pass<false, true, false>), grid, blk, 0, st, g, p, flux0, fe, sc, cur, part, -1, -1.0);
+  else                 hipLaunchKernelGGL((k_ion_pass<true, false, false>), grid, blk, 0, st, g, p, flux0, fe, sc, cur, part, -1, -1.0);
   hipLaunchKernelGGL(k_ion_reduce, dim3(1), dim3(256), 0, st, part, nb, words);
 }
-void launch_ion_pick2(const Real *words, int nranks, DevScalars *sc, int first, Real dt_limit, hipStream_t st)
-{ hipLaunchKernelGGL(k_ion_pick2, dim3(1), dim3(1), 0, st, words, nranks, sc, first, dt_limit); }
+void launch_ion_pick2(const Real *words, int nranks, DevScalars *sc, int first, Real dt_limit, hipStream_t st, int spec_armed)
+{ hipLaunchKernelGGL(k_ion_pick2, dim3(1), dim3(1), 0, st, words, nranks, sc, first, dt_limit, spec_armed); }
 void launch_ion_finish(const DevGrid &g, int cur, hipStream_t st)
 { const long n = (long)g.Nx2*g.Nx3*(g.Nx1 + 1); hipLaunchKernelGGL(k_ion_finish, dim3(nblk(n, 256)), dim3(256), 0, st, g, cur); }
 

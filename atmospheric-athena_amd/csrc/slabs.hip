@@ -443,7 +443,8 @@ int slabs_ion_pick(aa_grid *g, int first, double limit)
     SLAB_DEV(L, s);
     aa_grid *c = g->slab[s];
     HIPCHK(hipMemcpyAsync(L->dwords_all[s], L->hwords, (size_t)L->n*AA_ION_WORDS*sizeof(double), hipMemcpyHostToDevice, c->st));
-    launch_ion_pick2(L->dwords_all[s], L->n, c->sc, first, limit, c->st);
+    launch_ion_pick2(L->dwords_all[s], L->n, c->sc, first, limit, c->st, first ? (c->ion_spec_armed ? 1 : 0) : 0);
+    if (!first) c->ion_spec_armed = false;
   }
   // ... and the host does the same arithmetic (k_ion_pick2; ionrad_3d.c:941-967) for its own control flow: no second wait
   double dt_chem = DBL_MAX, dt_therm = DBL_MAX, max_dti = 0.0, count = 0.0, neg = 0.0;

@@ -67,6 +67,7 @@ class HipEngine:
     def integrate_begin(self): self.g.integrate_begin()
     def userwork(self): self.g.apply_pinned_cells()
     def ion_begin(self): self.g.ion_begin()
+    def ion_speculate(self, limit): self.g.ion_speculate(limit)
     def ion_rates(self): return self.g.ion_rates()
     def ion_update(self, dt): return self.g.ion_update(dt)
     def ion_pass(self, update, sweep): self.g.ion_pass(update, sweep, self.words.data_ptr())
@@ -245,6 +246,8 @@ class Driver:
         dist = self.dist if self.distributed else None
         dt_done, niter = 0.0, 0
         e.ion_begin()
+        if hasattr(e, "ion_speculate"):
+            e.ion_speculate(self.dt)        # the first pass may already apply the first update with the whole step
         e.ion_pass(False, True)
         e.ion_pick(dist, True, self.dt)
         while True:

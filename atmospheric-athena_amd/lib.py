@@ -97,7 +97,7 @@ def load(strict: bool | None = None) -> C.CDLL:
         "aa_start": (I, [P]), "aa_step": (I, [P, ip]),
         "aa_new_dt_local": (I, [P, dp]), "aa_ion_begin": (I, [P]), "aa_ion_rates": (I, [P, dp, dp]),
         "aa_ion_update": (I, [P, D, llp, dp]),
-        "aa_ion_is_fused": (I, [P]), "aa_ion_pass": (I, [P, I, I, P]), "aa_ion_pick": (I, [P, P, I, I, D]),
+        "aa_ion_is_fused": (I, [P]), "aa_ion_speculate": (I, [P, D]), "aa_ion_pass": (I, [P, I, I, P]), "aa_ion_pick": (I, [P, P, I, I, D]),
         "aa_ion_fetch": (I, [P, dp, ip, dp, dp, llp, dp, ip]), "aa_ion_finish": (I, [P]), "aa_host_syncs": (I, [P, I]),
         "aa_halo_doubles": (LL, [P]), "aa_pack_x3": (I, [P, I, P]), "aa_unpack_x3": (I, [P, I, P]),
         "aa_mesh_create": (I, [I, C.POINTER(P), ip, C.POINTER(P)]), "aa_mesh_destroy": (None, [P]),
@@ -258,6 +258,7 @@ class Grid:
     def integrate_3d_ctu(self): self._chk(self.L.aa_integrate_3d_ctu(self._h))
     def integrate_3d_vl(self): self._chk(self.L.aa_integrate_3d_vl(self._h))
     def integrate_begin(self): self._chk(self.L.aa_integrate_begin(self._h))
+    def ion_speculate(self, limit: float): self._chk(self.L.aa_ion_speculate(self._h, float(limit)))
     def cfl_in_update(self, on: bool = True): self._chk(self.L.aa_cfl_in_update(self._h, 1 if on else 0))
 
     def integrate(self):

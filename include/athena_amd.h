@@ -119,6 +119,12 @@ int aa_new_dt_local(aa_grid *g, double *dt_cfl);                /* new_dt.c:72-1
 int aa_ion_begin(aa_grid *g);                                   /* ionrad_3d.c:896-905            */
 int aa_ion_rates(aa_grid *g, double *dt_chem, double *dt_therm);/* :922-938 before Allreduce      */
 int aa_ion_update(aa_grid *g, double dt, long long *cellcount, double *dt_hydro); /* :965-1002    */
+/* Before the first aa_ion_pass of an ion step (after aa_ion_begin): `limit` = the value aa_ion_pick will be given.  The
+ * first pass then also applies the first sub-cycle's update with that whole step (the zone is in registers); where the
+ * reduction confirms the step -- a quiet radiation field, ONE sub-cycle per hydro step -- the closing update pass has nothing
+ * left to do; otherwise the next pass restarts from the state the entry saved.  Same results bit for bit; optional
+ * (AA_ION_SPECULATE=0 in the environment turns it off). */
+int aa_ion_speculate(aa_grid *g, double limit);
 /* The same loop for Grids that run the ONE-KERNEL sub-cycle (aa_ion_is_fused: rays of 64 zones or more; the two
  * calls above refuse such a Grid).  The loop is cut at its only true barrier, the reduction that yields the step:
  * pass n applies update(n-1) and runs sweep(n) + rates(n) on the updated zones; its reduction words (MIN dt_chem,

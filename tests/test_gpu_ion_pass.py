@@ -126,3 +126,37 @@ def test_ray_cut_off_at_the_threshold(lib, fused, strict):
     assert nlit > 20 and nlit < nx[1] * nx[2] - 20          # both sides of the threshold are populated
     assert ncut_near <= nx[1] * nx[2] // 8
     g.close()
+
+
+@pytest.mark.parametrize("strict", [True, False])
+@pytest.mark.parametrize("problem,ov,nstep", [
+    ("ioniz_sphere", ["domain1/Nx1=64", "domain1/Nx2=16", "domain1/Nx3=16"], 12),     # 80, 13, 12, 11, 10 sub-cycles, then 1 per step
+    ("ifront", ["domain1/Nx1=64", "domain1/Nx2=8", "domain1/Nx3=8", "problem/flux=1e3"], 5),
+    ("ifront", ["domain1/Nx1=128", "domain1/Nx2=6", "domain1/Nx3=5"], 4)])
+def test_speculative_first_update_changes_no_bit(problem, ov, nstep, strict, monkeypatch):
+    """aa_ion_speculate: the first pass of an ion step also applies the first sub-cycle's update with the whole hydro step;
+    k_ion_pick2 then finds out whether that was the step (one sub-cycle per hydro step: the closing update pass is skipped) or
+    not (the next pass restarts from e_init / s_init).  Against AA_ION_SPECULATE=0: the same sub-cycle counts, dt, state and
+    EdgeFlux, bit for bit, in both builds -- the update is the same code on the same operands -- over steps of both kinds."""
+    import importlib
+    import os
+    aa = importlib.import_module("atmospheric-athena_amd")
+    lib = importlib.import_module("atmospheric-athena_amd.lib")
+    decks = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "atmospheric-athena_amd", "decks")
+    out = []
+    for on in ("0", "1"):
+        monkeypatch.setenv("AA_ION_SPECULATE", on)
+        run = aa.config.load(os.path.join(decks, "athinput." + problem), ov, problem)
+        g = lib.setup_problem(aa.config.slab(run), 0, strict)
+        assert g.ion_is_fused()
+        g.start()
+        its, dts = [], []
+        for _ in range(nstep):
+            its.append(g.step()); dts.append(g.dt)
+        out.append((its, dts, g.download(), g.download_edgeflux()))
+        g.close()
+    a, b = out
+    assert a[0] == b[0] and a[1] == b[1]
+    assert np.array_equal(a[2], b[2], equal_nan=True) and np.array_equal(a[3], b[3], equal_nan=True)
+    if problem == "ioniz_sphere":
+        assert 1 in a[0] and max(a[0]) > 1          # both kinds of step were exercised
