@@ -106,7 +106,7 @@ int aa_create(const aa_params *p, aa_grid **out)
   // blast step, -4.2 ms ifront, -4.4 / -2.0 ms third order without / with gravity.  The one combination it does not pay
   // for is second order + passive scalar + gravity (ioniz_sphere: the kernel is bound by its own instruction stream
   // there, 249 VGPRs at 2 waves per SIMD, and the step gets 0.6-0.9 ms slower): left to the sweep kernel.  Same bits.
-  { const char *e = getenv("AA_CFL_FUSED"); g->cfl_step = e ? atoi(e) != 0 : true; }     // aa_step: new_dt's maxima from the update kernel
+  { const char *e = getenv("AA_CFL_FUSED"); g->cfl_step = e ? atoi(e) != 0 : true; g->cfl_force = e && atoi(e) == 2; }     // aa_step: new_dt's maxima from the update kernel
   { const char *e = getenv("AA_X3_FUSED"); g->x3_fused_mode = e ? (atoi(e) != 0) : -1; }    // (the potential arrives after aa_create)
   // rates inside the ray sweep: one block per 64 rays, so it needs many rays to fill the chip (512^2 rays:
   // -2.9 ms per step; 80^2 rays: +6 %); same results either way
@@ -439,6 +439,12 @@ static void cfl_arm(aa_grid *g)
 int aa_cfl_in_update(aa_grid *g, int on)
 {
   if (!g->slab.empty()) return 0;      // (composite Grids keep k_cfl)
+#if !defined(AA_FAST_DIV) || !AA_FAST_DIV
+  // the strict build keeps k_cfl: with -ffp-contract=off its 6-variable update kernel spills 15 registers with the CFL
+  // epilogue (17.0 against 14.9 ms at 512^3) -- more than the sweep it would save (AA_CFL_FUSED=2 forces it: the tests'
+  // bit-for-bit comparison of the two ways)
+  if (!g->cfl_force) on = 0;
+#endif
   g->cfl_in_update = on != 0; g->cfl_ready = false;
   return 0;
 }
@@ -827,7 +833,11 @@ int aa_step(aa_grid *g, int *niter_out)
   }
   // (between the integrator and new_dt this loop only pins zones: the integrator may leave new_dt's maxima behind)
   const bool keep_opt = g->cfl_in_update;
+#if defined(AA_FAST_DIV) && AA_FAST_DIV
   if (g->slab.empty() && g->cfl_step) g->cfl_in_update = true;
+#else
+  if (g->slab.empty() && g->cfl_step && g->cfl_force) g->cfl_in_update = true;
+#endif
   rc = (g->p.integrator == 1 ? aa_integrate_3d_vl(g) : aa_integrate_3d_ctu(g));                    // :572-585
   g->cfl_in_update = keep_opt;
   if (rc) return rc;

@@ -29,6 +29,7 @@ struct aa_grid {
   bool ion_spec_on = true;             // AA_ION_SPECULATE=0: the first pass of an ion step never applies an update
   double ion_spec_dt = -1.0, ion_spec_limit = 0.0;   // aa_ion_speculate: armed for the next first pass / what it was told
   bool ion_spec_armed = false;         //   ... the first pass has speculated: aa_ion_pick(first) settles it
+  bool cfl_force = false;              // AA_CFL_FUSED=2: also in the strict build
   bool cfl_step = true;                // aa_step does so by itself (AA_CFL_FUSED=0: k_cfl)
   bool cfl_ready = false;              //   ... and has done so for the state as it is now
   bool grav = false;
