@@ -537,17 +537,8 @@ AA_DEV void cell_states(const DevGrid &g, long m, Real dt, const Real q[3], cons
 #ifndef CA_PARK
 #define CA_PARK 1
 #endif
-#ifndef CA_X3FIRST
-#define CA_X3FIRST 1
-#endif
 #ifndef CA_LB2SEL
 #define CA_LB2SEL 1
-#endif
-#ifndef CA_FEARLY
-#define CA_FEARLY 0
-#endif
-#ifndef CA_SB
-#define CA_SB 1
 #endif
 template <int NS, bool GRAV, int ORD, bool X3F>
 __global__ void __launch_bounds__(64*CA_TJ, (CA_LB2SEL == 2 || (CA_LB2SEL == 1 && X3F && NS && GRAV)) ? 2 : 1)
@@ -625,16 +616,6 @@ k_correct_all(DevGrid g, Real dt, int kchunk)
 #pragma unroll
     for (int v = 0; v < 6; v++) { cf.dF[0][v] = 0.0; cf.dF[1][v] = 0.0; cf.dF[2][v] = 0.0; }
     Real mlo[3], mhi[3];
-#if CA_FEARLY
-    if (X3F && zone) {      // requested before the first-pass work of this iteration, consumed after it
-#pragma unroll
-      for (int v = 0; v < NV; v++) {
-        const Real a0 = Ff(g, 0, v)[m], a1 = Ff(g, 0, v)[m + 1], b0 = Ff(g, 1, v)[m], b1 = Ff(g, 1, v)[m + g.sJ];
-        cf.dF[0][v] = a1 - a0; cf.dF[1][v] = b1 - b0;
-        if (v == 0) { mlo[0] = a0; mhi[0] = a1; mlo[1] = b0; mhi[1] = b1; }
-      }
-    }
-#endif
     if (X3F) {
 #pragma unroll
       for (int n = 0; n < 6; n++) { wc[n] = wn[n]; wn[n] = wn2[n]; }
@@ -659,9 +640,7 @@ k_correct_all(DevGrid g, Real dt, int kchunk)
 #pragma unroll
       for (int n = 0; n < NV; n++) { s_park[n][row][lane] = wlN[n]; s_park[6 + n][row][lane] = wrN[n]; }
 #endif
-#if CA_SB
       __builtin_amdgcn_sched_barrier(0);
-#endif
     } else {
 #pragma unroll
       for (int n = 0; n < 6; n++) { wm3[n] = wc[n]; wc[n] = wn[n]; }
@@ -684,19 +663,13 @@ k_correct_all(DevGrid g, Real dt, int kchunk)
       }
     }
     if (zone) {
-    if (X3F && CA_FEARLY) {
 #pragma unroll
-      for (int v = 0; v < NV; v++) cf.dF[2][v] = f3n[v] - f3[v];
-      mlo[2] = f3[0]; mhi[2] = f3n[0];
-    } else {
-#pragma unroll
-      for (int v = 0; v < NV; v++) {
-        const Real a0 = Ff(g, 0, v)[m], a1 = Ff(g, 0, v)[m + 1], b0 = Ff(g, 1, v)[m], b1 = Ff(g, 1, v)[m + g.sJ];
-        const Real c0 = f3[v], c1 = X3F ? f3n[v] : Ff(g, 2, v)[m + g.sK];
-        cf.dF[0][v] = a1 - a0; cf.dF[1][v] = b1 - b0; cf.dF[2][v] = c1 - c0;
-        if (v == 0) { mlo[0] = a0; mhi[0] = a1; mlo[1] = b0; mhi[1] = b1; mlo[2] = c0; mhi[2] = c1; }
-        if (!X3F) f3[v] = c1;
-      }
+    for (int v = 0; v < NV; v++) {
+      const Real a0 = Ff(g, 0, v)[m], a1 = Ff(g, 0, v)[m + 1], b0 = Ff(g, 1, v)[m], b1 = Ff(g, 1, v)[m + g.sJ];
+      const Real c0 = f3[v], c1 = X3F ? f3n[v] : Ff(g, 2, v)[m + g.sK];
+      cf.dF[0][v] = a1 - a0; cf.dF[1][v] = b1 - b0; cf.dF[2][v] = c1 - c0;
+      if (v == 0) { mlo[0] = a0; mhi[0] = a1; mlo[1] = b0; mhi[1] = b1; mlo[2] = c0; mhi[2] = c1; }
+      if (!X3F) f3[v] = c1;
     }
     if (GRAV) {
       const Real dc = wc[0], phic = Pf(g, 0)[m];
@@ -709,7 +682,7 @@ k_correct_all(DevGrid g, Real dt, int kchunk)
         cf.kl[e] = dtodx*(phir - phic); cf.kr[e] = dtodx*(phic - phil);
       }
     }
-    if (CA_X3FIRST && do3) {   // ---- x3 first: what only this block needs (the plane below / the states zone k kept) is dead under x1 / x2 ----
+    if (do3) {   // ---- x3 first: what only this block needs (the plane below / the states zone k kept) is dead under x1 / x2 ----
       Real ll, lr;
       if (X3F) cell_finish<NS, 2, GRAV>(g, m, q, cf, wl3, wr3, full, ll, lr);
       else {
@@ -788,19 +761,6 @@ k_correct_all(DevGrid g, Real dt, int kchunk)
         }
       }
       __builtin_amdgcn_sched_barrier(0);
-    }
-    if (!CA_X3FIRST && do3) {   // ---- x3: the register window; lam3 = lambda_l the zone below gave to this zone's lower face ----
-      Real ll, lr;
-      if (X3F) cell_finish<NS, 2, GRAV>(g, m, q, cf, wl3, wr3, full, ll, lr);
-      else {
-        Real wm[6], ws[6], wp[6];
-        to_sweep<2>(wm3, wm3[4], wm); to_sweep<2>(wc, wc[4], ws); to_sweep<2>(wn, wn[4], wp);
-        cell_states<NS, 2, GRAV, ORD>(g, m, dt, q, cf, wm, ws, wp, full, ll, lr);
-      }
-      if (full && k > g.ks - 1) Ef(g, 2)[m] = 0.5*fabs(lr - lam3);
-      lam3 = ll;
-      if (GRAV && full)   // d^{n+1/2}, :2104-2125
-        g.dhalf[m] = wc[0] - q[0]*cf.dF[0][0] - q[1]*cf.dF[1][0] - q[2]*cf.dF[2][0];
     }
     }
     if (X3F) {
