@@ -388,6 +388,7 @@ class HipMeshEngine:
     def integrate(self, l): self.lev[l].integrate()
     def userwork(self, l): self.lev[l].apply_pinned_cells()
     def ion_begin(self, l): self.lev[l].ion_begin()
+    def ion_speculate(self, l, limit): self.lev[l].ion_speculate(limit)
     def ion_rates(self, l): return self.lev[l].ion_rates()
     def ion_update(self, l, dt): return self.lev[l].ion_update(dt)
     def ion_is_fused(self, l): return self.lev[l].ion_is_fused()
@@ -603,6 +604,8 @@ class MeshDriver:
         if has:
             e.set_level_state(l, self.time, self.dtl[l], self.nstep)
             e.ion_begin(l)
+            if hasattr(e, "ion_speculate"):
+                e.ion_speculate(l, limit)      # (see Driver._ion_radtransfer_fused)
         mir = {"dt_sel": 0.0, "hit": False, "neg": False, "dt_done": 0.0}
 
         def one_pass(update, first):
