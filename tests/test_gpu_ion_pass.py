@@ -160,3 +160,21 @@ def test_speculative_first_update_changes_no_bit(problem, ov, nstep, strict, mon
     assert np.array_equal(a[2], b[2], equal_nan=True) and np.array_equal(a[3], b[3], equal_nan=True)
     if problem == "ioniz_sphere":
         assert 1 in a[0] and max(a[0]) > 1          # both kinds of step were exercised
+
+
+def test_speculation_needs_the_limit_it_was_given(monkeypatch):
+    """aa_ion_speculate(limit) followed by aa_ion_pick(first, another limit) is a caller's bug: refused, not guessed at."""
+    import importlib
+    import os
+    aa = importlib.import_module("atmospheric-athena_amd")
+    lib = importlib.import_module("atmospheric-athena_amd.lib")
+    decks = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "atmospheric-athena_amd", "decks")
+    run = aa.config.load(os.path.join(decks, "athinput.ifront"), ["domain1/Nx1=64", "domain1/Nx2=8", "domain1/Nx3=8"], "ifront")
+    g = lib.setup_problem(aa.config.slab(run), 0, True)
+    g.start()
+    g.ion_begin()
+    g.ion_speculate(g.dt)
+    g.ion_pass(False, True, 0)
+    with pytest.raises(Exception):
+        g.ion_pick(0, 1, True, 0.5 * g.dt)
+    g.close()
