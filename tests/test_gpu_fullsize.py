@@ -142,3 +142,29 @@ def test_smr_256_conservation_across_levels(strict):
         assert np.allclose(A[..., 0], A[::-1, :, :, 0], rtol=tol, atol=0)
         assert np.allclose(A[..., 0], A[:, ::-1, :, 0], rtol=tol, atol=0)
         assert np.allclose(A[..., 1], -A[:, :, ::-1, 1], rtol=1e-9, atol=1e-12)
+
+
+@pytest.mark.parametrize("problem,nx,nslab", [("blast", (512, 512, 256), 2), ("ioniz_sphere", (256, 256, 256), 3)])
+def test_slabs_inside_the_library_at_size(problem, nx, nslab):
+    """The composite Grid (aa_params.nslab: the drop-in executable's AA_NGPU) at a size where every big-Grid kernel is the
+    default -- k_correct_all (with the x3 first pass for blast), k_flux2_update, the one-kernel sub-cycle with its
+    speculated first update -- and the slabs' ghost planes travel on the copy streams under the first x1 / x2 sweeps: the
+    N-slab run must agree with the one-Grid run (default build: multiply-adds of a marching kernel's first iteration
+    contract differently, and the chunks start where the slabs do; strict equality is tested at small sizes)."""
+    aa = importlib.import_module("atmospheric-athena_amd")
+    lib = importlib.import_module("atmospheric-athena_amd.lib")
+    out = []
+    for ns in (1, nslab):
+        run = aa.config.load(os.path.join(DECKS, "athinput." + problem), [f"domain1/Nx{d + 1}={nx[d]}" for d in range(3)], problem)
+        g = lib.setup_problem(aa.config.slab(run), 0, False, nslab=ns)
+        g.start()
+        its = [g.step() for _ in range(2)]
+        out.append((its, g.dt, g.download()[4:-4, 4:-4, 4:-4]))
+        g.close()
+    (ia, da, A), (ib, db, B) = out
+    assert ia == ib
+    tol = 1e-8 if problem == "ioniz_sphere" else 1e-12
+    assert abs(da / db - 1) < tol
+    scale = np.nanmax(np.abs(A), axis=(0, 1, 2)); scale[scale == 0] = 1
+    assert np.array_equal(np.isnan(A), np.isnan(B))
+    assert (np.nanmax(np.abs(A - B), axis=(0, 1, 2)) / scale).max() < tol
