@@ -217,6 +217,7 @@ long long aa_device_bytes(const aa_grid *g) { return g->slab.empty() ? g->bytes 
 int aa_upload_cons(aa_grid *g, const double *U)
 {
   g->cfl_ready = false;
+  g->inner_swept = false;          // the state changes under a pending aa_integrate_begin: its sweeps are redone
   if (!g->slab.empty()) return slabs_upload_cons(g, U);
   const int nvar = 5 + g->p.nscal; const size_t n = (size_t)g->d.N1*g->d.N2*g->d.N3*nvar;
   HIPCHK(hipMemcpyAsync(g->d.LR, U, n*sizeof(Real), hipMemcpyHostToDevice, g->st));
@@ -227,6 +228,7 @@ int aa_upload_cons(aa_grid *g, const double *U)
 int aa_download_cons(aa_grid *g, double *U)
 {
   if (!g->slab.empty()) return slabs_download_cons(g, U);
+  g->inner_swept = false;          // the face-state area is the staging buffer (see aa_integrate_begin in athena_amd.h)
   const int nvar = 5 + g->p.nscal; const size_t n = (size_t)g->d.N1*g->d.N2*g->d.N3*nvar;
   launch_soa_to_aos(g->d, nvar, g->d.LR, g->st);
   HIPCHK(hipMemcpyAsync(U, g->d.LR, n*sizeof(Real), hipMemcpyDeviceToHost, g->st));
@@ -238,6 +240,7 @@ int aa_download_cons_planes(aa_grid *g, int k_first, int nplanes, double *dst)
 {
   if (!g->slab.empty()) return fail(-1, "[aa_download_cons_planes]: one slab at a time");
   if (k_first < 0 || nplanes < 0 || k_first + nplanes > g->d.N3) return fail(-1, "[aa_download_cons_planes]: planes %d..%d", k_first, k_first + nplanes);
+  g->inner_swept = false;
   const int nvar = 5 + g->p.nscal; const size_t pl = (size_t)g->d.N1*g->d.N2*nvar;
   launch_soa_to_aos(g->d, nvar, g->d.LR, g->st);
   HIPCHK(hipMemcpyAsync(dst, g->d.LR + (size_t)k_first*pl, (size_t)nplanes*pl*sizeof(Real), hipMemcpyDeviceToHost, g->st));
@@ -246,7 +249,9 @@ int aa_download_cons_planes(aa_grid *g, int k_first, int nplanes, double *dst)
 }
 int aa_download_edgeflux_planes(aa_grid *g, int nplanes, double *dst)
 {
+  if (!g->slab.empty()) return fail(-1, "[aa_download_edgeflux_planes]: one slab at a time");
   if (!g->p.ion) return fail(-1, "[aa_download_edgeflux]: ion radiation is off");
+  if (nplanes < 0 || nplanes > g->d.Nx3 + 1) return fail(-1, "[aa_download_edgeflux_planes]: %d planes of %d", nplanes, g->d.Nx3 + 1);
   { int rc = aa_edgeflux_ready(g); if (rc) return rc; }
   const size_t n = (size_t)(g->d.Nx1 + 1)*(g->d.Nx2 + 1)*(size_t)nplanes;
   HIPCHK(hipMemcpyAsync(dst, g->d.edgeflux, n*sizeof(Real), hipMemcpyDeviceToHost, g->st));
@@ -384,6 +389,7 @@ int aa_bvals_ionrad(aa_grid *g)
 
 int aa_fetch_scalars(aa_grid *g)
 {
+  if (!g->slab.empty()) return fail(-1, "[aa_fetch_scalars]: not available on a Grid cut into slabs");
   HIPCHK(hipMemcpyAsync(g->sc_host, g->sc, sizeof(DevScalars), hipMemcpyDeviceToHost, g->st));
   HIPCHK(hipStreamSynchronize(g->st));
   g->host_syncs++;
@@ -602,6 +608,7 @@ int aa_ion_update(aa_grid *g, double dt, long long *cellcount, double *dt_hydro)
 // time (refined level).  The first call of an ion step must find the reductions armed (aa_ion_arm).
 int aa_ion_arm(aa_grid *g)
 {
+  if (!g->slab.empty()) return fail(-1, "[aa_ion_arm]: not available on a Grid cut into slabs (aa_ion_run / aa_ion_rates + aa_ion_update)");
   DevScalars init; memset(&init, 0, sizeof init);
   init.dt_chem = double_to_bits(DBL_MAX); init.dt_therm = double_to_bits(DBL_MAX);
   *g->sc_host = init;
@@ -612,6 +619,7 @@ int aa_ion_subcycle(aa_grid *g, double dt_done, double limit, double *dt, int *l
                     double *dt_therm, long long *cellcount, double *dt_hydro)
 {
   g->cfl_ready = false;
+  if (!g->slab.empty()) return fail(-1, "[aa_ion_subcycle]: not available on a Grid cut into slabs (aa_ion_run / aa_ion_rates + aa_ion_update)");
   if (g->ion_fused) return fail(-1, "[aa_ion_subcycle]: this Grid runs the one-kernel sub-cycle");
   if (g->nradplane > 0) {
     const Real flux0 = g->flux_i*(5.*(erf((g->time - 1.2e5)/8e4)+1)+0.1);     // ionradplane_3d.c:265
@@ -851,7 +859,8 @@ int aa_step(aa_grid *g, int *niter_out)
 
 // ---- x3 halo ------------------------------------------------------------------------------
 #define NO_SLABS(name) if (!g->slab.empty()) return fail(-1, "[" name "]: not available on a Grid cut into slabs")
-long long aa_halo_doubles(const aa_grid *g) { return (long long)g->d.N1*g->d.N2*AA_NGHOST*(5 + g->p.nscal); }
+long long aa_halo_doubles(const aa_grid *g)      // (a Grid cut into slabs exchanges its halos itself: 0)
+{ return g->slab.empty() ? (long long)g->d.N1*g->d.N2*AA_NGHOST*(5 + g->p.nscal) : 0LL; }
 int aa_pack_x3(aa_grid *g, int side, double *buf)
 {
   NO_SLABS("aa_pack_x3");
@@ -925,6 +934,7 @@ int aa_test_explog(int n, const double *x, double *ye, double *yl)
 int aa_history(aa_grid *g, double *sums)
 {
   if (!g->slab.empty()) return slabs_history(g, sums);
+  g->inner_swept = false;
   // partial rows go through the face-state area, idle outside the integrator
   const int nb = launch_history(g->d, g->p.nscal, g->d.LR, g->st);
   std::vector<double> part((size_t)nb*9);

@@ -285,6 +285,7 @@ static aa_mesh *mesh_alloc(int nlevels, aa_grid **levels)
   for (int l = 0; l < nlevels; l++) {
     aa_grid *g = levels[l];
     if (!g || g->level != l) { delete m; aa_fail(-1, "[aa_mesh_create]: levels[%d] was not created with level=%d", l, l); return nullptr; }
+    if (!g->slab.empty()) { delete m; aa_fail(-1, "[aa_mesh_create]: levels[%d] is cut into slabs (aa_params.nslab / AA_NGPU): nested levels stay on one device", l); return nullptr; }
     if (g->p.device != levels[0]->p.device) { delete m; aa_fail(-1, "[aa_mesh_create]: all levels must live on one device"); return nullptr; }
     m->lev[l] = g; m->box[l] = nullptr;
     g->keep_flux = true;
@@ -491,6 +492,7 @@ int aa_mesh_ionflux_prolong(aa_mesh *m, int l)
 // multi-GPU SMR: the child's restricted boundary flux (DEVICE buffer of (Nx1/2)(Nx2/2)*6 doubles) ...
 int aa_flux_x3_export(aa_grid *child, int side, double *dev_buf)
 {
+  if (!child->slab.empty()) return aa_fail(-1, "[aa_flux_x3_export]: not available on a Grid cut into slabs");
   const long n = (long)(child->p.Nx[0]/2)*(child->p.Nx[1]/2);
   hipLaunchKernelGGL(k_flux_x3_export, dim3(nblk(n, 256)), dim3(256), 0, child->st, child->d, side, dev_buf);
   HIPCHK(hipGetLastError());
@@ -499,6 +501,7 @@ int aa_flux_x3_export(aa_grid *child, int side, double *dev_buf)
 // ... and its application to the plane of the parent slab across the cut (Grid dt as in RestrictCorrect)
 int aa_flux_x3_apply(aa_grid *parent, int side, int i0, int j0, int n1, int n2, const double *dev_buf)
 {
+  if (!parent->slab.empty()) return aa_fail(-1, "[aa_flux_x3_apply]: not available on a Grid cut into slabs");
   if (i0 < AA_NGHOST || j0 < AA_NGHOST || i0 + n1 > AA_NGHOST + parent->p.Nx[0] || j0 + n2 > AA_NGHOST + parent->p.Nx[1])
     return aa_fail(-1, "[aa_flux_x3_apply]: region outside the Grid");
   hipLaunchKernelGGL(k_flux_x3_apply, dim3(nblk((long)n1*n2, 256)), dim3(256), 0, parent->st, parent->d, side, i0, j0, n1, n2,

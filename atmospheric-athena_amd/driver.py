@@ -34,21 +34,24 @@ MAXCELLCOUNT = 20   # ionrad.h:38
 class HipEngine:
     """One slab on one MI355X, through include/athena_amd.h."""
 
-    def __init__(self, grid: GridConfig, device: int = 0, strict: Optional[bool] = None, use_torch_stream: bool = True):
+    def __init__(self, grid: GridConfig, device: int = 0, strict: Optional[bool] = None, use_torch_stream: bool = True,
+                 nslab: int = 1):
         import torch
         from . import lib
         self.torch = torch
         self.cfg = grid
         torch.cuda.set_device(device)
-        self.g = lib.setup_problem(grid, device, strict)
-        if use_torch_stream:
+        # nslab > 1: the library cuts this Grid into x3 slabs itself (csrc/slabs.hip; one stream per slab, so the
+        # caller's stream is not handed over)
+        self.g = lib.setup_problem(grid, device, strict, nslab=nslab)
+        if use_torch_stream and nslab == 1:
             # run the kernels on torch's current stream so that torch.distributed collectives and
             # torch.cuda.Event timing are ordered with them
             self.g.set_stream(torch.cuda.current_stream().cuda_stream)
         # Driver.step calls integrate -> userwork (pinned zones only) -> new_dt in that order: the update kernel may
         # leave new_dt's maxima behind (aa_cfl_in_update; AA_CFL_FUSED=0 keeps the separate sweep over the Grid)
         self.g.cfl_in_update(os.environ.get("AA_CFL_FUSED", "1") != "0")
-        n = self.g.halo_doubles()
+        n = self.g.halo_doubles() if nslab == 1 else 0        # (slabs inside the library exchange their halos themselves)
         dev = torch.device("cuda", device)
         # the one-kernel radiation sub-cycle leaves this slab's reduction words in device memory; with several
         # ranks they are all-gathered on the stream (ONE collective per sub-cycle, no host round trip)

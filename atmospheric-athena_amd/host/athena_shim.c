@@ -8,24 +8,30 @@
  * Prolongate and ionradRestrictCorrect (smr.c) on top of aa_mesh_*.
  *
  * Host/device coherence (the reference's problem files and outputs index pG->U on the host):
- *   AA_COHERENCE=auto  (default) the first two steps run as `step` below while the zones Userwork_in_loop writes are
- *                      recorded; if both steps wrote the same values into the same zones (prob/ioniz_sphere.c:255-306
- *                      does; a problem without Userwork trivially does) they are re-imposed on the device from then on
- *                      (aa_apply_pinned_cells) and the host block is refreshed only when main() is about to read it:
- *                      when an <outputN> block is due at the next data_output (its schedule, output.c:205-208 and
- *                      :507-522, is mirrored from the same par table), when the loop is about to end (tlim / nlim:
- *                      the forced final output, main.c:743) and after SIGTERM (ath_signal.c).  Otherwise `step`.
- *                      Not seen: outputs enrolled by the problem file itself at run time, and reads of pG->U by
- *                      problem-file code other than Userwork_in_loop's writes -- use `step` for those.
- *   AA_COHERENCE=step  the host block is refreshed after Integrate() (so that
+ *   AA_COHERENCE=step  (default) the host block is refreshed after Integrate() (so that
  *                      Userwork_in_loop sees and may edit it; re-uploaded before new_dt) and
  *                      after the end-of-step bvals_mhd (so data_output sees ghost zones too).
- *                      Always correct; costs three PCIe transfers of U per step.
- *   AA_COHERENCE=learn first step as above, and the cells Userwork_in_loop changed are recorded;
+ *                      Always correct, whatever the problem file does; costs three PCIe transfers of U per step.
+ *   AA_COHERENCE=auto  (opt-in: a CONTRACT with the problem file) the first two steps run as `step` while the zones
+ *                      Userwork_in_loop writes are recorded; if both steps wrote the same values into the same zones
+ *                      (prob/ioniz_sphere.c:255-306 does; a problem without Userwork trivially does) they are re-imposed
+ *                      on the device from then on (aa_apply_pinned_cells) and the host block is refreshed only when
+ *                      main() is about to read it: when an <outputN> block is due at the next data_output (its schedule,
+ *                      output.c:205-208 and :507-522, is mirrored from the same par table), when the loop is about to end
+ *                      (tlim / nlim: the forced final output, main.c:743) and after SIGTERM (ath_signal.c).  The imprint
+ *                      is RE-VALIDATED every AA_REVALIDATE_EVERY steps (default 8) and on the step after every such
+ *                      refresh: that step runs as `step`, and the host block after Userwork_in_loop must equal the
+ *                      downloaded state with the recorded values imposed, zone for zone; if not (a Userwork that becomes
+ *                      active later, e.g. `if (time > t0)`, or whose values drift) the shim says so on stderr and stays
+ *                      `step` for the rest of the run -- the writes of the steps since the last validation were NOT
+ *                      seen by the device, which is why this mode is not the default.
+ *                      Not seen at all: outputs enrolled by the problem file itself at run time, and reads of pG->U by
+ *                      problem-file code other than Userwork_in_loop's writes -- use `step` for those.
+ *   AA_COHERENCE=learn first step as `step`, and the cells Userwork_in_loop changed are recorded;
  *                      from then on they are re-imposed on the device (aa_apply_pinned_cells)
  *                      and the host block is refreshed only at the end-of-step bvals_mhd every
- *                      AA_SYNC_EVERY steps (default 1).  Valid when Userwork writes the same
- *                      values every step, as prob/ioniz_sphere.c:255-306 does.
+ *                      AA_SYNC_EVERY steps (default 1).  Unverified (round 1's form): valid only when Userwork writes
+ *                      the same values every step.
  */
 #include <math.h>
 #include <signal.h>
@@ -57,6 +63,9 @@ static int host_newer[MAXLEV];      /* the host block of this level holds data t
 static int learn = 0, learned = 0, sync_every = 1;
 /* AA_COHERENCE=auto: the write set of Userwork_in_loop must repeat before it is trusted; the output schedule */
 static int automode = 0, gave_up = 0;
+/* auto, after the imprint is trusted: the copy of it that re-validation compares against, and when to look again */
+static long long pin_n[MAXLEV]; static long long *pin_idx[MAXLEV]; static double *pin_val[MAXLEV];
+static int reval_every = 8, steps_since_reval = 0, verify_now = 0, verify_next = 0;
 static long long nw_prev[MAXLEV]; static long long *iw_prev[MAXLEV]; static double *vw_prev[MAXLEV];
 #define MAXOUT_MIRROR 64
 static int nout = 0; static double out_t[MAXOUT_MIRROR], out_dt[MAXOUT_MIRROR];
@@ -113,8 +122,9 @@ static void ensure_grid(MeshS *pM)
   if (sizeof(ConsS) != (5 + AA_NSCALARS)*sizeof(double)) ath_error("[athena_amd]: ConsS layout\n");
   M = pM;
   env = getenv("AA_COHERENCE");
-  automode = (!env || strcmp(env, "auto") == 0);
+  automode = (env && strcmp(env, "auto") == 0);          /* default: step (always correct) */
   learn = automode || (env && strcmp(env, "learn") == 0);
+  { const char *r = getenv("AA_REVALIDATE_EVERY"); reval_every = r ? atoi(r) : 8; if (reval_every < 1) reval_every = 1; }
   if (env && strcmp(env, "step") != 0 && strcmp(env, "learn") != 0 && strcmp(env, "auto") != 0)
     ath_error("[athena_amd]: AA_COHERENCE=%s (auto, step or learn)\n", env);
   if (automode) {            /* the <outputN> schedule main()'s data_output will follow (output.c:183-208) */
@@ -216,7 +226,11 @@ static void to_host(int l)
 /* after the integrator (and, with SMR, RestrictCorrect): Userwork_in_loop reads and may write pG->U */
 static void refresh_for_userwork(int l)
 {
-  if (learn && learned) { CHK(aa_apply_pinned_cells(G[l])); return; }
+  if (learn && learned && automode && l == 0) {        /* is this a step on which the imprint is looked at again? */
+    verify_now = verify_next || (++steps_since_reval >= reval_every);
+    verify_next = 0;
+  }
+  if (learn && learned && !(automode && verify_now)) { CHK(aa_apply_pinned_cells(G[l])); return; }
   to_host(l);
   host_newer[l] = 1;
   if (learn) {
@@ -302,7 +316,7 @@ static void refresh_for_output(void)
   if (!(learn && learned)) due = 1;
   else if (automode) due = host_read_due();
   else due = (++steps_since_sync >= sync_every);
-  if (due) { for (l = 0; l < NL; l++) to_host(l); steps_since_sync = 0; }
+  if (due) { for (l = 0; l < NL; l++) to_host(l); steps_since_sync = 0; if (automode && learned) verify_next = 1; }
 }
 
 void bvals_mhd(DomainS *pD)
@@ -334,6 +348,32 @@ void new_dt(MeshS *pM)
 {
   int nl, nd, l; double t, dt; int n;
   ensure_grid(pM);
+  if (learn && learned && automode && verify_now && snap[0]) {
+    /* re-validation: the host block after Userwork_in_loop must be the downloaded state with the recorded values
+     * imposed -- nothing more (a Userwork that woke up), nothing less, nothing else (values that drift) */
+    const int nv = 5 + AA_NSCALARS;
+    int ok = 1;
+    for (l = 0; l < NL && ok; l++) {
+      long long c; int v;
+      for (c = 0; c < pin_n[l]; c++) for (v = 0; v < nv; v++) snap[l][pin_idx[l][c]*nv + v] = pin_val[l][c*nv + v];
+      if (memcmp(host_block(l), snap[l], ncell[l]*nv*sizeof(double)) != 0) ok = 0;
+    }
+    for (l = 0; l < NL; l++) { free(snap[l]); snap[l] = NULL; }
+    verify_now = 0; steps_since_reval = 0;
+    if (ok) {
+      for (l = 0; l < NL; l++) CHK(aa_apply_pinned_cells(G[l]));      /* this step's Userwork, on the device */
+    } else {
+      /* the host blocks hold what Userwork_in_loop really did on this step's state: they travel back (host_newer is set),
+       * and from here on every step does */
+      learn = 0; learned = 0; gave_up = 1;
+#ifndef AA_SMR
+      CHK(aa_cfl_in_update(G[0], 0));
+#endif
+      fprintf(stderr, "[athena_amd] WARNING: Userwork_in_loop no longer writes the imprint recorded at the start of the run "
+                      "(step %d): coherence falls back to `step` for the rest of the run; its writes since the last "
+                      "validation (at most %d steps) did not reach the device\n", pM->nstep, reval_every);
+    }
+  }
   if (learn && !learned && !gave_up && snap[0]) {           /* what did Userwork_in_loop change? */
     const int nv = 5 + AA_NSCALARS;
     int same = 1;
@@ -365,7 +405,8 @@ void new_dt(MeshS *pM)
         CHK(aa_set_pinned_cells(G[l], cnt_l[l], idx_l[l], val_l[l]));
         CHK(aa_apply_pinned_cells(G[l]));          /* this step's Userwork, on the device */
         fprintf(stderr, "[athena_amd] Userwork_in_loop pins %lld cells on level %d; re-imposed on the device from now on\n", cnt_l[l], l);
-        free(idx_l[l]); free(val_l[l]);
+        if (automode) { pin_n[l] = cnt_l[l]; pin_idx[l] = idx_l[l]; pin_val[l] = val_l[l]; }     /* kept for re-validation */
+        else { free(idx_l[l]); free(val_l[l]); }
         if (iw_prev[l]) { free(iw_prev[l]); free(vw_prev[l]); iw_prev[l] = NULL; vw_prev[l] = NULL; }
       }
       learned = 1;

@@ -169,15 +169,12 @@ def cpu_baseline(nx=128, nlim=12):
                 out = {"value": zc, "unit": "cell-updates/s", "cores": p2 * p3, "kind": "reference-mpi",
                        "sample": f"ioniz_sphere {nx}^3, {nlim} steps, NGrid 1x{p2}x{p3} (mpiexec -n {p2 * p3}), sub-cycles/step {its}, {wall:.1f} s wall"}
                 nsub = sum(its) / max(1, len(its))
-                ns_step = 1e9 / zc
                 out["nsub_mean"] = nsub
                 if os.path.exists(os.path.join(ref, "athena_sphere_hydro_mpi")):
                     zh, _, wh = _run_ref(os.path.join(ref, "athena_sphere_hydro_mpi"), deck, tmp, "hyd", nx, nlim, p2 * p3)
                     out["per_hydro_step_ns_per_zone"] = 1e9 / zh
-                    # a difference of two runs: below 3 % of a step it is run-to-run noise, not a measurement (on the CPU the
-                    # radiation step of this deck is cheap: the rays end in the first optically thick zones)
-                    diff = ns_step - 1e9 / zh
-                    out["per_subcycle_ns_per_zone"] = diff / max(nsub, 1e-30) if diff > 0.03 * ns_step else None
+                    # (no per-sub-cycle figure: it would be the difference of two 3-s runs, < 1 % of a CPU step on this deck --
+                    #  the rays end in the first optically thick zones -- i.e. below the run-to-run spread)
                     out["sample"] += f"; same deck without ion radiation {zh:.3e} zone-cycles/s ({wh:.1f} s wall)"
                 return out
             except Exception as e:      # e.g. hydra cannot start on this host: fall back to one core
@@ -301,7 +298,15 @@ def bench_smr(a, aa, torch, rank, world, local):
 
 
 def spin_up(drv, mode, log):
-    """Untimed steps that carry the deck from its initial state into the stationary regime (module docstring)."""
+    """Untimed steps that carry the deck from its initial state into the regime to be timed (module docstring):
+    'auto' the stationary one, 'burst' the first burst of sub-cycles after the doubling phase, N exactly N steps."""
+    if mode == "burst":
+        while len(log) < 96:
+            n = drv.step()
+            log.append(n)
+            if len(log) >= 4 and n >= 8:          # (the doubling phase takes 4 per step; 512^3: 30-81 from step 19 on)
+                break
+        return
     if mode != "auto":
         for _ in range(int(mode)):
             log.append(drv.step())
@@ -315,6 +320,242 @@ def spin_up(drv, mode, log):
         quiet = quiet + 1 if steady else 0
 
 
+def self_launch(a, argv):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it: the program starts its own ranks, as the
+    reference's binary does under MPI_Init (main.c:139-140, :210-211).  The ranks are CHILD processes of this one, which
+    has not touched the GPU (`import torch` alone does not); their one JSON line is relayed and their exit code kept."""
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + argv
+    pr = subprocess.run(cmd, stdout=subprocess.PIPE, text=True, env=env)
+    lines = [ln for ln in pr.stdout.splitlines() if ln.strip().startswith("{")]
+    if lines:
+        print(lines[-1])
+    elif pr.stdout:
+        sys.stderr.write(pr.stdout[-4000:])
+    sys.exit(pr.returncode if pr.returncode or lines else 1)
+
+
+class Ctx:
+    """What every measurement window of one invocation shares."""
+    def __init__(self, a, aa, driver, torch, dist, rank, world, local, multi):
+        self.a, self.aa, self.driver, self.torch, self.dist = a, aa, driver, torch, dist
+        self.rank, self.world, self.local, self.multi = rank, world, local, multi
+
+    def barrier(self):
+        if self.multi:
+            self.dist.barrier()
+        self.torch.cuda.synchronize()
+
+
+def run_window(c, strong, spinup, steps, warmup, nslab=1):
+    """One Driver from the deck's initial state: spin-up, warm-up, then EXACTLY `steps` timed steps between barrier +
+    synchronize pairs, MAX over ranks.  Returns the raw measurements (rank 0 builds the JSON from them)."""
+    a, aa, torch = c.a, c.aa, c.torch
+    nx, world = a.nx, c.world
+    nx3 = nx if strong else nx * world
+    deck = os.path.join(ROOT, PKG, "decks", "athinput." + a.problem)
+    par = aa.athinput.ParTable.from_file(deck)
+    x3min, x3max = par.getd("domain1", "x3min"), par.getd("domain1", "x3max")
+    ov = [f"domain1/Nx1={nx}", f"domain1/Nx2={nx}", f"domain1/Nx3={nx3}"]
+    if not strong:      # weak scaling: the box grows along x3 with the same dx
+        ov.append(f"domain1/x3max={x3min + (x3max - x3min) * world!r}")
+    par.cmdline(ov)
+    run = aa.config.from_par(par, a.problem)
+    run.integrator = a.integrator
+    run.order = a.order
+    t_setup = time.time()
+    if nslab > 1:      # ONE process, the library cuts the Grid (csrc/slabs.hip): the path of the drop-in executables
+        fac = lambda grid: c.driver.HipEngine(grid, c.local, True if a.strict else None, nslab=nslab)
+        drv = c.driver.Driver(run, fac, 0, 1, c.local)
+    else:
+        drv = c.driver.Driver(run, None, c.rank, world, c.local, strict=True if a.strict else None)
+    if a.ionized_slab:
+        if not run.ion:
+            sys.exit("--ionized-slab needs a problem with ion radiation")
+        U = drv.eng.g.host_initial
+        U[..., 5] = 1.0e-4 * U[..., 0]
+        drv.eng.g.upload(U)
+    drv.start()
+    eng = drv.eng
+    torch.cuda.synchronize()
+    t_setup = time.time() - t_setup
+    spin_log = []
+    t_spin = time.time()
+    spin_up(drv, spinup if run.ion else "0", spin_log)
+    torch.cuda.synchronize()
+    t_spin = time.time() - t_spin
+    for _ in range(warmup):
+        drv.step()
+    hist0 = drv.history()
+    eng.g.profile_reset()
+    if not a.no_kernel_times:
+        eng.g.profile_enable(True)
+    drv.niter_trace.clear()
+    drv.host_sync_count(reset=True)
+    c.barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        drv.step()
+    c.barrier()
+    t1 = time.perf_counter()
+    prof = eng.g.profile() if not a.no_kernel_times else {}
+    eng.g.profile_enable(False)
+    nsync = drv.host_sync_count()
+    elapsed = t1 - t0
+    if c.multi:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        c.dist.all_reduce(t, op=c.dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    hist1 = drv.history()      # volume integrals (dump_history.c): a NaN or Inf anywhere in the state shows up here
+    w = {"run": run, "nx": nx, "nx3": nx3, "strong": strong, "elapsed": elapsed, "steps": steps, "warmup": warmup, "prof": prof,
+         "nsync": nsync, "hist0": hist0, "hist1": hist1, "spin_log": spin_log, "t_spin": t_spin, "t_setup": t_setup,
+         "niter": list(drv.niter_trace), "dt": drv.dt, "time": drv.time, "hbm": eng.g.device_bytes(), "spinup": spinup,
+         "zones": nx * nx * nx3, "zones_gpu": (nx * nx * nx3) // (world * nslab) if (strong or nslab > 1) else nx ** 3, "nslab": nslab}
+    eng.close()
+    return w
+
+
+def chain_traffic(a, w, world, names):
+    """HBM bytes per launch of the named kernels from the committed rocprofv3 PMC passes of this same command
+    (profiles/r03_traffic.json / r03_burst_traffic.json); only valid for the workload they were taken on."""
+    try:
+        tf = {"auto": "r03_traffic.json", "burst": "r03_burst_traffic.json", "19": "r03_burst_traffic.json"}.get(w["spinup"])
+        tj = json.load(open(os.path.join(ROOT, "profiles", tf)))
+        if tj.get("workload", "").startswith(f"{a.problem} {w['nx']}x{w['nx']}x{w['nx3']}") and a.integrator == "ctu" and a.order == 2 \
+                and world == 1 and w["nslab"] == 1 and not a.ionized_slab and not a.strict:
+            return {k: tj["kernels"].get(k) for k in names}
+    except Exception:
+        pass
+    return {}
+
+
+def analyse(c, w):
+    """The JSON object of one window (rank 0)."""
+    a, world = c.a, c.world
+    run, nx, nx3, steps, elapsed, prof = w["run"], w["nx"], w["nx3"], w["steps"], w["elapsed"], w["prof"]
+    zones, zones_gpu = w["zones"], w["zones_gpu"]
+    niter = w["niter"]
+    nsub_tot = sum(niter)
+    nsub = nsub_tot / max(1, len(niter))
+    value = zones * steps / elapsed
+    nvar = 5 + run.nscal
+    hist0, hist1 = w["hist0"], w["hist1"]
+    regime = {"auto": " (stationary regime: dt at the CFL limit, sub-cycle count constant)",
+              "burst": " (burst regime: the first burst of sub-cycles after the dt-doubling phase)"}.get(w["spinup"], "")
+    out = {
+        "metric": "cell-updates/sec (hydro+ion-rad step)", "value": value, "unit": "cell-updates/s",
+        "n_gpus": world, "steps": steps, "warmup": w["warmup"], "ms_per_step": 1e3 * elapsed / steps,
+        "higher_is_better": True, "scaling": "strong" if w["strong"] else "weak", "vs_baseline": None, "dtype": "f64",
+        "data": "synthetic (deck values on a uniform grid, generated in place"
+                + ("; neutral fraction reset to 1e-4 everywhere: fully ionized slab" if a.ionized_slab else "") + ")",
+        "config": {"workload": f"{a.problem} {nx}x{nx}x{nx3} single level, "
+                               + ((f"CTU+{'PPM' if a.order == 3 else 'PLM'}+Roe+H-correction") if a.integrator == "ctu" else "VL+PLM+Roe")
+                               + (" + static gravity + plane-parallel ion radiation" if a.problem == "ioniz_sphere"
+                                  else (" + plane-parallel ion radiation" if a.problem == "ifront" else ""))
+                               + (f"; timed after {len(w['spin_log'])} spin-up steps" + regime if run.ion else ""),
+                   "build": "libathena_amd_strict.so (-ffp-contract=off)" if a.strict else "libathena_amd.so",
+                   "zones_per_gpu": zones_gpu,
+                   "partition": (f"x3 slabs x{w['nslab']} inside the library (one process, aa_params.nslab)" if w["nslab"] > 1 else
+                                 f"x3 slabs x{world}" + (" of one box (strong scaling)" if w["strong"] else "")),
+                   "nvar": nvar, "spinup_steps": len(w["spin_log"]), "spinup_subcycle_trace": w["spin_log"], "spinup_s": w["t_spin"],
+                   "radiation_subcycles_per_step": nsub, "subcycle_trace": niter,
+                   "final_dt": w["dt"], "final_time": w["time"], "hbm_resident_GB": w["hbm"] / 1e9, "setup_s": w["t_setup"]},
+    }
+    # the state that was timed: finite everywhere, mass and energy of the box before / after (outflow
+    # boundaries: not conserved to round-off), no sub-cycle loop at its iteration limit
+    fin = all(math.isfinite(float(x)) for x in hist1)
+    out["state_check"] = {"finite": fin, "mass_before": float(hist0[0]), "mass_after": float(hist1[0]),
+                          "mass_rel_change": float(hist1[0] / hist0[0] - 1.0) if hist0[0] else None,
+                          "energy_rel_change": float(hist1[1] / hist0[1] - 1.0) if hist0[1] else None,
+                          "max_subcycles": max(niter) if niter else 0, "maxiter": run.maxiter,
+                          "ok": bool(fin and (not run.ion or max(niter) < run.maxiter))}
+    out["host_syncs_per_step"] = w["nsync"] / steps
+    # new_dt costs one read-back per step (two with several ranks: the slab's own and the all-reduce's)
+    out["host_syncs_per_subcycle"] = (w["nsync"] / steps - (2.0 if c.multi else 1.0)) / max(nsub, 1e-30) if run.ion else None
+    if prof:
+        ms_step = {k: v[0] / steps for k, v in prof.items()}
+        cls = {"hydro": 0.0, "subcycle": 0.0, "ion_step": 0.0, "other": 0.0}
+        for k, v in ms_step.items():
+            cls[kernel_class(k)] += v
+        b_h = 2 * 8 * nvar
+        hydro_names = sorted((k for k in ms_step if kernel_class(k) == "hydro"), key=lambda k: -ms_step[k])
+        sub_names = sorted((k for k in ms_step if kernel_class(k) == "subcycle"), key=lambda k: -ms_step[k])
+        # 1. the contract's `roofline`: SURVEY 8(d)'s unit of work and its ALGORITHMIC bytes, divided by the time of the kernels
+        #    that perform the unit (hipEvent pairs on the launch stream inside the timed region).  The unit that takes most of
+        #    the step is reported: the hydro cell-update (2*NVAR*8 B, done by the integrator's kernel chain) or the radiation
+        #    sub-cycle (64 B per cell, one k_ion_pass).  The dominant KERNEL and the bytes its own schedule must move are kept
+        #    beside it (`kernel_own_bytes_frac`: round 2's `frac`).
+        dom = dominant_kernel(prof)
+        unit_hydro = cls["hydro"] >= cls["subcycle"]
+        if unit_hydro and cls["hydro"] > 0:
+            ms_unit, b_unit, names = cls["hydro"], b_h, hydro_names
+            unit = f"hydro cell-update: 2*NVAR*8 = {b_h} B (SURVEY 8d), performed by " + " + ".join(names)
+        elif cls["subcycle"] > 0:
+            ms_unit, b_unit, names = cls["subcycle"] * steps / max(nsub_tot, 1), 64, sub_names
+            unit = "radiation sub-cycle: 64 B per cell (SURVEY 8d), performed by " + " + ".join(names)
+        else:
+            ms_unit = 0.0
+        if ms_unit > 0:
+            ach = b_unit * zones_gpu / (ms_unit * 1e-3) / 1e9
+            tr = chain_traffic(a, w, world, names)
+            per_unit = steps if unit_hydro else max(nsub_tot, 1)
+            traffic = (sum(tr[k] * prof[k][1] for k in names) / per_unit) if tr and all(tr.get(k) is not None for k in names) else None
+            rf = {"bound": "hbm", "kernel": names[0] if len(names) == 1 else "chain(" + "+".join(names) + ")", "achieved": ach,
+                  "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
+                  "bytes_per_launch": b_unit * zones_gpu, "bytes_basis": unit, "avg_launch_ms": ms_unit}
+            if dom:
+                ms, n = prof[dom]
+                scale = (nvar / 6.0) if kernel_class(dom) == "hydro" else 1.0
+                kb = KERNEL_BYTES[dom]
+                if dom == "correct_all" and "sweep_x3" not in prof:
+                    kb = CORRECT_ALL_X3_BYTES       # the x3 first pass rides along: its fluxes are neither written nor read
+                own = kb * zones_gpu * scale / (ms / n * 1e-3) / 1e9
+                rf["dominant_kernel"] = dom
+                rf["dominant_kernel_avg_launch_ms"] = ms / n
+                rf["kernel_own_bytes_per_zone"] = kb * scale
+                rf["kernel_own_bytes_frac"] = own / HBM_PEAK_GBS
+                rf["dominant_kernel_traffic"] = chain_traffic(a, w, world, [dom]).get(dom)
+            out["roofline"] = rf
+        # 2. the phases of the step on SURVEY 8(d)'s algorithmic bytes: hydro chain 2*NVAR*8 B per
+        #    cell-update, radiation 64 B per cell and sub-cycle
+        ph = {}
+        if cls["hydro"] > 0:
+            a_h = b_h * zones_gpu / (cls["hydro"] * 1e-3) / 1e9
+            tf = HYDRO_FLOP_PER_CELL * zones_gpu / (cls["hydro"] * 1e-3) / 1e12
+            ph["hydro"] = {"ms_per_step": cls["hydro"], "bytes_per_cell": b_h, "achieved_GBs": a_h, "frac_hbm": a_h / HBM_PEAK_GBS,
+                           "ns_per_zone": 1e6 * cls["hydro"] / zones_gpu,
+                           "fp64_TFLOPs_est": tf, "frac_fp64_peak_est": tf / FP64_PEAK_TFLOPS}
+        if nsub_tot > 0 and cls["subcycle"] > 0:
+            ms_sub = cls["subcycle"] * steps / nsub_tot
+            a_s = 64 * zones_gpu / (ms_sub * 1e-3) / 1e9
+            ph["subcycle"] = {"ms_per_subcycle": ms_sub, "bytes_per_cell": 64, "achieved_GBs": a_s, "frac_hbm": a_s / HBM_PEAK_GBS,
+                              "ns_per_zone": 1e6 * ms_sub / zones_gpu, "subcycles_timed": nsub_tot,
+                              "note": "all kernels of the ion step's loop / sub-cycles timed; with ONE sub-cycle per step that is the first pass "
+                                      "(which also does the step's entry: floors, save_energy_and_x) plus the closing update-only pass"}
+            if prof.get("ion_pass", (0, 0))[1] > 0 and nsub > 1.5:
+                # the repeating unit of a long loop: one full pass = update(n-1) + sweep(n) + rates(n)
+                ms_full = prof["ion_pass"][0] / prof["ion_pass"][1]
+                a_f = 64 * zones_gpu / (ms_full * 1e-3) / 1e9
+                ph["subcycle"]["full_pass_ms"] = ms_full
+                ph["subcycle"]["full_pass_frac_hbm"] = a_f / HBM_PEAK_GBS
+        ph["ion_step_overhead_ms"] = cls["ion_step"]
+        ph["other_ms"] = cls["other"]
+        ph["unattributed_ms"] = 1e3 * elapsed / steps - sum(cls.values())
+        out["phases"] = ph
+        out["kernel_ms_per_step"] = dict(sorted(ms_step.items(), key=lambda kv: -kv[1]))
+        out["kernel_launches_per_step"] = {k: v[1] / steps for k, v in prof.items()}
+    # 3. the whole step, the survey's definition: (2*NVAR*8 + 64*<N_sub>) B per cell-update (BASELINE.md 3)
+    bstep = (2 * 8 * nvar) + (64 * nsub if run.ion else 0)
+    out["step_roofline"] = {"bytes_per_cell_update": bstep, "achieved": value / world * bstep / 1e9,
+                            "peak": HBM_PEAK_GBS, "unit": "GB/s per GPU",
+                            "frac": value / world * bstep / 1e9 / HBM_PEAK_GBS}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -326,8 +567,17 @@ def main():
     ap.add_argument("--order", type=int, default=2, choices=[2, 3], help="reconstruction: 2 PLM (default), 3 PPM (--with-order=3)")
     ap.add_argument("--spinup", default="auto",
                     help="untimed steps before the warm-up: 'auto' (until dt has stopped doubling and the sub-cycle count is "
-                         "stationary, at most 200) or a number (0: the start-up transient; 19 at 512^3: the burst of sub-cycles)")
-    ap.add_argument("--strong", action="store_true", help="N>1: cut ONE nx^3 box into N x3 slabs (default: weak scaling, nx^3 per GPU)")
+                         "stationary, at most 320), 'burst' (until the first burst of sub-cycles after the dt-doubling phase) "
+                         "or a number (0: the start-up transient; 19 at 512^3: the burst of sub-cycles)")
+    ap.add_argument("--scaling", default=None, choices=["weak", "strong", "both"],
+                    help="N>1: weak (nx^3 per GPU, the box grows along x3), strong (ONE nx^3 box cut into N x3 slabs: BASELINE "
+                         "configs[3]) or both (default for N>1: the weak line with the strong window under `strong_scaling`)")
+    ap.add_argument("--strong", action="store_true", help="same as --scaling strong")
+    ap.add_argument("--inlib", type=int, default=0, metavar="N",
+                    help="ONE process, the library cuts the Grid into N x3 slabs itself (aa_params.nslab; AA_SLAB_DEVICES picks the "
+                         "devices): the multi-GPU path of the drop-in executables, strong scaling, no launcher involved")
+    ap.add_argument("--no-burst", action="store_true", help="N=1: skip the second (burst-regime) window")
+    ap.add_argument("--burst-window", action="store_true", help="N=1: time the second (burst-regime) window also with a numeric --spinup")
     ap.add_argument("--strict", action="store_true", help="time libathena_amd_strict.so (-ffp-contract=off: the bit-exact hydro build)")
     ap.add_argument("--smr", action="store_true",
                     help="BASELINE.json configs[4]: 2-level static mesh refinement, per GPU a root slab of nx^3 zones plus "
@@ -343,15 +593,18 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-times", action="store_true")
     a = ap.parse_args()
+    if a.strong:
+        a.scaling = "strong"
+
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ and not a.inlib:
+        self_launch(a, sys.argv[1:])        # does not return
 
     import torch
     aa = importlib.import_module(PKG)
     driver = importlib.import_module(PKG + ".driver")
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
     local = 0 if REHEARSAL else int(os.environ.get("LOCAL_RANK", "0"))
-    if world != a.gpus:
-        if world == 1 and a.gpus > 1:
-            sys.exit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N bench.py --gpus N")
+    if world != a.gpus and not a.inlib:
         a.gpus = world
     if not torch.cuda.is_available():
         sys.exit("bench.py needs an MI355X: the hot path has no CPU fallback")
@@ -360,181 +613,60 @@ def main():
         return bench_smr(a, aa, torch, rank, world, local)
     force = bool(os.environ.get("AA_FORCE_DISTRIBUTED"))
     multi = world > 1 or force
+    dist = None
     if multi:
         import torch.distributed as dist
         init_pg(dist, torch, rank, world, local)
+    c = Ctx(a, aa, driver, torch, dist, rank, world, local, multi)
 
-    nx = a.nx
-    nx3 = nx if a.strong else nx * world
-    deck = os.path.join(ROOT, PKG, "decks", "athinput." + a.problem)
-    par = aa.athinput.ParTable.from_file(deck)
-    x3min, x3max = par.getd("domain1", "x3min"), par.getd("domain1", "x3max")
-    ov = [f"domain1/Nx1={nx}", f"domain1/Nx2={nx}", f"domain1/Nx3={nx3}"]
-    if not a.strong:      # weak scaling: the box grows along x3 with the same dx
-        ov.append(f"domain1/x3max={x3min + (x3max - x3min) * world!r}")
-    par.cmdline(ov)
-    run = aa.config.from_par(par, a.problem)
-    run.integrator = a.integrator
-    run.order = a.order
-    t_setup = time.time()
-    drv = driver.Driver(run, None, rank, world, local, strict=True if a.strict else None)
-    if a.ionized_slab:
-        if not run.ion:
-            sys.exit("--ionized-slab needs a problem with ion radiation")
-        U = drv.eng.g.host_initial
-        U[..., 5] = 1.0e-4 * U[..., 0]
-        drv.eng.g.upload(U)
-    drv.start()
-    eng = drv.eng
-    torch.cuda.synchronize()
-    t_setup = time.time() - t_setup
+    if a.inlib:
+        # one process, N slabs behind the C entry points (strong scaling of ONE nx^3 box; the slabs sit on the devices of
+        # AA_SLAB_DEVICES, all on the current one by default = a rehearsal)
+        w = run_window(c, True, a.spinup, a.steps, a.warmup, nslab=a.inlib)
+        out = analyse(c, w)
+        out["n_gpus"] = a.inlib
+        out["config"]["slab_devices"] = os.environ.get("AA_SLAB_DEVICES", "all slabs on the current device (rehearsal, not a measurement)")
+        print(json.dumps(out))
+        return
 
-    def barrier():
-        if multi:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    spin_log = []
-    t_spin = time.time()
-    spin_up(drv, a.spinup if run.ion else "0", spin_log)
-    torch.cuda.synchronize()
-    t_spin = time.time() - t_spin
-    for _ in range(a.warmup):
-        drv.step()
-    hist0 = drv.history()
-    eng.g.profile_reset()
-    if not a.no_kernel_times:
-        eng.g.profile_enable(True)
-    drv.niter_trace.clear()
-    drv.host_sync_count(reset=True)
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        drv.step()
-    barrier()
-    t1 = time.perf_counter()
-    prof = eng.g.profile() if not a.no_kernel_times else {}
-    eng.g.profile_enable(False)
-    nsync = drv.host_sync_count()
-    elapsed = t1 - t0
-    if multi:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    hist1 = drv.history()      # volume integrals (dump_history.c): a NaN or Inf anywhere in the state shows up here
-
+    mode = a.scaling or ("both" if world > 1 else "weak")
+    first_strong = (mode == "strong")
+    w = run_window(c, first_strong, a.spinup, a.steps, a.warmup)
+    out = analyse(c, w) if rank == 0 else None
+    if mode == "both" and world > 1:
+        # BASELINE's metric is also quoted on ONE 512^3 box over N GPUs (configs[3]): the same job times that window too
+        ws = run_window(c, True, a.spinup, a.steps, a.warmup)
+        if rank == 0:
+            s = analyse(c, ws)
+            out["strong_scaling"] = {k: s[k] for k in ("value", "ms_per_step", "steps", "warmup", "state_check", "host_syncs_per_subcycle",
+                                                       "step_roofline") if k in s}
+            out["strong_scaling"].update(zones_per_gpu=s["config"]["zones_per_gpu"], workload=s["config"]["workload"],
+                                         radiation_subcycles_per_step=s["config"]["radiation_subcycles_per_step"],
+                                         kernel_ms_per_step=s.get("kernel_ms_per_step"))
+    if world == 1 and not multi and w["run"].ion and (a.spinup == "auto" or a.burst_window) and not a.no_burst:
+        # second window: the regime in which the radiation sub-cycle dominates the step (dozens of sub-cycles), so that the
+        # sub-cycle kernel's roofline fraction is a driver-timed number as well
+        wb = run_window(c, False, "burst", min(6, a.steps), 0)
+        if rank == 0:
+            b = analyse(c, wb)
+            sub = b.get("phases", {}).get("subcycle", {})
+            out["regimes"] = {"stationary": {"nsub": out["config"]["radiation_subcycles_per_step"], "ms_per_step": out["ms_per_step"]},
+                              "burst": {"nsub": b["config"]["radiation_subcycles_per_step"], "ms_per_step": b["ms_per_step"],
+                                        "value": b["value"], "steps": b["steps"], "spinup_steps": b["config"]["spinup_steps"],
+                                        "subcycle_trace": b["config"]["subcycle_trace"],
+                                        "ms_per_subcycle": sub.get("ms_per_subcycle"), "full_pass_ms": sub.get("full_pass_ms"),
+                                        "full_pass_frac_hbm": sub.get("full_pass_frac_hbm"),
+                                        "hydro_ms_per_step": b.get("phases", {}).get("hydro", {}).get("ms_per_step"),
+                                        "step_roofline_frac": b["step_roofline"]["frac"], "state_ok": b["state_check"]["ok"],
+                                        "roofline": b.get("roofline")}}
     if rank == 0:
-        zones_gpu = run.rootNx[0] * run.rootNx[1] * run.rootNx[2] // world if a.strong else nx ** 3
-        zones = nx * nx * nx3
-        nsub_tot = sum(drv.niter_trace)
-        nsub = nsub_tot / max(1, len(drv.niter_trace))
-        value = zones * a.steps / elapsed
-        nvar = 5 + run.nscal
-        out = {
-            "metric": "cell-updates/sec (hydro+ion-rad step)", "value": value, "unit": "cell-updates/s",
-            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * elapsed / a.steps,
-            "higher_is_better": True, "scaling": "strong" if a.strong else "weak", "vs_baseline": None, "dtype": "f64",
-            "data": "synthetic (deck values on a uniform grid, generated in place"
-                    + ("; neutral fraction reset to 1e-4 everywhere: fully ionized slab" if a.ionized_slab else "") + ")",
-            "config": {"workload": f"{a.problem} {nx}x{nx}x{nx3} single level, "
-                                   + ((f"CTU+{'PPM' if a.order == 3 else 'PLM'}+Roe+H-correction") if a.integrator == "ctu" else "VL+PLM+Roe")
-                                   + (" + static gravity + plane-parallel ion radiation" if a.problem == "ioniz_sphere"
-                                      else (" + plane-parallel ion radiation" if a.problem == "ifront" else ""))
-                                   + (f"; timed after {len(spin_log)} spin-up steps"
-                                      + (" (stationary regime: dt at the CFL limit, sub-cycle count constant)" if a.spinup == "auto" else "")
-                                      if run.ion else ""),
-                       "build": "libathena_amd_strict.so (-ffp-contract=off)" if a.strict else "libathena_amd.so",
-                       "zones_per_gpu": zones_gpu, "partition": f"x3 slabs x{world}" + (" of one box (strong scaling)" if a.strong else ""),
-                       "nvar": nvar, "spinup_steps": len(spin_log), "spinup_subcycle_trace": spin_log, "spinup_s": t_spin,
-                       "radiation_subcycles_per_step": nsub, "subcycle_trace": drv.niter_trace,
-                       "final_dt": drv.dt, "final_time": drv.time, "hbm_resident_GB": eng.g.device_bytes() / 1e9, "setup_s": t_setup},
-        }
-        # the state that was timed: finite everywhere, mass and energy of the box before / after (outflow
-        # boundaries: not conserved to round-off), no sub-cycle loop at its iteration limit
-        fin = all(math.isfinite(float(x)) for x in hist1)
-        out["state_check"] = {"finite": fin, "mass_before": float(hist0[0]), "mass_after": float(hist1[0]),
-                              "mass_rel_change": float(hist1[0] / hist0[0] - 1.0) if hist0[0] else None,
-                              "energy_rel_change": float(hist1[1] / hist0[1] - 1.0) if hist0[1] else None,
-                              "max_subcycles": max(drv.niter_trace) if drv.niter_trace else 0, "maxiter": run.maxiter,
-                              "ok": bool(fin and (not run.ion or max(drv.niter_trace) < run.maxiter))}
-        out["host_syncs_per_step"] = nsync / a.steps
-        # new_dt costs one read-back per step (two with several ranks: the slab's own and the all-reduce's)
-        out["host_syncs_per_subcycle"] = (nsync / a.steps - (2.0 if multi else 1.0)) / max(nsub, 1e-30) if run.ion else None
-        if prof:
-            ms_step = {k: v[0] / a.steps for k, v in prof.items()}
-            cls = {"hydro": 0.0, "subcycle": 0.0, "ion_step": 0.0, "other": 0.0}
-            for k, v in ms_step.items():
-                cls[kernel_class(k)] += v
-            # 1. the dominant kernel: compulsory bytes of one launch / its mean duration (hipEvent pairs
-            #    recorded on the launch stream inside the timed region)
-            dom = dominant_kernel(prof)
-            if dom:
-                ms, n = prof[dom]
-                scale = (nvar / 6.0) if kernel_class(dom) == "hydro" else 1.0
-                kb = KERNEL_BYTES[dom]
-                if dom == "correct_all" and "sweep_x3" not in prof:
-                    kb = CORRECT_ALL_X3_BYTES       # the x3 first pass rides along: its fluxes are neither written nor read
-                bpl = kb * zones_gpu * scale
-                ach = bpl / (ms / n * 1e-3) / 1e9
-                # measured HBM bytes per launch of that kernel: from the committed rocprofv3 PMC passes of
-                # this same command (profiles/r02_traffic.json); only valid for the workload it was taken on
-                traffic = None
-                try:
-                    # (the PMC passes were taken in the stationary regime and in the burst regime of `--spinup 19`)
-                    tf = "r02_traffic.json" if a.spinup == "auto" else ("r02_burst_traffic.json" if a.spinup == "19" else None)
-                    tj = json.load(open(os.path.join(ROOT, "profiles", tf)))
-                    if tj.get("workload", "").startswith(f"{a.problem} {nx}x{nx}x{nx3}") and a.integrator == "ctu" and a.order == 2 and world == 1 \
-                            and not a.ionized_slab and not a.strict:
-                        traffic = tj["kernels"].get(dom)
-                except Exception:
-                    pass
-                out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                   "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "bytes_per_launch": bpl,
-                                   "bytes_basis": f"{kb * scale:g} B/zone: the distinct doubles this kernel must read + write (DESIGN.md section 3)",
-                                   "avg_launch_ms": ms / n}
-            # 2. the phases of the step on SURVEY 8(d)'s algorithmic bytes: hydro chain 2*NVAR*8 B per
-            #    cell-update, radiation 64 B per cell and sub-cycle
-            ph = {}
-            b_h = 2 * 8 * nvar
-            if cls["hydro"] > 0:
-                a_h = b_h * zones_gpu / (cls["hydro"] * 1e-3) / 1e9
-                tf = HYDRO_FLOP_PER_CELL * zones_gpu / (cls["hydro"] * 1e-3) / 1e12
-                ph["hydro"] = {"ms_per_step": cls["hydro"], "bytes_per_cell": b_h, "achieved_GBs": a_h, "frac_hbm": a_h / HBM_PEAK_GBS,
-                               "ns_per_zone": 1e6 * cls["hydro"] / zones_gpu,
-                               "fp64_TFLOPs_est": tf, "frac_fp64_peak_est": tf / FP64_PEAK_TFLOPS}
-            if nsub_tot > 0 and cls["subcycle"] > 0:
-                ms_sub = cls["subcycle"] * a.steps / nsub_tot
-                a_s = 64 * zones_gpu / (ms_sub * 1e-3) / 1e9
-                ph["subcycle"] = {"ms_per_subcycle": ms_sub, "bytes_per_cell": 64, "achieved_GBs": a_s, "frac_hbm": a_s / HBM_PEAK_GBS,
-                                  "ns_per_zone": 1e6 * ms_sub / zones_gpu, "subcycles_timed": nsub_tot,
-                                  "note": "all kernels of the ion step's loop / sub-cycles timed; with ONE sub-cycle per step that is the first pass "
-                                          "(which also does the step's entry: floors, save_energy_and_x) plus the closing update-only pass"}
-                if prof.get("ion_pass", (0, 0))[1] > 0 and nsub > 1.5:
-                    # the repeating unit of a long loop: one full pass = update(n-1) + sweep(n) + rates(n)
-                    ms_full = prof["ion_pass"][0] / prof["ion_pass"][1]
-                    a_f = 64 * zones_gpu / (ms_full * 1e-3) / 1e9
-                    ph["subcycle"]["full_pass_ms"] = ms_full
-                    ph["subcycle"]["full_pass_frac_hbm"] = a_f / HBM_PEAK_GBS
-            ph["ion_step_overhead_ms"] = cls["ion_step"]
-            ph["other_ms"] = cls["other"]
-            ph["unattributed_ms"] = 1e3 * elapsed / a.steps - sum(cls.values())
-            out["phases"] = ph
-            out["kernel_ms_per_step"] = dict(sorted(ms_step.items(), key=lambda kv: -kv[1]))
-            out["kernel_launches_per_step"] = {k: v[1] / a.steps for k, v in prof.items()}
-        # 3. the whole step, the survey's definition: (2*NVAR*8 + 64*<N_sub>) B per cell-update
-        bstep = (2 * 8 * nvar) + (64 * nsub if run.ion else 0)
-        out["step_roofline"] = {"bytes_per_cell_update": bstep, "achieved": value / world * bstep / 1e9,
-                                "peak": HBM_PEAK_GBS, "unit": "GB/s per GPU",
-                                "frac": value / world * bstep / 1e9 / HBM_PEAK_GBS}
         if not a.no_cpu_baseline and world == 1:
             cb = cpu_baseline()
             out["cpu_baseline"] = cb
             if "phases" in out and "per_hydro_step_ns_per_zone" in cb:
                 ph = out["phases"]
                 out["gpu_vs_cpu"] = {"hydro_step": cb["per_hydro_step_ns_per_zone"] / ph["hydro"]["ns_per_zone"] if "hydro" in ph else None,
-                                     "subcycle": (cb["per_subcycle_ns_per_zone"] / ph["subcycle"]["ns_per_zone"]
-                                                  if "subcycle" in ph and cb.get("per_subcycle_ns_per_zone") else None),
-                                     "note": f"one MI355X against {cb['cores']} host cores, per zone and per hydro step / sub-cycle"}
+                                     "note": f"one MI355X against {cb['cores']} host cores, per zone and per hydro step"}
         print(json.dumps(out))
     if multi:
         dist.barrier()

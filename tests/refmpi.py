@@ -1,0 +1,68 @@
+"""TEST INFRASTRUCTURE: run the reference's own MPI build (oracle/_ref/athena_ioniz_sphere_mpi, the unmodified sources
+compiled by oracle/Makefile.ref; it travels to the GPU box as a prebuilt binary) on the host cores and reassemble the
+full-precision restart dumps its ranks write (restart.c:531-770; one file per rank under id<r>/, main.c:227-232).
+Used by the -m gpu parity tests as the checker, never by the product."""
+import os
+import re
+import shutil
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+from make_golden import read_rst      # noqa: E402  (the .rst parser only; nothing of /root/reference is touched)
+
+MPIEXEC = "/opt/conda/bin/mpiexec"
+EXE = os.path.join(ROOT, "oracle", "_ref", "athena_ioniz_sphere_mpi")
+DECK = os.path.join(ROOT, "atmospheric-athena_amd", "decks", "athinput.ioniz_sphere")
+
+
+def available():
+    return os.path.exists(EXE) and os.path.exists(MPIEXEC)
+
+
+def rank_grid(cores, nx):
+    """x2 x x3 split (never x1: the rays travel along x1), as many ranks as the cores allow"""
+    best = (1, 1)
+    for p2 in range(1, cores + 1):
+        for p3 in range(p2, cores + 1):
+            if p2 * p3 <= cores and nx[1] % p2 == 0 and nx[2] % p3 == 0 and (p2 * p3, p2) > (best[0] * best[1], best[0]):
+                best = (p2, p3)
+    return best
+
+
+def run(nx, nlim, overrides=(), cores=None):
+    """-> dict(U [Nx3][Nx2][Nx1][6] of the whole Domain after `nlim` steps, niter per step, time, dt, ranks)."""
+    cores = cores or min(len(os.sched_getaffinity(0)), 16)
+    p2, p3 = rank_grid(cores, nx)
+    tmp = tempfile.mkdtemp(prefix="refmpi_")
+    try:
+        txt = open(DECK).read().replace("<domain1>", f"<domain1>\nNGrid_x1 = 1\nNGrid_x2 = {p2}\nNGrid_x3 = {p3}", 1)
+        txt = re.sub(r"(?m)^maxout\s*=.*$", "maxout = 1", txt, count=1) + "\n<output1>\nout_fmt = rst\ndt = 1e300\n"
+        deck = os.path.join(tmp, "athinput")
+        open(deck, "w").write(txt)
+        rundir = os.path.join(tmp, "run")
+        env = dict(os.environ); env["LD_LIBRARY_PATH"] = "/opt/conda/lib:" + env.get("LD_LIBRARY_PATH", "")
+        args = [MPIEXEC, "-n", str(p2 * p3), EXE, "-i", deck, "-d", rundir] + [f"domain1/Nx{d + 1}={nx[d]}" for d in range(3)] \
+            + [f"time/nlim={nlim}"] + list(overrides)
+        pr = subprocess.run(args, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, cwd=tmp, timeout=1800, env=env)
+        if pr.returncode != 0:
+            raise RuntimeError(f"reference MPI run failed rc={pr.returncode}: {pr.stderr[-500:]}")
+        niter = [int(x) for x in re.findall(r"Radiation done in (\d+) iterations", pr.stderr)][::p2 * p3]
+        l2, l3 = nx[1] // p2, nx[2] // p3
+        U = np.zeros((nx[2], nx[1], nx[0], 6))
+        time = dt = None
+        for r in range(p2 * p3):
+            d = os.path.join(rundir, f"id{r}")
+            f = sorted(x for x in os.listdir(d) if x.endswith(".rst"))[-1]
+            g = read_rst(os.path.join(d, f), (nx[0], l2, l3), 1, True)
+            assert g["nstep"] == nlim
+            j, k = r % p2, r // p2                  # ranks are dealt x1-fastest, then x2, then x3 (init_mesh.c:589-596)
+            U[k * l3:(k + 1) * l3, j * l2:(j + 1) * l2] = g["U"]
+            time, dt = g["time"], g["dt"]
+        return dict(U=U, niter=niter, time=time, dt=dt, ranks=p2 * p3)
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)

@@ -189,7 +189,7 @@ def test_restart_of_the_reference_driver_on_gpu_library():
 
 @pytest.mark.parametrize("problem,nx,nlim,outdt", [("blast", (24, 16, 20), 9, 0.004), ("ioniz_sphere", (32, 32, 32), 7, 3.0e-5)])
 def test_auto_coherence_refreshes_the_host_exactly_when_main_reads_it(problem, nx, nlim, outdt):
-    """AA_COHERENCE=auto (the default): after two verified steps the host block is refreshed only when an <outputN> block
+    """AA_COHERENCE=auto (opt-in; the default is `step`): after two verified steps the host block is refreshed only when an <outputN> block
     is due, the loop ends, or SIGTERM arrives.  A restart output every `outdt` of simulated time puts dumps in the
     middle of the run: every dump must equal the one of AA_COHERENCE=step (same library, host kept in the loop every
     step) bit for bit, and there must be several of them."""
@@ -224,3 +224,30 @@ def test_auto_coherence_refreshes_the_host_exactly_when_main_reads_it(problem, n
         assert np.array_equal(x["U"], y["U"], equal_nan=True)
         if ion:
             assert np.array_equal(x["edgeflux"], y["edgeflux"])
+
+
+def test_userwork_that_wakes_up_later():
+    """A Userwork_in_loop that is a fixed imprint for the first steps and starts writing other, time-dependent values at
+    step 5 (tests/fixtures/userwork_late.c: the `if (time > t0)` pattern).  The DEFAULT coherence (`step`: the host block
+    takes part in every step) must follow the all-CPU reference through it.  AA_COHERENCE=auto adopts the imprint after two
+    steps, and must find out at its next re-validation (every AA_REVALIDATE_EVERY steps), say so, and carry on as `step`;
+    with re-validation on every step it is `step` in effect and must match the reference as well."""
+    if not os.path.exists(os.path.join(REFBIN, "athena_userwork_amd")):
+        pytest.skip("oracle/_ref/athena_userwork_amd not built (make -C oracle ref)")
+    nx, nlim = (20, 16, 12), 12
+    ref, _ = run("athena_userwork", "blast", nx, nlim)
+    gpu, err = run("athena_userwork_amd", "blast", nx, nlim)
+    assert "coherence=step" in err                                       # the default
+    assert gpu["nstep"] == ref["nstep"] == nlim and abs(gpu["dt"] / ref["dt"] - 1) < 1e-12
+    scale = np.abs(ref["U"][..., :5]).max(axis=(0, 1, 2)); scale[scale == 0] = 1
+    assert (np.abs(gpu["U"][..., :5] - ref["U"][..., :5]).max(axis=(0, 1, 2)) / scale).max() < 1e-11
+    # the stirred block really moved (the test would be empty otherwise)
+    assert np.abs(ref["U"][-3:, -3:, -3:, 1]).min() > 0.01
+    # auto, validated every step: equal to step
+    every, err1 = run("athena_userwork_amd", "blast", nx, nlim, {"AA_COHERENCE": "auto", "AA_REVALIDATE_EVERY": "1"})
+    assert "re-imposed on the device from now on" in err1 and "falls back to `step`" in err1
+    assert np.array_equal(every["U"], gpu["U"]) and every["dt"] == gpu["dt"]
+    # auto with the default interval: the wake-up at step 5 is caught by the validation of step 2 + 8 = 10 at the latest
+    late, err8 = run("athena_userwork_amd", "blast", nx, nlim, {"AA_COHERENCE": "auto"})
+    assert "coherence=auto" in err8 and "re-imposed on the device from now on" in err8
+    assert "WARNING: Userwork_in_loop no longer writes the imprint" in err8 and "falls back to `step`" in err8

@@ -258,13 +258,17 @@ def test_ioniz_sphere_vs_oracle(aa, lib, nx, nsteps, strict, fused_rates, ion_pa
     # fused multiply-adds) moves a few cells by ~1e-6; every other case holds 1e-8.
     # tests/test_conditioning.py: the ORACLE run again from a start state moved by one unit in the last place spreads
     # by 5e-6 .. 7e-6 on this case -- 2e-5 is what arithmetic that differs in the last bit can be held to here.
-    tol = 2e-5 if nx == (24, 16, 12) else 1e-8
-    assert max(err) < tol, err
     if nx == (24, 16, 12):
+        # held to what the oracle's own 1-ulp twins do in this session (tests/twins.py: ~7e-6 on ~48 zones), not to a constant
+        import twins
+        twin_worst, twin_nflip = twins.sphere_24x16x12()
         scale = np.nanmax(np.abs(b), axis=(0, 1, 2))
         nflip = int((np.abs(a - b) / scale > 1e-8).any(axis=-1).sum())
-        print(f"N_flip (zones beyond 1e-8) = {nflip} of {a[..., 0].size}, max {max(err):.2e}, strict={strict}")
-        assert nflip <= 64                      # ~1 % of the zones, around the planet; every other zone holds 1e-8
+        print(f"N_flip (zones beyond 1e-8) = {nflip} of {a[..., 0].size} (twins: {twin_nflip}), max {max(err):.2e} (twins: {twin_worst:.2e}), strict={strict}")
+        assert max(err) <= 2.0 * twin_worst, (err, twin_worst)
+        assert nflip <= 2 * twin_nflip, (nflip, twin_nflip)      # every other zone holds 1e-8
+    else:
+        assert max(err) < 1e-8, err
     g.close()
 
 
@@ -319,15 +323,19 @@ def test_tiny_and_awkward_grids(aa, lib, problem, nx, integrator, ion_path):
 
 @pytest.mark.parametrize("name,strict,tol", [("dev_blast_24x24x24_s30_s34", True, 0.0),
                                              ("dev_ioniz_sphere_32x32x32_s12_s15", True, 1e-9),
-                                             ("dev_ioniz_sphere_32x32x32_s12_s15", False, 1e-3),
-                                             ("dev_ifront_24x8x8_s40_s44", False, 1e-8)])
+                                             ("dev_ioniz_sphere_32x32x32_s12_s15", False, 1e-6),
+                                             ("dev_ifront_24x8x8_s40_s44", False, 1e-8),
+                                             # the regime the benchmark is timed in: ONE sub-cycle per step, six steps
+                                             ("dev_ioniz_sphere_36x36x36_s27_s33", True, 1e-9),
+                                             ("dev_ioniz_sphere_36x36x36_s27_s33", False, 1e-8)])
 def test_from_developed_reference_state(aa, lib, name, strict, tol, ion_path):
     """Load a reference state deep into the run (shocks, an evolved ionization front with up to 65
-    sub-cycles per step) the way a restart would, advance, compare with the reference's later state."""
+    sub-cycles per step; the stationary regime with one sub-cycle per step) the way a restart would, advance,
+    compare with the reference's later state."""
     gz = np.load(os.path.join(GOLD, name + ".npz"))
     prob = name[4:].rsplit("_", 3)[0]
     nx = tuple(int(x) for x in gz["nx"])
-    ov = [f"domain1/Nx{d + 1}={nx[d]}" for d in range(3)]
+    ov = [f"domain1/Nx{d + 1}={nx[d]}" for d in range(3)] + ([str(o) for o in gz["overrides"]] if "overrides" in gz.files else [])
     run = aa.config.load(os.path.join(orc.DECKS, "athinput." + prob), ov, prob)
     g = lib.setup_problem(aa.config.slab(run), 0, strict)
     nv = 5 + run.nscal
@@ -352,11 +360,50 @@ def test_from_developed_reference_state(aa, lib, name, strict, tol, ion_path):
             # the 32^3 sphere has a planet 3 zones in radius beside a 1e5 density jump: with fused
             # multiply-adds a limiter / Roe->HLLE decision flips in a few dozen zones by the third step
             # (the strict build of the same sources matches to 1e-9, in fact bit for bit); everywhere
-            # else the default build stays at rounding level.  tests/test_conditioning.py: the ORACLE itself, started
-            # from the same state moved by one unit in the last place, spreads by 6e-5 on 25 zones in these 3 steps.
+            # else the default build stays at rounding level.  Measured 1.8e-8 on 43 zones; asserted: north_star's 1e-6
+            # (tol), and no worse than the ORACLE's own 1-ulp twins of this pair do in this session (tests/twins.py:
+            # ~6e-5 on ~27 zones), in size and in the number of zones that move at all.
+            import twins
+            twin_worst, twin_nflip = twins.developed_sphere_32()
             nflip = int((err > 1e-9).any(axis=-1).sum())
-            print(f"N_flip (zones beyond 1e-9) = {nflip} of {err[..., 0].size}, max {err.max():.2e}")
-            assert (err > 1e-9).any(axis=-1).mean() < 0.005
+            print(f"N_flip (zones beyond 1e-9) = {nflip} of {err[..., 0].size} (twins: {twin_nflip}), max {err.max():.2e} (twins: {twin_worst:.2e})")
+            assert err.max() <= twin_worst and nflip <= 3 * twin_nflip, (err.max(), twin_worst, nflip, twin_nflip)
+    g.close()
+
+
+@pytest.mark.parametrize("spec", ["1", "0"])
+@pytest.mark.parametrize("strict", [True, False])
+def test_headline_regime_against_the_reference(aa, lib, strict, spec, ion_path, monkeypatch):
+    """The regime bench.py times: dt at the CFL limit, ONE radiation sub-cycle per step, i.e. ionrad_3d.c:919-1012 with the
+    loop body executed once.  On the device that is the speculated first update confirmed by k_ion_pick2 (spec_state 1), the
+    closing pass skipped and new_dt's maxima taken in the update kernel (aa_step).  Reference pair: steps 27 -> 33 of the
+    planet in a +-1.5e10 cm box at 36^3 (tests/golden/make_golden.py `dev`), sub-cycle counts 1 x 6, NaN-free.  Both builds,
+    both forms of the sub-cycle, speculation on and off: same sub-cycle counts, dt sequence to 1e-12, fields <= 1e-9 (strict)
+    / 1e-8 (default) of each field's maximum, ion fraction <= 1e-8, EdgeFlux <= 1e-9 (north_star's bar: 1e-6)."""
+    monkeypatch.setenv("AA_ION_SPECULATE", spec)
+    gz = np.load(os.path.join(GOLD, "dev_ioniz_sphere_36x36x36_s27_s33.npz"))
+    nx = tuple(int(x) for x in gz["nx"])
+    ov = [f"domain1/Nx{d + 1}={nx[d]}" for d in range(3)] + [str(o) for o in gz["overrides"]]
+    run = aa.config.load(os.path.join(orc.DECKS, "athinput.ioniz_sphere"), ov, "ioniz_sphere")
+    g = lib.setup_problem(aa.config.slab(run), 0, strict)
+    assert g.ion_is_fused() == (ion_path == "scan")
+    nv = 5 + run.nscal
+    U = g.new_host_block()
+    U[4:-4, 4:-4, 4:-4, :] = gz["UA"][..., :nv]
+    g.upload(U)
+    g.set_mesh_state(float(gz["timeA"]), float(gz["dtA"]), int(gz["nstepA"]))
+    g.bvals_mhd(); g.bvals_ionrad()
+    niter = [g.step() for _ in range(int(gz["nstepB"]) - int(gz["nstepA"]))]
+    assert niter == [1] * 6 == [int(x) for x in gz["niter"]]
+    assert abs(g.time / float(gz["timeB"]) - 1) < 1e-12 and abs(g.dt / float(gz["dtB"]) - 1) < 1e-12
+    out = g.download()[4:-4, 4:-4, 4:-4, :nv]; ref = gz["UB"][..., :nv]
+    assert np.isfinite(out).all()
+    err = relerr(out, ref)
+    assert max(err) < (1e-9 if strict else 1e-8), err
+    xg = 1.0 - out[..., 5] / out[..., 0]; xr = 1.0 - ref[..., 5] / ref[..., 0]
+    assert np.max(np.abs(xg - xr)) < 1e-8
+    ef = g.download_edgeflux()
+    assert np.allclose(ef, gz["edgefluxB"], rtol=1e-9, atol=1e-9 * np.abs(gz["edgefluxB"]).max())
     g.close()
 
 
@@ -374,6 +421,38 @@ def test_ioniz_sphere_default_kernels_vs_oracle(aa, lib):
     assert np.max(np.abs(xg - xo)) < 1e-8
     ef = g.download_edgeflux()
     assert np.allclose(ef, o.edgeflux, rtol=1e-9, atol=1e-9 * np.abs(o.edgeflux).max())
+    g.close()
+
+
+def test_128_cubed_12_steps_against_the_reference_mpi_run(aa, lib):
+    """The run bench.py's cpu_baseline times anyway -- the reference's own MPI build (oracle/_ref/athena_ioniz_sphere_mpi)
+    on the host cores, ioniz_sphere 128^3, 12 steps (11, 5, then 4 sub-cycles per step) -- with full-precision restart dumps,
+    reassembled (tests/refmpi.py), against the DEFAULT build with every size-switched kernel in its default form
+    (k_correct_all, k_flux2_update with new_dt's maxima, the one-kernel sub-cycle with the scan sweep and speculation).
+    Twelve steps, default kernels, the real reference: north_star's bar is 1e-6 on density and ion fraction; asserted 1e-8,
+    with identical sub-cycle counts and the dt sequence's end to 1e-12."""
+    import refmpi
+    if not refmpi.available():
+        pytest.skip("oracle/_ref/athena_ioniz_sphere_mpi or mpiexec not on this box")
+    nx = (128, 128, 128); nsteps = 12
+    ref = refmpi.run(nx, nsteps)
+    ov = [f"domain1/Nx{d + 1}={nx[d]}" for d in range(3)]
+    run = aa.config.load(os.path.join(orc.DECKS, "athinput.ioniz_sphere"), ov, "ioniz_sphere")
+    g = lib.setup_problem(aa.config.slab(run), 0, False)
+    assert g.ion_is_fused()
+    nv = 5 + run.nscal
+    g.start()
+    niter = [g.step() for _ in range(nsteps)]
+    assert niter == ref["niter"], (niter, ref["niter"])
+    assert abs(g.time / ref["time"] - 1) < 1e-12 and abs(g.dt / ref["dt"] - 1) < 1e-12
+    a = g.download()[4:-4, 4:-4, 4:-4, :nv]; b = ref["U"][..., :nv]
+    assert np.isfinite(a).all() and np.isfinite(b).all()
+    err = relerr(a, b)
+    xg = 1.0 - a[..., 5] / a[..., 0]; xr = 1.0 - b[..., 5] / b[..., 0]
+    ex = float(np.max(np.abs(xg - xr)))
+    print(f"128^3 x 12 steps vs the reference's MPI run on {ref['ranks']} ranks: max rel err per field {err}, ion fraction {ex:.2e}")
+    assert max(err) < 1e-8, err
+    assert ex < 1e-8
     g.close()
 
 

@@ -103,7 +103,8 @@ def test_developed_state_pairs_bitwise(name):
     g = np.load(os.path.join(GOLD, name + ".npz"))
     prob = name[4:].rsplit("_", 3)[0]
     nx = g["nx"]
-    s = orc.make_sim(prob, [f"domain1/Nx{d + 1}={int(nx[d])}" for d in range(3)])
+    over = [str(o) for o in g["overrides"]] if "overrides" in g.files else []      # e.g. the zoomed box of the one-sub-cycle pair
+    s = orc.make_sim(prob, [f"domain1/Nx{d + 1}={int(nx[d])}" for d in range(3)] + over)
     nv = 5 + s.grid.run.nscal
     s.active[..., :nv] = g["UA"][..., :nv]
     s.time = float(g["timeA"]); s.dt = float(g["dtA"]); s.nstep = int(g["nstepA"])
@@ -113,6 +114,17 @@ def test_developed_state_pairs_bitwise(name):
         assert niter == [int(x) for x in g["niter"]]
     assert s.time == float(g["timeB"]) and s.dt == float(g["dtB"])
     assert _same(s.active[..., :nv], g["UB"][..., :nv])
+    if "edgefluxB" in g.files:
+        assert _same(s.edgeflux, g["edgefluxB"])
+
+
+def test_the_headline_regime_is_pinned():
+    """The benchmark's timed region takes ONE radiation sub-cycle per step (ionrad_3d.c:919-1012 with the loop body
+    executed once): one of the developed reference pairs must be in exactly that regime, NaN-free, over several steps."""
+    g = np.load(os.path.join(GOLD, "dev_ioniz_sphere_36x36x36_s27_s33.npz"))
+    assert [int(x) for x in g["niter"]] == [1] * 6
+    assert np.isfinite(g["UA"]).all() and np.isfinite(g["UB"]).all()
+    assert float(g["dtB"]) < 1.5 * float(g["dtA"])            # dt is no longer doubling: it sits at the CFL limit
 
 
 SMR = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLD, "smr_*.npz")))
