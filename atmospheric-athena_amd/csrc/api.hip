@@ -189,7 +189,7 @@ int aa_create(const aa_params *p, aa_grid **out)
 void aa_destroy(aa_grid *g)
 {
   if (!g) return;
-  if (!g->slab.empty()) { slabs_destroy(g); return; }
+  if (g->link) { slabs_destroy(g); return; }          // a composite handle, whether or not it has slabs yet
   hipStreamSynchronize(g->st);
   prof_drain(g);
   hipFree(g->pool); hipFree(g->sc); hipHostFree(g->sc_host);
@@ -714,8 +714,8 @@ int aa_ion_pick(aa_grid *g, const double *dev_words_all, int nranks, int first, 
 // negative-dt_chem flag of the rates the step came from; dt_chem / dt_therm are those of the NEXT step (diagnostics)
 int aa_ion_fetch(aa_grid *g, double *dt, int *limit_hit, double *dt_chem, double *dt_therm, long long *cellcount, double *dt_hydro, int *neg)
 {
-  // (a Grid cut into slabs: slabs_ion_pick has already brought the slabs' words to the host and left the result here)
-  if (g->slab.empty()) { int rc = fetch_scalars(g); if (rc) return rc; }
+  // (a Grid cut into slabs: every slab has picked from the gathered words; slab 0's scalars come back)
+  { int rc = g->slab.empty() ? fetch_scalars(g) : slabs_fetch_scalars(g); if (rc) return rc; }
   *dt = g->sc_host->dt_applied; *limit_hit = g->sc_host->hit_applied;
   if (dt_chem) *dt_chem = g->sc_host->dt_chem_out;
   if (dt_therm) *dt_therm = g->sc_host->dt_therm_out;

@@ -101,6 +101,7 @@ int slabs_ion_rates(aa_grid *g, double *dt_chem, double *dt_therm);
 int slabs_ion_update(aa_grid *g, double dt, long long *cellcount, double *dt_hydro);
 int slabs_ion_pass(aa_grid *g, int update, int sweep);
 int slabs_ion_pick(aa_grid *g, int first, double limit);
+int slabs_fetch_scalars(aa_grid *g);
 int slabs_ion_finish(aa_grid *g);
 int slabs_ion_run_phased(aa_grid *g, double limit, int *niter_out, double *dt_done_out);
 int slabs_history(aa_grid *g, double *sums);

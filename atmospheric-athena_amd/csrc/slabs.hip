@@ -11,9 +11,14 @@
 //   * bvals_mhd: x1, x2 and physical x3 boundaries per slab, then both directions of the 4-plane x3 halo as
 //     device-to-device copies between neighbouring slabs (hipMemcpyPeerAsync over xGMI), ordered by events on the
 //     slabs' own streams -- no host synchronisation;
-//   * new_dt and the radiation sub-cycle's reductions: every slab leaves its words in pinned host memory, the
-//     host folds them (MIN / MAX / integer SUM: bitwise independent of the cut) -- one wait per sub-cycle, the
-//     slabs' kernels running concurrently;
+//   * new_dt: every slab leaves its maxima in pinned host memory, the host folds them (one wait per step).  The radiation
+//     sub-cycle's reductions stay on the devices: slab 0 pulls every slab's words (ion_pass.hip) with small peer copies,
+//     every slab pulls the gathered set back and picks the step itself (k_ion_pick2 with nranks = nslab, as the
+//     multi-process driver does behind its all-gather), all ordered by events -- the host reads back ONCE per
+//     sub-cycle (slab 0's scalars), and the next pass is already queued behind it (MIN / MAX / integer SUM: bitwise
+//     independent of the cut);
+//   * peer access between neighbouring devices is asked for and CHECKED; where it is refused (or with
+//     AA_SLAB_NO_PEER=1) the halo travels through pinned host buffers instead, and the library says so on stderr;
 //   * StaticGravPot is evaluated at the positions of the caller's undivided Grid, and the problem generator /
 //     Userwork hooks work on the caller's block, so an N-slab run reproduces the 1-slab run bit for bit.
 // Block decomposition as init_mesh.c:583-620: Nx3/N planes each, the remainder to the first slabs.
@@ -41,12 +46,21 @@ struct SlabLink {
   std::vector<hipEvent_t> unpacked;        // slab's recv buffers have been unpacked (free for the next copy)
   std::vector<bool> unpacked_valid;
   bool halo_due = false;                   // messages posted, ghost planes not yet written
-  double *hwords = nullptr;                // pinned: n x AA_ION_WORDS
   DevScalars *hsc = nullptr;               // pinned: n
   std::vector<Real*> dwords_all;           // device: n x AA_ION_WORDS on every slab
+  std::vector<hipEvent_t> wdone;           // slab's words of the pass just queued are complete
+  hipEvent_t gathered = nullptr;           // slab 0 holds every slab's words
+  // no peer access between two neighbouring devices (or AA_SLAB_NO_PEER=1): the halo goes device -> pinned host -> device
+  bool staged = false;
+  std::vector<Real*> hstage[2];            // pinned: the slab's two send buffers on the host
+  std::vector<hipStream_t> xout;           // the slab's device -> host copies
+  std::vector<hipEvent_t> staged_ev;       // ... are complete
   size_t halo = 0;
+  int home = 0;                            // the caller's current device when the handle was made
 };
 
+// every composite entry point leaves the caller's current HIP device as it found it
+struct DevGuard { int d = -1; DevGuard() { if (hipGetDevice(&d) != hipSuccess) d = -1; } ~DevGuard() { if (d >= 0) (void)hipSetDevice(d); } };
 #define SLAB_DEV(L, s) HIPCHK(hipSetDevice((L)->dev[s]))
 static int halo_finish(aa_grid *g);          // the ghost planes of a posted exchange are written before anything reads them
 #define HALO_FLUSH(g) do { int rc_ = halo_finish(g); if (rc_) return rc_; } while (0)
@@ -63,11 +77,14 @@ int slabs_create(const aa_params *p, int nslab, aa_grid **out)
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
     return aa_fail(-3, "[aa_create]: no HIP device visible -- this library has no CPU path");
+  DevGuard keep;
   aa_grid *g = new aa_grid();
   g->p = *p; g->p.nslab = nslab;
   memset(&g->d, 0, sizeof g->d);
   g->level = 0;
-  SlabLink *L = new SlabLink(); g->link = L; L->n = nslab;
+  SlabLink *L = new SlabLink(); g->link = L; L->n = nslab; L->home = keep.d;
+#define CREATE_CHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { slabs_destroy(g); \
+  return aa_fail(-2, "[aa_create] HIP error %s at %s:%d: %s", #x, __FILE__, __LINE__, hipGetErrorString(e_)); } } while (0)
   // devices: AA_SLAB_DEVICES="0,1,2,.." or round robin over the visible ones (one device: a rehearsal of the
   // multi-GPU path, every slab on it)
   std::vector<int> devs;
@@ -81,74 +98,108 @@ int slabs_create(const aa_params *p, int nslab, aa_grid **out)
     ps.nslab = 1;
     ps.Nx[2] = nk; ps.MinX[2] = minx3;                                    // init_grid.c:104-111
     ps.device = devs.empty() ? (p->device + s) % ndev : devs[s % devs.size()];
-    if (ps.device >= ndev) { aa_destroy(g); return aa_fail(-1, "[aa_create]: slab %d wants HIP device %d of %d", s, ps.device, ndev); }
+    if (ps.device >= ndev) { slabs_destroy(g); return aa_fail(-1, "[aa_create]: slab %d wants HIP device %d of %d", s, ps.device, ndev); }
     const int lo = (s > 0) ? s - 1 : (periodic ? nslab - 1 : -1), hi = (s < nslab - 1) ? s + 1 : (periodic ? 0 : -1);
     if (lo >= 0) ps.bc[4] = AA_BC_NONE;
     if (hi >= 0) ps.bc[5] = AA_BC_NONE;
     aa_grid *c = nullptr;
     int rc = aa_create(&ps, &c);
-    if (rc) { aa_destroy(g); return rc; }
+    if (rc) { slabs_destroy(g); return rc; }
     g->slab.push_back(c);
     L->k0.push_back(k0); L->nk.push_back(nk); L->dev.push_back(ps.device); L->lo.push_back(lo); L->hi.push_back(hi);
     k0 += nk; minx3 += (Real)nk*dx3;
   }
   g->ion_fused = g->slab[0]->ion_fused;
-  for (aa_grid *c : g->slab) if (c->ion_fused != g->ion_fused) { aa_destroy(g); return aa_fail(-1, "[aa_create]: slabs disagree on the sub-cycle path"); }
+  for (aa_grid *c : g->slab) if (c->ion_fused != g->ion_fused) { slabs_destroy(g); return aa_fail(-1, "[aa_create]: slabs disagree on the sub-cycle path"); }
   L->halo = (size_t)aa_halo_doubles(g->slab[0]);
-  L->packed.resize(nslab); L->copied.resize(nslab); L->copied_valid.assign(nslab, false);
-  L->xfer.assign(nslab, nullptr); L->unpacked.resize(nslab); L->unpacked_valid.assign(nslab, false);
-  L->dwords_all.assign(nslab, nullptr);
-  for (int w = 0; w < 2; w++) { L->send[w].assign(nslab, nullptr); L->recv[w].assign(nslab, nullptr); }
-  for (int s = 0; s < nslab; s++) {
-    SLAB_DEV(L, s);
-    for (int w = 0; w < 2; w++) {
-      HIPCHK(hipMalloc(&L->send[w][s], L->halo*sizeof(Real)));
-      HIPCHK(hipMalloc(&L->recv[w][s], L->halo*sizeof(Real)));
-    }
-    HIPCHK(hipMalloc(&L->dwords_all[s], (size_t)nslab*AA_ION_WORDS*sizeof(Real)));
-    HIPCHK(hipEventCreateWithFlags(&L->packed[s], hipEventDisableTiming));
-    HIPCHK(hipEventCreateWithFlags(&L->copied[s], hipEventDisableTiming));
-    HIPCHK(hipEventCreateWithFlags(&L->unpacked[s], hipEventDisableTiming));
-    HIPCHK(hipStreamCreateWithFlags(&L->xfer[s], hipStreamNonBlocking));
+  L->packed.assign(nslab, nullptr); L->copied.assign(nslab, nullptr); L->copied_valid.assign(nslab, false);
+  L->xfer.assign(nslab, nullptr); L->unpacked.assign(nslab, nullptr); L->unpacked_valid.assign(nslab, false);
+  L->dwords_all.assign(nslab, nullptr); L->wdone.assign(nslab, nullptr);
+  L->xout.assign(nslab, nullptr); L->staged_ev.assign(nslab, nullptr);
+  for (int w = 0; w < 2; w++) { L->send[w].assign(nslab, nullptr); L->recv[w].assign(nslab, nullptr); L->hstage[w].assign(nslab, nullptr); }
+  // peer access between neighbouring devices: asked for, and CHECKED
+  { const char *e = getenv("AA_SLAB_NO_PEER"); L->staged = e && atoi(e) != 0; }
+  if (L->staged) fprintf(stderr, "[athena_amd] AA_SLAB_NO_PEER: the x3 halo of the slabs travels through pinned host memory\n");
+  for (int s = 0; s < nslab && !L->staged; s++) {
+    CREATE_CHK(hipSetDevice(L->dev[s]));
     for (int o : {L->lo[s], L->hi[s]})
       if (o >= 0 && L->dev[o] != L->dev[s]) {
         int can = 0;
-        if (hipDeviceCanAccessPeer(&can, L->dev[s], L->dev[o]) == hipSuccess && can) {
-          hipError_t e = hipDeviceEnablePeerAccess(L->dev[o], 0);
-          if (e != hipSuccess) (void)hipGetLastError();                    // already enabled
+        hipError_t e = hipDeviceCanAccessPeer(&can, L->dev[s], L->dev[o]);
+        if (e == hipSuccess && can) {
+          e = hipDeviceEnablePeerAccess(L->dev[o], 0);
+          if (e == hipErrorPeerAccessAlreadyEnabled) { (void)hipGetLastError(); e = hipSuccess; }
+        }
+        if (e != hipSuccess || !can) {
+          (void)hipGetLastError();
+          fprintf(stderr, "[athena_amd] WARNING: no peer access from HIP device %d to %d (%s): the x3 halo of the slabs travels through "
+                          "pinned host memory instead of xGMI\n", L->dev[s], L->dev[o], e != hipSuccess ? hipGetErrorString(e) : "refused");
+          L->staged = true;
         }
       }
   }
-  HIPCHK(hipHostMalloc(&L->hwords, (size_t)nslab*AA_ION_WORDS*sizeof(double)));
-  HIPCHK(hipHostMalloc(&L->hsc, (size_t)nslab*sizeof(DevScalars)));
-  HIPCHK(hipHostMalloc(&g->sc_host, sizeof(DevScalars)));
+  for (int s = 0; s < nslab; s++) {
+    CREATE_CHK(hipSetDevice(L->dev[s]));
+    for (int w = 0; w < 2; w++) {
+      CREATE_CHK(hipMalloc(&L->send[w][s], L->halo*sizeof(Real)));
+      CREATE_CHK(hipMalloc(&L->recv[w][s], L->halo*sizeof(Real)));
+      if (L->staged) CREATE_CHK(hipHostMalloc(&L->hstage[w][s], L->halo*sizeof(Real)));
+    }
+    CREATE_CHK(hipMalloc(&L->dwords_all[s], (size_t)nslab*AA_ION_WORDS*sizeof(Real)));
+    CREATE_CHK(hipEventCreateWithFlags(&L->packed[s], hipEventDisableTiming));
+    CREATE_CHK(hipEventCreateWithFlags(&L->copied[s], hipEventDisableTiming));
+    CREATE_CHK(hipEventCreateWithFlags(&L->unpacked[s], hipEventDisableTiming));
+    CREATE_CHK(hipEventCreateWithFlags(&L->wdone[s], hipEventDisableTiming));
+    CREATE_CHK(hipStreamCreateWithFlags(&L->xfer[s], hipStreamNonBlocking));
+    if (L->staged) {
+      CREATE_CHK(hipStreamCreateWithFlags(&L->xout[s], hipStreamNonBlocking));
+      CREATE_CHK(hipEventCreateWithFlags(&L->staged_ev[s], hipEventDisableTiming));
+    }
+  }
+  CREATE_CHK(hipSetDevice(L->dev[0]));
+  CREATE_CHK(hipEventCreateWithFlags(&L->gathered, hipEventDisableTiming));
+  CREATE_CHK(hipHostMalloc(&L->hsc, (size_t)nslab*sizeof(DevScalars)));
+  CREATE_CHK(hipHostMalloc(&g->sc_host, sizeof(DevScalars)));
+#undef CREATE_CHK
   for (aa_grid *c : g->slab) g->bytes += c->bytes;
   *out = g;
   return 0;
 }
 
-void slabs_destroy(aa_grid *g)
+void slabs_destroy(aa_grid *g)      // (also the error path of slabs_create: whatever exists so far)
 {
+  DevGuard keep;
   SlabLink *L = g->link;
   for (size_t s = 0; s < g->slab.size(); s++) {
     hipSetDevice(L->dev[s]);
     hipStreamSynchronize(g->slab[s]->st);
-    if (s < L->xfer.size() && L->xfer[s]) { hipStreamSynchronize(L->xfer[s]); hipStreamDestroy(L->xfer[s]); hipEventDestroy(L->unpacked[s]); }
-    if (s < L->send[0].size()) for (int w = 0; w < 2; w++) { if (L->send[w][s]) hipFree(L->send[w][s]); if (L->recv[w][s]) hipFree(L->recv[w][s]); }
+    if (s < L->xfer.size() && L->xfer[s]) { hipStreamSynchronize(L->xfer[s]); hipStreamDestroy(L->xfer[s]); }
+    if (s < L->xout.size() && L->xout[s]) { hipStreamSynchronize(L->xout[s]); hipStreamDestroy(L->xout[s]); }
+    if (s < L->unpacked.size() && L->unpacked[s]) hipEventDestroy(L->unpacked[s]);
+    if (s < L->staged_ev.size() && L->staged_ev[s]) hipEventDestroy(L->staged_ev[s]);
+    if (s < L->wdone.size() && L->wdone[s]) hipEventDestroy(L->wdone[s]);
+    if (s < L->send[0].size()) for (int w = 0; w < 2; w++) {
+      if (L->send[w][s]) hipFree(L->send[w][s]);
+      if (L->recv[w][s]) hipFree(L->recv[w][s]);
+      if (L->hstage[w][s]) hipHostFree(L->hstage[w][s]);
+    }
     if (s < L->dwords_all.size() && L->dwords_all[s]) hipFree(L->dwords_all[s]);
-    if (s < L->packed.size() && L->packed[s]) { hipEventDestroy(L->packed[s]); hipEventDestroy(L->copied[s]); }
+    if (s < L->packed.size() && L->packed[s]) hipEventDestroy(L->packed[s]);
+    if (s < L->copied.size() && L->copied[s]) hipEventDestroy(L->copied[s]);
     aa_destroy(g->slab[s]);
   }
-  if (L->hwords) hipHostFree(L->hwords);
+  if (L->gathered) hipEventDestroy(L->gathered);
   if (L->hsc) hipHostFree(L->hsc);
   if (g->sc_host) hipHostFree(g->sc_host);
   delete L;
+  g->link = nullptr;
   g->slab.clear();
   delete g;
 }
 
 int slabs_sync(aa_grid *g)
 {
+  DevGuard keep;
   HALO_FLUSH(g);
   SlabLink *L = g->link;
   for (int s = 0; s < L->n; s++) { SLAB_DEV(L, s); HIPCHK(hipStreamSynchronize(g->slab[s]->st)); }
@@ -159,6 +210,7 @@ long long slabs_device_bytes(const aa_grid *g) { return g->bytes; }
 // ---- host transfers: k-plane ranges of the caller's block --------------------------------------------
 int slabs_upload_cons(aa_grid *g, const double *U)
 {
+  DevGuard keep;
   HALO_FLUSH(g);
   SlabLink *L = g->link;
   const size_t pl = (size_t)(g->p.Nx[0] + 2*AA_NGHOST)*(g->p.Nx[1] + 2*AA_NGHOST)*(5 + g->p.nscal);
@@ -171,6 +223,7 @@ int slabs_upload_cons(aa_grid *g, const double *U)
 }
 int slabs_download_cons(aa_grid *g, double *U)
 {
+  DevGuard keep;
   HALO_FLUSH(g);
   SlabLink *L = g->link;
   const size_t pl = (size_t)(g->p.Nx[0] + 2*AA_NGHOST)*(g->p.Nx[1] + 2*AA_NGHOST)*(5 + g->p.nscal);
@@ -187,6 +240,7 @@ int slabs_download_cons(aa_grid *g, double *U)
 }
 int slabs_upload_edgeflux(aa_grid *g, const double *ef)
 {
+  DevGuard keep;
   SlabLink *L = g->link;
   const size_t pl = (size_t)(g->p.Nx[0] + 1)*(g->p.Nx[1] + 1);
   for (int s = 0; s < L->n; s++) { SLAB_DEV(L, s); int rc = aa_upload_edgeflux(g->slab[s], ef + (size_t)L->k0[s]*pl); if (rc) return rc; }
@@ -194,6 +248,7 @@ int slabs_upload_edgeflux(aa_grid *g, const double *ef)
 }
 int slabs_download_edgeflux(aa_grid *g, double *ef)
 {
+  DevGuard keep;
   SlabLink *L = g->link;
   const size_t pl = (size_t)(g->p.Nx[0] + 1)*(g->p.Nx[1] + 1);
   for (int s = 0; s < L->n; s++) {
@@ -207,6 +262,7 @@ int slabs_download_edgeflux(aa_grid *g, double *ef)
 // ---- hooks ---------------------------------------------------------------------------------------------
 int slabs_set_grav_tables(aa_grid *g, const double *pc, const double *p1, const double *p2, const double *p3)
 {
+  DevGuard keep;
   SlabLink *L = g->link;
   const size_t pl = (size_t)(g->p.Nx[0] + 2*AA_NGHOST)*(g->p.Nx[1] + 2*AA_NGHOST);
   for (int s = 0; s < L->n; s++) {
@@ -222,6 +278,7 @@ int slabs_set_grav_tables(aa_grid *g, const double *pc, const double *p1, const 
 
 int slabs_set_pinned_cells(aa_grid *g, long long n, const long long *index, const double *values)
 {
+  DevGuard keep;
   HALO_FLUSH(g);
   SlabLink *L = g->link;
   const int nvar = 5 + g->p.nscal;
@@ -247,6 +304,7 @@ int slabs_set_pinned_cells(aa_grid *g, long long n, const long long *index, cons
 }
 int slabs_apply_pinned_cells(aa_grid *g)
 {
+  DevGuard keep;
   HALO_FLUSH(g);
   SlabLink *L = g->link;
   for (int s = 0; s < L->n; s++) { SLAB_DEV(L, s); int rc = aa_apply_pinned_cells(g->slab[s]); if (rc) return rc; }
@@ -254,6 +312,7 @@ int slabs_apply_pinned_cells(aa_grid *g)
 }
 int slabs_add_radplane(aa_grid *g, int dir, double flux)
 {
+  DevGuard keep;
   SlabLink *L = g->link;
   if (dir == -2) g->ion_fused = false;
   for (int s = 0; s < L->n; s++) { SLAB_DEV(L, s); int rc = aa_add_radplane_3d(g->slab[s], dir, flux); if (rc) return rc; }
@@ -261,6 +320,7 @@ int slabs_add_radplane(aa_grid *g, int dir, double flux)
 }
 int slabs_bvals_ionrad(aa_grid *g)
 {
+  DevGuard keep;
   SlabLink *L = g->link;
   for (int s = 0; s < L->n; s++) { SLAB_DEV(L, s); int rc = aa_bvals_ionrad(g->slab[s]); if (rc) return rc; }
   return 0;
@@ -270,6 +330,7 @@ int slabs_bvals_ionrad(aa_grid *g)
 // MPI_Waitall + unpack_ix3 / unpack_ox3: the slab's kernel stream waits for its copies and writes its ghost planes
 static int halo_finish(aa_grid *g)
 {
+  DevGuard keep;
   SlabLink *L = g->link;
   if (!L->halo_due) return 0;
   L->halo_due = false;
@@ -292,6 +353,7 @@ static int halo_finish(aa_grid *g)
 // their copy streams
 static int halo_post(aa_grid *g)
 {
+  DevGuard keep;
   SlabLink *L = g->link;
   HALO_FLUSH(g);
   const int nvar = 5 + g->p.nscal;
@@ -307,6 +369,12 @@ static int halo_post(aa_grid *g)
     if (L->lo[s] >= 0) launch_pack_x3(c->d, nvar, c->d.ks, L->send[0][s], c->st);                       // pack_ix3
     if (L->hi[s] >= 0) launch_pack_x3(c->d, nvar, c->d.ke - AA_NGHOST + 1, L->send[1][s], c->st);       // pack_ox3
     HIPCHK(hipEventRecord(L->packed[s], c->st));
+    if (L->staged) {             // no peer access: the send buffers go to pinned host memory on a copy stream of the sender
+      HIPCHK(hipStreamWaitEvent(L->xout[s], L->packed[s], 0));
+      if (L->lo[s] >= 0) HIPCHK(hipMemcpyAsync(L->hstage[0][s], L->send[0][s], bytes, hipMemcpyDeviceToHost, L->xout[s]));
+      if (L->hi[s] >= 0) HIPCHK(hipMemcpyAsync(L->hstage[1][s], L->send[1][s], bytes, hipMemcpyDeviceToHost, L->xout[s]));
+      HIPCHK(hipEventRecord(L->staged_ev[s], L->xout[s]));
+    }
   }
   for (int r = 0; r < L->n; r++) {
     if (L->lo[r] < 0 && L->hi[r] < 0) continue;
@@ -315,13 +383,15 @@ static int halo_post(aa_grid *g)
     if (L->unpacked_valid[r]) HIPCHK(hipStreamWaitEvent(x, L->unpacked[r], 0));     // my recv buffers are free
     if (L->lo[r] >= 0) {         // the lower neighbour's upper planes fill my lower ghost planes
       const int o = L->lo[r];
-      HIPCHK(hipStreamWaitEvent(x, L->packed[o], 0));
-      HIPCHK(hipMemcpyPeerAsync(L->recv[0][r], L->dev[r], L->send[1][o], L->dev[o], bytes, x));
+      HIPCHK(hipStreamWaitEvent(x, L->staged ? L->staged_ev[o] : L->packed[o], 0));
+      if (L->staged) HIPCHK(hipMemcpyAsync(L->recv[0][r], L->hstage[1][o], bytes, hipMemcpyHostToDevice, x));
+      else HIPCHK(hipMemcpyPeerAsync(L->recv[0][r], L->dev[r], L->send[1][o], L->dev[o], bytes, x));
     }
     if (L->hi[r] >= 0) {
       const int o = L->hi[r];
-      HIPCHK(hipStreamWaitEvent(x, L->packed[o], 0));
-      HIPCHK(hipMemcpyPeerAsync(L->recv[1][r], L->dev[r], L->send[0][o], L->dev[o], bytes, x));
+      HIPCHK(hipStreamWaitEvent(x, L->staged ? L->staged_ev[o] : L->packed[o], 0));
+      if (L->staged) HIPCHK(hipMemcpyAsync(L->recv[1][r], L->hstage[0][o], bytes, hipMemcpyHostToDevice, x));
+      else HIPCHK(hipMemcpyPeerAsync(L->recv[1][r], L->dev[r], L->send[0][o], L->dev[o], bytes, x));
     }
     HIPCHK(hipEventRecord(L->copied[r], x));
     L->copied_valid[r] = true;
@@ -333,6 +403,7 @@ static int halo_post(aa_grid *g)
 
 int slabs_bvals_mhd(aa_grid *g)
 {
+  DevGuard keep;
   SlabLink *L = g->link;
   HALO_FLUSH(g);
   for (int s = 0; s < L->n; s++) { SLAB_DEV(L, s); int rc = aa_bvals_mhd(g->slab[s]); if (rc) return rc; }   // x1, x2, physical x3
@@ -343,6 +414,7 @@ int slabs_bvals_mhd(aa_grid *g)
 // exchange belongs to the x3 step and is done with its inner side
 int slabs_bvals_mhd_side(aa_grid *g, int dir, int side)
 {
+  DevGuard keep;
   SlabLink *L = g->link;
   HALO_FLUSH(g);
   if (dir < 2) {
@@ -358,6 +430,7 @@ int slabs_bvals_mhd_side(aa_grid *g, int dir, int side)
 // ---- time step: new_dt.c:72-177 ----------------------------------------------------------------------
 static int cfl_all(aa_grid *g)
 {
+  DevGuard keep;
   SlabLink *L = g->link;
   for (int s = 0; s < L->n; s++) {
     SLAB_DEV(L, s);
@@ -397,6 +470,7 @@ int slabs_new_dt_local(aa_grid *g, double *dt_cfl)
 
 int slabs_integrate(aa_grid *g, int vl)
 {
+  DevGuard keep;
   SlabLink *L = g->link;
   slabs_push_state(g);
   if (L->halo_due) {     // the ghost planes are still on their way: first the sweeps that do not read them
@@ -414,62 +488,79 @@ int slabs_integrate(aa_grid *g, int vl)
 // ---- radiation -----------------------------------------------------------------------------------------
 int slabs_ion_begin(aa_grid *g)
 {
+  DevGuard keep;
   SlabLink *L = g->link;
   slabs_push_state(g);
   for (int s = 0; s < L->n; s++) { SLAB_DEV(L, s); int rc = aa_ion_begin(g->slab[s]); if (rc) return rc; }
   return 0;
 }
 
-// the one-kernel sub-cycle: every slab runs its pass; slabs_ion_pick folds the slabs' words on the host
+// the one-kernel sub-cycle: every slab runs its pass and leaves its words in its own device memory
 int slabs_ion_pass(aa_grid *g, int update, int sweep)
 {
+  DevGuard keep;
   SlabLink *L = g->link;
   for (int s = 0; s < L->n; s++) {
     SLAB_DEV(L, s);
     aa_grid *c = g->slab[s];
     int rc = aa_ion_pass(c, update, sweep, nullptr); if (rc) return rc;
-    HIPCHK(hipMemcpyAsync(L->hwords + (size_t)s*AA_ION_WORDS, c->ion_words, AA_ION_WORDS*sizeof(double), hipMemcpyDeviceToHost, c->st));
+    HIPCHK(hipEventRecord(L->wdone[s], c->st));
   }
   return 0;
 }
 
+// ionrad_3d.c:275,399,554,672 (the MPI_Allreduce calls) without the host: slab 0 pulls every slab's words (after ALL of
+// them are complete: by then every slab has also finished reading the previous set out of slab 0), every slab pulls the
+// gathered set back and picks the step itself.  The next pass of slab s is queued behind its own pick, i.e. behind the
+// gather: its words are not overwritten before slab 0 has them.
 int slabs_ion_pick(aa_grid *g, int first, double limit)
 {
+  DevGuard keep;
   SlabLink *L = g->link;
-  for (int s = 0; s < L->n; s++) { SLAB_DEV(L, s); HIPCHK(hipStreamSynchronize(g->slab[s]->st)); }
-  g->host_syncs++;
-  // every slab gets all words and picks the step itself (its next pass reads it from its own memory) ...
+  const size_t wb = AA_ION_WORDS*sizeof(double);
+  {
+    SLAB_DEV(L, 0);
+    aa_grid *c0 = g->slab[0];
+    for (int s = 1; s < L->n; s++) HIPCHK(hipStreamWaitEvent(c0->st, L->wdone[s], 0));
+    for (int s = 0; s < L->n; s++) {
+      if (L->dev[s] == L->dev[0]) HIPCHK(hipMemcpyAsync(L->dwords_all[0] + (size_t)s*AA_ION_WORDS, g->slab[s]->ion_words, wb, hipMemcpyDeviceToDevice, c0->st));
+      else HIPCHK(hipMemcpyPeerAsync(L->dwords_all[0] + (size_t)s*AA_ION_WORDS, L->dev[0], g->slab[s]->ion_words, L->dev[s], wb, c0->st));
+    }
+    HIPCHK(hipEventRecord(L->gathered, c0->st));
+  }
   for (int s = 0; s < L->n; s++) {
     SLAB_DEV(L, s);
     aa_grid *c = g->slab[s];
-    HIPCHK(hipMemcpyAsync(L->dwords_all[s], L->hwords, (size_t)L->n*AA_ION_WORDS*sizeof(double), hipMemcpyHostToDevice, c->st));
+    if (first && c->ion_spec_armed && limit != c->ion_spec_limit)
+      return aa_fail(-1, "[aa_ion_pick]: limit %.17g, but aa_ion_speculate was told %.17g", limit, c->ion_spec_limit);
+    if (s > 0) {
+      HIPCHK(hipStreamWaitEvent(c->st, L->gathered, 0));
+      if (L->dev[s] == L->dev[0]) HIPCHK(hipMemcpyAsync(L->dwords_all[s], L->dwords_all[0], (size_t)L->n*wb, hipMemcpyDeviceToDevice, c->st));
+      else HIPCHK(hipMemcpyPeerAsync(L->dwords_all[s], L->dev[s], L->dwords_all[0], L->dev[0], (size_t)L->n*wb, c->st));
+    }
     launch_ion_pick2(L->dwords_all[s], L->n, c->sc, first, limit, c->st, first ? (c->ion_spec_armed ? 1 : 0) : 0);
     if (!first) c->ion_spec_armed = false;
   }
-  // ... and the host does the same arithmetic (k_ion_pick2; ionrad_3d.c:941-967) for its own control flow: no second wait
-  double dt_chem = DBL_MAX, dt_therm = DBL_MAX, max_dti = 0.0, count = 0.0, neg = 0.0;
-  for (int r = 0; r < L->n; r++) {
-    const double *w = L->hwords + (size_t)r*AA_ION_WORDS;
-    dt_chem = (dt_chem < w[0]) ? dt_chem : w[0]; dt_therm = (dt_therm < w[1]) ? dt_therm : w[1];
-    max_dti = (max_dti > w[2]) ? max_dti : w[2]; count += w[3]; neg = (neg > w[4]) ? neg : w[4];
-  }
-  DevScalars *h = g->sc_host;
-  double dt_done = 0.0;
-  if (!first) {
-    h->dt_applied = h->dt_sel; h->hit_applied = h->limit_hit; h->neg_applied = h->neg_out;
-    dt_done = h->dt_done + h->dt_sel;
-  }
-  h->dt_done = dt_done;
-  h->max_dti = double_to_bits(max_dti); h->cellcount = (unsigned long long)count;
-  double dt = (dt_therm < dt_chem) ? dt_therm : dt_chem;
-  int hit = 0;
-  if (dt_done + dt > limit) { dt = limit - dt_done; hit = 1; }
-  h->dt_sel = dt; h->limit_hit = hit; h->dt_chem_out = dt_chem; h->dt_therm_out = dt_therm; h->neg_out = (neg != 0.0);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+// the ONE read-back of a sub-cycle: slab 0's scalars (every slab holds the same ones)
+int slabs_fetch_scalars(aa_grid *g)
+{
+  DevGuard keep;
+  SlabLink *L = g->link;
+  SLAB_DEV(L, 0);
+  aa_grid *c0 = g->slab[0];
+  HIPCHK(hipMemcpyAsync(g->sc_host, c0->sc, sizeof(DevScalars), hipMemcpyDeviceToHost, c0->st));
+  HIPCHK(hipStreamSynchronize(c0->st));
+  g->host_syncs++;
   return 0;
 }
 
 int slabs_ion_finish(aa_grid *g)
 {
+  DevGuard keep;
   SlabLink *L = g->link;
   for (int s = 0; s < L->n; s++) { SLAB_DEV(L, s); int rc = aa_ion_finish(g->slab[s]); if (rc) return rc; }
   return 0;
@@ -478,6 +569,7 @@ int slabs_ion_finish(aa_grid *g)
 // the two-kernel sub-cycle (short rays): the reductions go through the host twice per sub-cycle, as under MPI
 int slabs_ion_rates(aa_grid *g, double *dt_chem, double *dt_therm)
 {
+  DevGuard keep;
   SlabLink *L = g->link;
   *dt_chem = DBL_MAX; *dt_therm = DBL_MAX;
   for (int s = 0; s < L->n; s++) {
@@ -489,6 +581,7 @@ int slabs_ion_rates(aa_grid *g, double *dt_chem, double *dt_therm)
 }
 int slabs_ion_update(aa_grid *g, double dt, long long *cellcount, double *dt_hydro)
 {
+  DevGuard keep;
   SlabLink *L = g->link;
   long long n = 0; double h = DBL_MAX;
   for (int s = 0; s < L->n; s++) {
@@ -524,6 +617,7 @@ int slabs_ion_run_phased(aa_grid *g, double limit, int *niter_out, double *dt_do
 
 int slabs_history(aa_grid *g, double *sums)
 {
+  DevGuard keep;
   SlabLink *L = g->link;
   for (int q = 0; q < 9; q++) sums[q] = 0.0;
   for (int s = 0; s < L->n; s++) {            // dump_history.c:257 MPI_Reduce(SUM) over the Grids of a Domain

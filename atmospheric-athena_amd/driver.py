@@ -478,6 +478,7 @@ class MeshDriver:
             assert dist.is_initialized() and dist.get_world_size() == nranks and dist.get_rank() == rank
         self._sdev = getattr(self.eng, "scalar_device", torch.device("cpu"))
         self.niter_trace: List[List[int]] = []
+        self._fused_cache = {}
 
     def has(self, l: int) -> bool: return l < self.nl
 
@@ -581,14 +582,26 @@ class MeshDriver:
 
     # ---- radiation ---------------------------------------------------------------------------------
     def _level_fused(self, l: int) -> bool:
-        """whether level l runs the one-kernel sub-cycle: the same answer on every rank (x3 slabs keep Nx1), also on
-        ranks that hold no zones of the level"""
-        if not hasattr(self.eng, "ion_pass"):
-            return False
-        env = os.environ.get("AA_ION_FUSED")
-        if env is not None:
-            return env not in ("", "0")
-        return self.level_nx1[l] >= 64
+        """whether level l runs the one-kernel sub-cycle: asked of the LIBRARY (aa_ion_is_fused: it knows aa_params.ion_path,
+        AA_ION_FUSED as it parses it, the ray direction) on the ranks that hold zones of the level, and agreed on by all
+        ranks once -- ranks without zones of the level have no Grid to ask, and a rank that disagreed would issue the
+        other protocol's collectives."""
+        if l in self._fused_cache:
+            return self._fused_cache[l]
+        if not hasattr(self.eng, "ion_pass") or not hasattr(self.eng, "ion_is_fused"):
+            ans = False
+        else:
+            mine = (1.0 if self.eng.ion_is_fused(l) else 0.0) if self.has(l) else -1.0          # -1: no opinion
+            if self.distributed:
+                hi = self._allreduce((mine,), self.dist.ReduceOp.MAX)[0]
+                lo = self._allreduce((mine if mine >= 0 else 2.0,), self.dist.ReduceOp.MIN)[0]
+                if hi >= 0 and lo <= 1.0 and hi != lo:
+                    raise RuntimeError(f"[MeshDriver]: the ranks disagree on the radiation sub-cycle path of level {l}")
+                ans = hi > 0.5
+            else:
+                ans = mine > 0.5
+        self._fused_cache[l] = ans
+        return ans
 
     def _ion_radtransfer_fused(self, l: int) -> int:
         """ionrad_3d.c:862 on level l with the one-kernel sub-cycle (see Driver._ion_radtransfer_fused): one pass, ONE

@@ -83,6 +83,48 @@ def test_slabs_with_the_big_grid_kernels(problem, nx, nsteps, nslab, monkeypatch
         assert np.array_equal(many["ef"], one["ef"])
 
 
+@pytest.mark.parametrize("problem,nx,nsteps,nslab", [("blast", (24, 16, 32), 3, 2), ("ioniz_sphere", (64, 20, 20), 2, 4)])
+def test_halo_through_pinned_host_memory_when_peer_access_is_refused(problem, nx, nsteps, nslab, monkeypatch, capfd):
+    """hipDeviceCanAccessPeer / hipDeviceEnablePeerAccess may say no between two devices; the halo then travels device ->
+    pinned host -> device on the slabs' copy streams, ordered by events as the peer copies are.  Forced here
+    (AA_SLAB_NO_PEER=1) on the one-device rehearsal: the library says so, and the bits are the one-Grid run's."""
+    one = _run(problem, nx, nsteps, 1, "ctu", True)
+    monkeypatch.setenv("AA_SLAB_NO_PEER", "1")
+    many = _run(problem, nx, nsteps, nslab, "ctu", True)
+    assert "travels through pinned host memory" in capfd.readouterr().err
+    assert many["its"] == one["its"] and many["time"] == one["time"] and many["dt"] == one["dt"]
+    assert np.array_equal(many["U"], one["U"], equal_nan=True)
+    if "ef" in one:
+        assert np.array_equal(many["ef"], one["ef"])
+
+
+def test_composite_handles_refuse_what_they_cannot_do_and_keep_the_callers_device():
+    """Entry points that make no sense on a Grid cut into slabs fail with a message instead of touching null pointers, and
+    every composite call leaves the caller's current HIP device as it found it."""
+    import ctypes as C
+    import torch
+    aa = importlib.import_module("atmospheric-athena_amd")
+    lib = importlib.import_module("atmospheric-athena_amd.lib")
+    run = aa.config.load(os.path.join(ROOT, "atmospheric-athena_amd", "decks", "athinput.ifront"),
+                         ["domain1/Nx1=64", "domain1/Nx2=8", "domain1/Nx3=16"], "ifront")
+    g = lib.setup_problem(aa.config.slab(run), 0, True, nslab=2)
+    assert torch.cuda.current_device() == 0
+    g.start(); g.step()
+    assert g.halo_doubles() == 0
+    L = g.L
+    buf = (C.c_double * 16)()
+    for f in (L.aa_fetch_scalars, L.aa_ion_arm):          # (exported for the Mesh / drivers; not in lib.py's table)
+        f.restype = C.c_int; f.argtypes = [C.c_void_p]
+    for call in (lambda: L.aa_pack_x3(g._h, 0, C.cast(buf, C.c_void_p)), lambda: L.aa_fetch_scalars(g._h), lambda: L.aa_ion_arm(g._h)):
+        assert call() != 0 and b"slabs" in L.aa_last_error()
+    assert g.host_syncs(True) >= 0
+    g.step()
+    n = g.host_syncs()
+    its = g.ion_radtransfer_3d()
+    assert g.host_syncs() - n == its             # ONE read-back per radiation sub-cycle, also across the slabs
+    g.close()
+
+
 def test_too_thin_slabs_are_refused():
     aa = importlib.import_module("atmospheric-athena_amd")
     lib = importlib.import_module("atmospheric-athena_amd.lib")
