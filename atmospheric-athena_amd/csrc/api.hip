@@ -102,10 +102,7 @@ int aa_create(const aa_params *p, aa_grid **out)
   // (80^3: +7 %): same results bit for bit, so the choice follows the size unless AA_CORRECT_ALL forces it
   { const char *e = getenv("AA_CORRECT_ALL");
     g->correct_all = e ? atoi(e) != 0 : ((long long)p->Nx[0]*p->Nx[1]*p->Nx[2] >= (1LL << 21)); }
-  // k_correct_all also does the x3 first pass (no k_sweep_march<2> launch, those fluxes never in HBM): -3.1 ms of a 512^3
-  // blast step, -4.2 ms ifront, -4.4 / -2.0 ms third order without / with gravity.  The one combination it does not pay
-  // for is second order + passive scalar + gravity (ioniz_sphere: the kernel is bound by its own instruction stream
-  // there, 249 VGPRs at 2 waves per SIMD, and the step gets 0.6-0.9 ms slower): left to the sweep kernel.  Same bits.
+  // (k_correct_all also does the x3 first pass: see x3_fused below)
   { const char *e = getenv("AA_CFL_FUSED"); g->cfl_step = e ? atoi(e) != 0 : true; g->cfl_force = e && atoi(e) == 2; }     // aa_step: new_dt's maxima from the update kernel
   { const char *e = getenv("AA_X3_FUSED"); g->x3_fused_mode = e ? (atoi(e) != 0) : -1; }    // (the potential arrives after aa_create)
   // rates inside the ray sweep: one block per 64 rays, so it needs many rays to fill the chip (512^2 rays:
@@ -433,9 +430,11 @@ int aa_new_dt(aa_grid *g)
 }
 
 // k_correct_all also does the x3 first pass (no k_sweep_march<2> launch, those fluxes never in HBM): -3.1 ms of a 512^3
-// blast step, -4.2 ms ifront, -4.4 / -2.0 ms third order without / with gravity.  The one combination it does not pay for
-// is second order + passive scalar + gravity (ioniz_sphere: the kernel is bound by its own instruction stream there,
-// 249 VGPRs at 2 waves per SIMD, and the step gets 0.6-0.9 ms slower): left to the sweep kernel.  Same bits either way.
+// blast step, -4.2 ms ifront, -4.4 / -2.0 ms third order without / with gravity.  Second order + passive scalar + gravity
+// (ioniz_sphere: 249 VGPRs at 2 waves per SIMD) was a draw in round 2 and left to the sweep kernel; with the hardware
+// min / max in the reconstruction (AA_FD_MINMAX: 12 % fewer instructions in this kernel) it is ahead there too --
+// 19.5 against 17.2 + 4.55 ms, hydro chain 45.5 -> 43.3 (round 3, same-box ABAB) -- and is the default everywhere.
+// Same bits either way.
 // aa_cfl_in_update: zero the maxima and let k_flux2_update fill them
 static void cfl_arm(aa_grid *g)
 {
@@ -455,8 +454,8 @@ int aa_cfl_in_update(aa_grid *g, int on)
   return 0;
 }
 
-static bool x3_fused(const aa_grid *g)
-{ return g->x3_fused_mode >= 0 ? g->x3_fused_mode != 0 : !(g->p.nscal > 0 && g->grav && !g->d.slope); }
+static bool x3_fused(const aa_grid *g)      // default: always (round 3; until then not for second order + scalar + gravity)
+{ return g->x3_fused_mode >= 0 ? g->x3_fused_mode != 0 : true; }
 
 // The part of the step that needs none of the x3 neighbours' planes: the first-pass x1 and x2 sweeps of the k-planes
 // ks .. ke (a pencil along x1 or x2 lies in one plane).  A multi-GPU caller posts the x3 halo, calls this, waits for the

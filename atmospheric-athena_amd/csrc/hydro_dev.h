@@ -37,6 +37,13 @@ AA_DEV Real sqr(Real x) { return x*x; }
 #ifndef AA_FD_PLM
 #define AA_FD_PLM AA_FAST_DIV
 #endif
+// P/(gamma - 1) in prim_to_cons as a product with the (loop-invariant) reciprocal: two divisions less per face; x2 / x3
+// first passes -6 %, hydro chain 45.7 -> 45.1 ms (round 3, same-box ABAB at 512^3) -- and OFF: the conserved face states
+// feed the Riemann solver's Roe -> HLLE switch (see AA_FD_ROE below), and with the energy rounded differently the
+// 3-level blast of the drop-in test left the reference by 7.6e-7 in time after six steps (one flipped switch)
+#ifndef AA_FD_P2C
+#define AA_FD_P2C 0
+#endif
 // The Riemann solver keeps the reference's operations in every build: its switch to HLLE (negative density or pressure of
 // an intermediate state, roe.c:256-286) is the one DISCONTINUOUS decision of the hydro step, and symmetric flows sit
 // exactly on it -- with the reciprocal forms in flux_roe a 3-level blast differed from the reference by 2.6e-3 in 116
@@ -89,7 +96,11 @@ template <int NS>
 AA_DEV void prim_to_cons(const Real w[6], Real u[6], Real Gamma_1)
 {
   u[0] = w[0]; u[1] = w[0]*w[1]; u[2] = w[0]*w[2]; u[3] = w[0]*w[3];
+#if AA_FD_P2C
+  u[4] = w[4]*(1.0/Gamma_1) + 0.5*w[0]*(sqr(w[1]) + sqr(w[2]) + sqr(w[3]));      // (the quotient is loop-invariant: one division per thread)
+#else
   u[4] = w[4]/Gamma_1 + 0.5*w[0]*(sqr(w[1]) + sqr(w[2]) + sqr(w[3]));
+#endif
   u[5] = NS ? w[5]*w[0] : 0.0;
 }
 
@@ -99,6 +110,29 @@ AA_DEV Real cfast(const Real u[6], Real Gamma, Real Gamma_1)
   Real p = Gamma_1*(u[4] - 0.0 - 0.5*(sqr(u[1]) + sqr(u[2]) + sqr(u[3]))/u[0]);
   Real asq = Gamma*p/u[0];
   return sqrt(asq);
+}
+
+// The wave speeds the H-correction's eta is made of (integrate_3d_ctu.c:2300-2343): v - cfast of a face's left state,
+// v + cfast of its right state.  Default build (AA_FD_ETA): one reciprocal of the density serves the velocity, the pressure
+// and the sound speed, the square root comes from v_rsq_f64 -- 3 divisions + 1 square root (~60 instructions, most of them
+// quarter rate) become ~25.  eta enters the second-pass fluxes only through max(|lambda|, etah): continuous, no switch
+// hangs on its last bit.  A non-positive a^2 (negative face pressure beside the planet's density jump: the NaN etas the
+// reference produces there) takes the reference's own expression, so the NaN pattern is the reference's.
+#ifndef AA_FD_ETA
+#define AA_FD_ETA AA_FAST_DIV
+#endif
+AA_DEV Real lambda_face(const Real u[6], Real Gamma, Real Gamma_1, Real sign)
+{
+#if AA_FD_ETA
+  const Real d = u[0];
+  if (d > 1.0e-280 && d < 1.0e280) {
+    const Real di = q_rcp(d);
+    const Real p = Gamma_1*(u[4] - 0.0 - 0.5*(sqr(u[1]) + sqr(u[2]) + sqr(u[3]))*di);
+    const Real asq = Gamma*p*di;
+    if (asq > 1.0e-280 && asq < 1.0e280) return u[1]*di + sign*(asq*q_rsqrt(asq));
+  }
+#endif
+  return u[1]/u[0] + sign*cfast(u, Gamma, Gamma_1);
 }
 
 // rsolvers/hlle.c:62 (compiled into roe.c as flux_hlle, roe.c:339-341)
@@ -263,6 +297,22 @@ AA_DEV void flux_roe(const Real ul[6], const Real ur[6], const Real wl[6], const
 // wl_next = Wl[i+1] (left state of the upper interface) and wr_here = Wr[i] (right state of
 // the lower interface), PLM in characteristic variables + CTU characteristic tracing.
 // TRACE=false is the VL_INTEGRATOR branch (lr_states_plm.c:250-255).
+// AA_FD_MINMAX (default build): v_min_f64 / v_max_f64 for the 66 MIN / MAX of a reconstructed cell instead of the
+// reference's compare-and-select macro (3 instructions each): -5 % of the first-pass sweeps, -3 % of k_correct_all
+// (round 3, same-box ABAB at 512^3: hydro chain 48.0 -> 46.7 ms).  Equal on finite operands up to the sign of a zero; a NaN
+// operand is dropped by the hardware min / max where the macro's result depends on the operand order -- the strict build
+// keeps the macro, and so does every MAX of the H-correction's eta chain in both builds (NaN etas are part of the
+// reference's behaviour beside the planet's density jump).
+#ifndef AA_FD_MINMAX
+#define AA_FD_MINMAX AA_FAST_DIV
+#endif
+#if AA_FD_MINMAX
+AA_DEV Real pmax(Real a, Real b) { return __builtin_fmax(a, b); }
+AA_DEV Real pmin(Real a, Real b) { return __builtin_fmin(a, b); }
+#else
+AA_DEV Real pmax(Real a, Real b) { return rmax(a, b); }
+AA_DEV Real pmin(Real a, Real b) { return rmin(a, b); }
+#endif
 template <int NS, bool TRACE>
 AA_DEV void plm_cell(const Real wm[6], const Real w[6], const Real wp[6], Real dtodx, Real Gamma,
                      Real wl_next[6], Real wr_here[6])
@@ -307,9 +357,9 @@ AA_DEV void plm_cell(const Real wm[6], const Real w[6], const Real wp[6], Real d
   for (int n = 0; n < NV; n++) {
     da[n] = 0.0;
     if (dal[n]*dar[n] > 0.0) {
-      Real lim1 = rmin(fabs(dal[n]), fabs(dar[n]));
-      Real lim2 = rmin(0.5*fabs(dac[n]), fabs(dag[n]));
-      da[n] = ((dac[n] < 0.) ? -1. : 1.)*rmin(2.0*lim1, lim2);
+      Real lim1 = pmin(fabs(dal[n]), fabs(dar[n]));
+      Real lim2 = pmin(0.5*fabs(dac[n]), fabs(dag[n]));
+      da[n] = ((dac[n] < 0.) ? -1. : 1.)*pmin(2.0*lim1, lim2);
     }
   }
   Real dWm[6];
@@ -325,11 +375,11 @@ AA_DEV void plm_cell(const Real wm[6], const Real w[6], const Real wp[6], Real d
     Wlv[n] = w[n] - 0.5*dWm[n];
     Wrv[n] = w[n] + 0.5*dWm[n];
     Real C = Wrv[n] + Wlv[n];
-    Wlv[n] = rmax(rmin(w[n], wm[n]), Wlv[n]);
-    Wlv[n] = rmin(rmax(w[n], wm[n]), Wlv[n]);
+    Wlv[n] = pmax(pmin(w[n], wm[n]), Wlv[n]);
+    Wlv[n] = pmin(pmax(w[n], wm[n]), Wlv[n]);
     Wrv[n] = C - Wlv[n];
-    Wrv[n] = rmax(rmin(w[n], wp[n]), Wrv[n]);
-    Wrv[n] = rmin(rmax(w[n], wp[n]), Wrv[n]);
+    Wrv[n] = pmax(pmin(w[n], wp[n]), Wrv[n]);
+    Wrv[n] = pmin(pmax(w[n], wp[n]), Wrv[n]);
     Wlv[n] = (C - Wrv[n]);
     dW[n] = Wrv[n] - Wlv[n];
   }
@@ -339,10 +389,10 @@ AA_DEV void plm_cell(const Real wm[6], const Real w[6], const Real wp[6], Real d
     for (int n = 0; n < NV; n++) { wl_next[n] = Wrv[n]; wr_here[n] = Wlv[n]; }
     return;
   }
-  Real qx = 0.5*rmax(ev4, 0.0)*dtodx;
+  Real qx = 0.5*pmax(ev4, 0.0)*dtodx;
 #pragma unroll
   for (int n = 0; n < NV; n++) wl_next[n] = Wrv[n] - qx*dW[n];
-  qx = -0.5*rmin(ev0, 0.0)*dtodx;
+  qx = -0.5*pmin(ev0, 0.0)*dtodx;
 #pragma unroll
   for (int n = 0; n < NV; n++) wr_here[n] = Wlv[n] + qx*dW[n];
 
@@ -406,9 +456,9 @@ AA_DEV void limited_slopes(const Real wm[6], const Real w[6], const Real wp[6], 
   for (int n = 0; n < NV; n++) {
     da[n] = 0.0;
     if (dal[n]*dar[n] > 0.0) {
-      Real lim1 = rmin(fabs(dal[n]), fabs(dar[n]));
-      Real lim2 = rmin(0.5*fabs(dac[n]), fabs(dag[n]));
-      da[n] = ((dac[n] < 0.) ? -1. : 1.)*rmin(2.0*lim1, lim2);
+      Real lim1 = pmin(fabs(dal[n]), fabs(dar[n]));
+      Real lim2 = pmin(0.5*fabs(dac[n]), fabs(dag[n]));
+      da[n] = ((dac[n] < 0.) ? -1. : 1.)*pmin(2.0*lim1, lim2);
     }
   }
   dWm[0] = da[0]; dWm[0] += da[1]; dWm[0] += da[4];
@@ -456,22 +506,22 @@ AA_DEV void ppm_cell(const Real wm[6], const Real w[6], const Real wp[6], const 
   }
 #pragma unroll
   for (int n = 0; n < NV; n++) {
-    Wlv[n] = rmax(rmin(w[n], wm[n]), Wlv[n]);
-    Wlv[n] = rmin(rmax(w[n], wm[n]), Wlv[n]);
-    Wrv[n] = rmax(rmin(w[n], wp[n]), Wrv[n]);
-    Wrv[n] = rmin(rmax(w[n], wp[n]), Wrv[n]);
+    Wlv[n] = pmax(pmin(w[n], wm[n]), Wlv[n]);
+    Wlv[n] = pmin(pmax(w[n], wm[n]), Wlv[n]);
+    Wrv[n] = pmax(pmin(w[n], wp[n]), Wrv[n]);
+    Wrv[n] = pmin(pmax(w[n], wp[n]), Wrv[n]);
   }
 #pragma unroll
   for (int n = 0; n < NV; n++) {
     dW[n] = Wrv[n] - Wlv[n];
     W6[n] = 6.0*(w[n] - 0.5*(Wlv[n]*(1.0 - gamma_curv) + Wrv[n]*(1.0 + gamma_curv)));
   }
-  Real qx1 = 0.5*rmax(ev4, 0.0)*dtodx;
+  Real qx1 = 0.5*pmax(ev4, 0.0)*dtodx;
 #pragma unroll
   for (int n = 0; n < NV; n++)
     wl_next[n] = Wrv[n] - qx1 *(dW[n] - (1.0 - FOUR_3RDS*qx1)*W6[n])
                         + qxx1*(dW[n] - (1.0 -       2.0*qx1)*W6[n]);
-  Real qx2 = -0.5*rmin(ev0, 0.0)*dtodx;
+  Real qx2 = -0.5*pmin(ev0, 0.0)*dtodx;
 #pragma unroll
   for (int n = 0; n < NV; n++)
     wr_here[n] = Wlv[n] + qx2 *(dW[n] + (1.0 - FOUR_3RDS*qx2)*W6[n])

@@ -160,8 +160,7 @@ AA_DEV void face_correct(const DevGrid &g, long m, int i, int j, int k, Real dt,
   Real sl[6], sr[6];
 #pragma unroll
   for (int n = 0; n < 6; n++) { sl[n] = ul[gv<D>(n)]; sr[n] = ur[gv<D>(n)]; }
-  Real cfr = cfast(sr, g.Gamma, g.Gamma_1), cfl = cfast(sl, g.Gamma, g.Gamma_1);
-  Real lambdar = sr[1]/sr[0] + cfr, lambdal = sl[1]/sl[0] - cfl;
+  Real lambdar = lambda_face(sr, g.Gamma, g.Gamma_1, 1.0), lambdal = lambda_face(sl, g.Gamma, g.Gamma_1, -1.0);
   Ef(g, D)[m] = 0.5*fabs(lambdar - lambdal);
   if (GRAV && D == 1 && j <= g.je + 1) {       // d^{n+1/2}, :2104-2125 (needs all first-pass fluxes:
                                                // done in the x2 correct pass, which runs after them)
@@ -490,11 +489,9 @@ AA_DEV void cell_recon(const DevGrid &g, long m, Real dt, const CellFlux &cf, co
 }
 // second half: conversion, transverse correction, face states stored; returns the wave speeds eta needs: lam_l of the
 // left state the zone gave to its UPPER face, lam_r of the right state it gave to its LOWER face
-// `park` != nullptr: the twelve face states go to the thread's LDS slots park[v*PS], park[(6 + v)*PS] instead of to HBM
-// (k_correct_all stores them at the head of its next iteration, behind that iteration's loads: CA_DEFER)
 template <int NS, int D, bool GRAV>
 AA_DEV void cell_finish(const DevGrid &g, long m, const Real q[3], const CellFlux &cf, const Real wl[6], const Real wr[6],
-                        bool store, Real &lam_l, Real &lam_r, Real *park = nullptr, int PS = 0)
+                        bool store, Real &lam_l, Real &lam_r)
 {
   constexpr int NV = 5 + NS;
   const long sD = stride<D>(g);
@@ -517,26 +514,22 @@ AA_DEV void cell_finish(const DevGrid &g, long m, const Real q[3], const CellFlu
       ul[1 + e] -= cf.gm[e]; ul[4] -= cf.ge[e];
     }
   }
-  if (park) {
-#pragma unroll
-    for (int v = 0; v < NV; v++) { park[v*PS] = ul[v]; park[(6 + v)*PS] = ur[v]; }
-  } else if (store) {
+  if (store) {
 #pragma unroll
     for (int v = 0; v < NV; v++) { LRf(g, D, 0, v)[m + sD] = ul[v]; LRf(g, D, 1, v)[m] = ur[v]; }
   }
 #pragma unroll
   for (int n = 0; n < 6; n++) { sl[n] = ul[gv<D>(n)]; sr[n] = ur[gv<D>(n)]; }
-  const Real cfr = cfast(sr, g.Gamma, g.Gamma_1), cfl = cfast(sl, g.Gamma, g.Gamma_1);
-  lam_r = sr[1]/sr[0] + cfr;
-  lam_l = sl[1]/sl[0] - cfl;
+  lam_r = lambda_face(sr, g.Gamma, g.Gamma_1, 1.0);
+  lam_l = lambda_face(sl, g.Gamma, g.Gamma_1, -1.0);
 }
 template <int NS, int D, bool GRAV, int ORD>
 AA_DEV void cell_states(const DevGrid &g, long m, Real dt, const Real q[3], const CellFlux &cf, const Real wm[6], const Real w[6],
-                        const Real wp[6], bool store, Real &lam_l, Real &lam_r, Real *park = nullptr, int PS = 0)
+                        const Real wp[6], bool store, Real &lam_l, Real &lam_r)
 {
   Real wl[6], wr[6];
   cell_recon<NS, D, GRAV, ORD>(g, m, dt, cf, wm, w, wp, wl, wr);
-  cell_finish<NS, D, GRAV>(g, m, q, cf, wl, wr, store, lam_l, lam_r, park, PS);
+  cell_finish<NS, D, GRAV>(g, m, q, cf, wl, wr, store, lam_l, lam_r);
 }
 
 #ifndef CA_PARK
@@ -544,12 +537,6 @@ AA_DEV void cell_states(const DevGrid &g, long m, Real dt, const Real q[3], cons
 #endif
 #ifndef CA_LB2SEL
 #define CA_LB2SEL 1
-#endif
-// CA_DEFER: the face states of the LAST direction block(s) of an iteration (1: x2; 2: x1 and x2) wait in LDS and are stored at
-// the head of the next iteration, behind that iteration's loads.  Loads and stores retire through ONE in-order counter: a
-// wait for the head loads otherwise sits behind the stores issued just before them and exposes their full write latency.
-#ifndef CA_DEFER
-#define CA_DEFER 1
 #endif
 template <int NS, bool GRAV, int ORD, bool X3F>
 __global__ void __launch_bounds__(64*CA_TJ, (CA_LB2SEL == 2 || (CA_LB2SEL == 1 && X3F && NS && GRAV)) ? 2 : 1)
@@ -566,11 +553,8 @@ k_correct_all(DevGrid g, Real dt, int kchunk)
   // through one counter).  s_h1: per wave, the 6 + 6 conserved variables of the two x1 neighbours, fetched by lanes 0..11.
   __shared__ Real s_h1[CA_TJ][12];
   __shared__ Real s_h2[2][6][64];
-  __shared__ Real s_def[CA_DEFER ? CA_DEFER : 1][CA_DEFER ? 12 : 1][CA_TJ][64];
   constexpr int NV = 5 + NS;
-  constexpr int PS = CA_TJ*64;                     // stride between a thread's slots in s_def
   const int lane = threadIdx.x, row = threadIdx.y;
-  bool pend = false;                               // face states of the previous iteration wait in s_def
   // Zones s-1 .. e+1 in every direction get their face states.  Tiles do NOT overlap in x1 / x2 (round 1's did by one
   // provider lane / row: 64x4 threads for 63x3 zones, 35 % more threads, loads and arithmetic than zones) and start on a
   // 128-byte line (zone is - 16: the rows' first active zone is line-aligned).  What a tile cannot do alone is the eta of
@@ -696,29 +680,12 @@ k_correct_all(DevGrid g, Real dt, int kchunk)
         cf.kl[e] = dtodx*(phir - phic); cf.kr[e] = dtodx*(phic - phil);
       }
     }
-#if CA_DEFER
-    if (pend) {      // (block-uniform) the previous iteration's parked face states, behind this iteration's loads
-      __builtin_amdgcn_sched_barrier(0);
-      if (in) {
-        const long mp = m - g.sK;
-#pragma unroll
-        for (int v = 0; v < NV; v++) {
-          LRf(g, 1, 0, v)[mp + g.sJ] = s_def[0][v][row][lane]; LRf(g, 1, 1, v)[mp] = s_def[0][6 + v][row][lane];
-        }
-#if CA_DEFER > 1
-#pragma unroll
-        for (int v = 0; v < NV; v++) {
-          LRf(g, 0, 0, v)[mp + 1] = s_def[1][v][row][lane]; LRf(g, 0, 1, v)[mp] = s_def[1][6 + v][row][lane];
-        }
-#endif
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      pend = false;
-    }
-#endif
     // the neighbour zones go to their (wave-private) LDS slots HERE, before the first face-state store of the iteration: the
     // wait for these loads would otherwise sit behind the x3 block's twelve stores and drain them (loads and stores retire
-    // through ONE in-order counter: rocprof showed an s_waitcnt vmcnt(0) in the middle of every iteration)
+    // through ONE in-order counter: the ISA had an s_waitcnt vmcnt(0) in the middle of every iteration; 18.5 -> 18.3 ms).
+    // (Tried on top and dropped, round 3: the x2 block's -- and the x1 block's -- twelve face states parked in LDS and stored at
+    //  the head of the NEXT iteration behind its loads, so that no load wait sits behind fresh stores: 18.6-18.9 / 19.5-19.7
+    //  against 18.3-18.5 ms.  The write latency is not what this kernel waits for; it moves its 92 GB at 5 TB/s.)
     if (full) {
       if (lane < 12) s_h1[row][lane] = hv1;
       if (edge_row) {
@@ -755,8 +722,7 @@ k_correct_all(DevGrid g, Real dt, int kchunk)
 #pragma unroll
           for (int v = 0; v < 6; v++) { if (lane == 0) wm[v] = wh[v]; else wp[v] = wh[v]; }
         }
-        if (do1) cell_states<NS, 0, GRAV, ORD>(g, m, dt, q, cf, wm, ws, wp, true, ll, lr,
-                                               CA_DEFER > 1 ? &s_def[CA_DEFER > 1 ? 1 : 0][0][row][lane] : nullptr, PS);
+        if (do1) cell_states<NS, 0, GRAV, ORD>(g, m, dt, q, cf, wm, ws, wp, true, ll, lr);
         const Real lprev = __shfl_up(ll, 1);
         if (do1) {
           if (lane > 0) { if (i > g.is - 1) Ef(g, 0)[m] = 0.5*fabs(lr - lprev); }
@@ -791,8 +757,7 @@ k_correct_all(DevGrid g, Real dt, int kchunk)
           for (int n = 0; n < NV; n++) wp[n] = s_w[row + 1][n][lane];
           if (!NS) wp[5] = 0.0;
         }
-        if (do2) cell_states<NS, 1, GRAV, ORD>(g, m, dt, q, cf, wm, ws, wp, true, ll, lr, CA_DEFER ? &s_def[0][0][row][lane] : nullptr, PS);
-        if (CA_DEFER) pend = true;
+        if (do2) cell_states<NS, 1, GRAV, ORD>(g, m, dt, q, cf, wm, ws, wp, true, ll, lr);
         s_l[row][lane] = ll;
         __syncthreads();
         if (do2) {
@@ -817,21 +782,6 @@ k_correct_all(DevGrid g, Real dt, int kchunk)
       }
     }
   }
-#if CA_DEFER
-  if (pend && in) {      // the last plane's parked face states
-    const long mp = (long)k1*g.sK + mcol;
-#pragma unroll
-    for (int v = 0; v < NV; v++) {
-      LRf(g, 1, 0, v)[mp + g.sJ] = s_def[0][v][row][lane]; LRf(g, 1, 1, v)[mp] = s_def[0][6 + v][row][lane];
-    }
-#if CA_DEFER > 1
-#pragma unroll
-    for (int v = 0; v < NV; v++) {
-      LRf(g, 0, 0, v)[mp + 1] = s_def[1][v][row][lane]; LRf(g, 0, 1, v)[mp] = s_def[1][6 + v][row][lane];
-    }
-#endif
-  }
-#endif
 }
 
 // eta of the faces on the tile edges of k_correct_all: the face's slot holds lambda_r of the zone above it, the edge

@@ -60,6 +60,10 @@ typedef struct aa_grid aa_grid;
 
 /* ---- lifecycle: init_grid.c (U, EdgeFlux), integrate_init_3d (integrate_3d_ctu.c:3374),
  *      ion_radtransfer_init_3d (ionrad_3d.c:739), ion_radtransfer_init (ionrad.c:64)      */
+/* aa_params.nslab > 1 (or AA_NGPU=N in the environment): the handle stands for the caller's ONE Grid cut into N x3 slabs, one
+ * per HIP device (AA_SLAB_DEVICES=0,1,.. or p->device, +1, .. modulo the visible ones; csrc/slabs.hip).  Root level only
+ * (aa_mesh_create refuses it), >= 4 planes per slab, <= 64 slabs; aa_pack_x3 / aa_unpack_x3 / aa_set_stream return an error
+ * on it and aa_halo_doubles 0 (the slabs exchange their halos themselves); the caller's current device is left unchanged. */
 int         aa_create(const aa_params *p, aa_grid **out);
 void        aa_destroy(aa_grid *g);   /* integrate_destruct_3d :3498 */
 const char *aa_last_error(void);
@@ -87,7 +91,8 @@ int aa_set_static_grav_tables(aa_grid *g, const double *phi_cc, const double *ph
  * the [k][j][i] block incl. ghosts, nvar values each) applied after the integrator.          */
 int aa_set_pinned_cells(aa_grid *g, long long n, const long long *index, const double *values);
 int aa_apply_pinned_cells(aa_grid *g);
-/* ionradplane_3d.c:56 add_radplane_3d (called by problem()); dir must be -1 (+x1 rays) */
+/* ionradplane_3d.c:56 add_radplane_3d (called by problem()); dir = -1 (rays along +x1) or -2 (along +x2: two-kernel
+ * sub-cycle).  dir = -3 and dir > 0 are refused: the reference has no defined behaviour for them. */
 int aa_add_radplane_3d(aa_grid *g, int dir, double flux);
 int aa_has_radplane(const aa_grid *g);   /* main.c:546 `radplanelist[0].nradplane > 0`: whether a step includes the ion step */
 
@@ -109,7 +114,8 @@ int aa_step(aa_grid *g, int *niter);                /* one pass of main.c:519-66
 /* The part of integrate_3d_ctu that reads none of the x3 neighbours' planes (the first-pass x1 / x2 sweeps of the
  * planes ks..ke, integrate_3d_ctu.c:196-620): call it between posting the x3 halo (bvals_mhd.c:423-493) and waiting
  * for it; aa_integrate_3d_ctu then does the rest.  Same bits with or without; a no-op where the split does not apply. */
-int aa_integrate_begin(aa_grid *g);
+int aa_integrate_begin(aa_grid *g);      /* (aa_upload_cons, aa_download_cons and aa_history between the two calls are allowed:
+                                           * they stage through the face-state area and make the integrator redo these sweeps) */
 /* new_dt.c:72-140 inside the integrator: with on != 0 the caller promises that between aa_integrate_3d_ctu and the
  * next aa_new_dt_local / aa_cfl_max_v nothing but aa_apply_pinned_cells changes the active zones (the order of main.c:572-629
  * when Userwork_in_loop only pins zones); the update kernel then leaves max(|v_d| + a) behind while the new state is in

@@ -20,8 +20,7 @@ DECKS = os.path.join(ROOT, "atmospheric-athena_amd", "decks")
 
 def run_gpu(problem, ov, strict, fused, nstep, monkeypatch, order=2):
     """fused: False = separate kernels; True = k_flux2_update; "all" = k_correct_all + k_flux2_update; "all+x3" = the
-    same with the x3 first pass inside k_correct_all (AA_X3_FUSED; the library's default for every configuration but
-    second order + scalar + gravity, forced either way here)"""
+    same with the x3 first pass inside k_correct_all (AA_X3_FUSED; the library's default since round 3, forced either way here)"""
     aa = importlib.import_module("atmospheric-athena_amd")
     lib = importlib.import_module("atmospheric-athena_amd.lib")
     monkeypatch.setenv("AA_FUSED_UPDATE", "1" if fused else "0")

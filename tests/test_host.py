@@ -160,3 +160,25 @@ def test_bench_helpers():
     assert bench._rank_grid(16, 128) == (4, 4) and bench._rank_grid(8, 128) == (2, 4) and bench._rank_grid(1, 128) == (1, 1)
     p2, p3 = bench._rank_grid(12, 96)
     assert p2 * p3 <= 12 and 96 % p2 == 0 and 96 % p3 == 0
+
+
+def test_boundary_docs_match_the_shim():
+    """The shim's defaults and the C header are the contract a maintainer of the reference reads: INTEGRATION.md's table of
+    environment knobs must state the default the code has, and list every value the code accepts."""
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    shim = open(os.path.join(root, "atmospheric-athena_amd", "host", "athena_shim.c")).read()
+    doc = open(os.path.join(root, "INTEGRATION.md")).read()
+    hdr = open(os.path.join(root, "include", "athena_amd.h")).read()
+    # the default: no AA_COHERENCE in the environment => neither auto nor learn => step
+    assert re.search(r'automode = \(env && strcmp\(env, "auto"\) == 0\)', shim)
+    assert re.search(r'learn = automode \|\| \(env && strcmp\(env, "learn"\) == 0\)', shim)
+    row = next(ln for ln in doc.splitlines() if ln.startswith("| `AA_COHERENCE`"))
+    assert row.split("|")[2].strip() == "`step`"
+    for mode in re.findall(r'strcmp\(env, "(\w+)"\) != 0', shim):          # every accepted value is documented
+        assert f"`{mode}`" in row, mode
+    m = re.search(r'reval_every = r \? atoi\(r\) : (\d+)', shim)
+    row = next(ln for ln in doc.splitlines() if ln.startswith("| `AA_REVALIDATE_EVERY`"))
+    assert row.split("|")[2].strip() == m.group(1)
+    assert "dir = -1 (rays along +x1) or -2" in hdr and "dir must be -1" not in hdr
+    assert "nslab > 1" in hdr and "AA_NGPU" in doc
