@@ -930,8 +930,11 @@ AA_DEV void face_flux2(const DevGrid &g, long m, Real f[6])
 }
 
 // new_dt.c:72-140 for one zone: max(|v_d| + a) per direction (the operands and their order as in k_cfl)
+// (no multiply-add contraction in here, in either build: the same zone must give the same bits whether it is visited by
+//  k_cfl, by k_pinned_cfl or inside the update kernel, so that AA_CFL_FUSED changes no bit of dt in the default build either)
 AA_DEV void cfl_zone(Real d, Real m1, Real m2, Real m3, Real e, Real Gamma, Real Gamma_1, Real mx[3])
 {
+#pragma clang fp contract(off)
   const Real di = 1.0/d;
   const Real v1 = m1*di, v2 = m2*di, v3 = m3*di;
   const Real qsq = v1*v1 + v2*v2 + v3*v3;
@@ -1621,7 +1624,12 @@ template <int NS, bool GRAV>
 static void correct_all_impl(const DevGrid &g, Real dt, bool x3f, hipStream_t st)
 {
   const int ni = g.ie - g.is + 3, nj = g.je - g.js + 3, nk = g.ke - g.ks + 3;    // zones s-1 .. e+1
-  int kc = 32;
+  // planes per block: with the x3 first pass on board a chunk starts three planes early (two of first-pass work only and the
+  // provider plane), so longer chunks pay: 64 planes 19.7 against 20.0 - 20.6 ms for 32 at 512^3 (128: 20.4, 16: 20.2);
+  // AA_CA_KC overrides
+  static int kc_env = -1;
+  if (kc_env < 0) { const char *e = getenv("AA_CA_KC"); kc_env = e ? atoi(e) : 0; }
+  int kc = kc_env > 0 ? kc_env : (x3f ? 64 : 32);
   while (kc > 4 && (long)nblk(ni - 1, 63)*nblk(nj - 1, CA_TJ - 1)*((nk + kc - 1)/kc) < 1024) kc >>= 1;
   dim3 grid(nblk(ni + 15, 64), nblk(nj, CA_TJ), (nk + kc - 1)/kc), blk(64, CA_TJ);
   if (x3f) {

@@ -135,7 +135,7 @@ def test_new_dt_maxima_from_the_update_kernel(problem, ov, nstep, strict, monkey
     """AA_CFL_FUSED: k_flux2_update leaves max(|v_d| + a) of the zones it has just updated behind (pinned zones excepted,
     which k_pinned_cfl adds after Userwork has overwritten them: ioniz_sphere's core), new_dt reads that instead of sweeping
     the Grid with k_cfl.  MAX of the same non-negative doubles: the dt sequence and the state are the same, bit for bit, in
-    the strict build; in the default build the two kernels may contract one multiply-add differently (1e-15)."""
+    BOTH builds (cfl_zone is compiled without multiply-add contraction everywhere: ADVICE r02)."""
     aa = importlib.import_module("atmospheric-athena_amd")
     lib = importlib.import_module("atmospheric-athena_amd.lib")
     monkeypatch.setenv("AA_FUSED_UPDATE", "1")
@@ -151,8 +151,5 @@ def test_new_dt_maxima_from_the_update_kernel(problem, ov, nstep, strict, monkey
         out.append((g.download(), its, dts))
         g.close()
     assert out[0][1] == out[1][1]
-    if strict:
-        assert out[0][2] == out[1][2]
-        assert np.array_equal(out[0][0], out[1][0], equal_nan=True)
-    else:
-        assert np.allclose(out[0][2], out[1][2], rtol=1e-14, atol=0)
+    assert out[0][2] == out[1][2]
+    assert np.array_equal(out[0][0], out[1][0], equal_nan=True)
