@@ -77,6 +77,9 @@ class GridConfig:
     lx3: int                                          # neighbour rank below (-1: physical BC)
     rx3: int                                          # neighbour rank above
     level: int = 0                                    # DomainS.Level (static mesh refinement)
+    lx2: int = -1                                     # x2 x x3 pencils: neighbour ranks in x2 (-1: physical BC / not cut)
+    rx2: int = -1
+    p2: int = 1                                       # Grids along x2 (NGrid_x2); nranks = p2 * (Grids along x3)
 
 
 def from_par(par: ParTable, problem: Optional[str] = None) -> RunConfig:
@@ -151,6 +154,45 @@ def slab(run: RunConfig, rank: int = 0, nranks: int = 1) -> GridConfig:
                       Nx=(run.rootNx[0], run.rootNx[1], nx3[rank]),
                       disp=(0, 0, disp3), MinX=(run.xmin[0], run.xmin[1], minx3),
                       bc=tuple(bc), lx3=lx3, rx3=rx3)
+
+
+def pencil(run: RunConfig, rank: int, p2: int, p3: int) -> GridConfig:
+    """One Grid of an NGrid_x2 x NGrid_x3 = p2 x p3 decomposition of the root Domain (init_mesh.c:526-620; x1 is never cut:
+    the rays travel along it and it is the contiguous axis).  Ranks are dealt x2-fastest, then x3 (init_mesh.c:589-596 with
+    NGrid_x1 = 1); cells per Grid and the remainder rule as :583-620, MinX accumulated as init_grid.c:104-111."""
+    if p2 < 1 or p3 < 1 or not (0 <= rank < p2 * p3):
+        raise ParError(f"[config]: bad rank {rank} of {p2}x{p3}")
+    if p2 == 1:
+        return slab(run, rank, p3)
+    r2, r3 = rank % p2, rank // p2
+    nx2, nx3 = split_cells(run.rootNx[1], p2), split_cells(run.rootNx[2], p3)
+    if min(nx2) < NGHOST or min(nx3) < NGHOST:
+        raise ParError(f"[config]: pencils thinner than nghost={NGHOST} ({run.rootNx[1]}/{p2} x {run.rootNx[2]}/{p3})")
+    dx = run.dx
+    minx2, minx3 = run.xmin[1], run.xmin[2]
+    for r in range(r2):
+        minx2 += float(nx2[r]) * dx[1]
+    for r in range(r3):
+        minx3 += float(nx3[r]) * dx[2]
+    per2 = (run.bc[2] == 4 and run.bc[3] == 4)
+    per3 = (run.bc[4] == 4 and run.bc[5] == 4)
+
+    def nb(r, p, per):
+        lo = r - 1 if r > 0 else (p - 1 if (per and p > 1) else -1)
+        hi = r + 1 if r < p - 1 else (0 if (per and p > 1) else -1)
+        return lo, hi
+
+    l2, h2 = nb(r2, p2, per2)
+    l3, h3 = nb(r3, p3, per3)
+    bc = list(run.bc)
+    for side, n in ((2, l2), (3, h2), (4, l3), (5, h3)):
+        if n >= 0:
+            bc[side] = 0
+    return GridConfig(run=run, rank=rank, nranks=p2 * p3,
+                      Nx=(run.rootNx[0], nx2[r2], nx3[r3]),
+                      disp=(0, sum(nx2[:r2]), sum(nx3[:r3])), MinX=(run.xmin[0], minx2, minx3), bc=tuple(bc),
+                      lx3=(l3 * p2 + r2) if l3 >= 0 else -1, rx3=(h3 * p2 + r2) if h3 >= 0 else -1,
+                      lx2=(r3 * p2 + l2) if l2 >= 0 else -1, rx2=(r3 * p2 + h2) if h2 >= 0 else -1, p2=p2)
 
 
 def levels(par: ParTable, run: RunConfig) -> List[GridConfig]:

@@ -877,6 +877,29 @@ int aa_unpack_x3(aa_grid *g, int side, const double *buf)
   return 0;
 }
 
+// x2 halo of an x2 x x3 pencil decomposition (init_mesh.c:526-620 allows any NGrid_x2 x NGrid_x3; never x1: the rays):
+// bvals_mhd.c:2462-2560 pack_ix2 / pack_ox2, :2896-3000 unpack.  Order of a bvals_mhd call with pencils: x1 sides
+// (aa_bvals_mhd_side), then the x2 exchange / the physical x2 sides, then x3 -- so that the corners travel (:170).
+long long aa_halo_doubles_x2(const aa_grid *g)
+{ return g->slab.empty() ? (long long)g->d.N1*AA_NGHOST*(g->d.ke - g->d.ks + 1)*(5 + g->p.nscal) : 0LL; }
+int aa_pack_x2(aa_grid *g, int side, double *buf)
+{
+  NO_SLABS("aa_pack_x2");
+  Scope s(g, "halo_pack");
+  const int j0 = side == 0 ? g->d.js : g->d.je - AA_NGHOST + 1;    // pack_ix2 / pack_ox2
+  launch_pack_x2(g->d, 5 + g->p.nscal, j0, buf, g->st);
+  return 0;
+}
+int aa_unpack_x2(aa_grid *g, int side, const double *buf)
+{
+  NO_SLABS("aa_unpack_x2");
+  g->inner_swept = false; g->cfl_ready = false;
+  Scope s(g, "halo_unpack");
+  const int j0 = side == 0 ? g->d.js - AA_NGHOST : g->d.je + 1;    // unpack_ix2 / unpack_ox2
+  launch_unpack_x2(g->d, 5 + g->p.nscal, j0, buf, g->st);
+  return 0;
+}
+
 // ---- function-level tests -------------------------------------------------------------------
 int aa_test_fluxes(int nscal, double gamma, int n, const double *Ul, const double *Ur, const double *etah, double *F)
 {

@@ -121,6 +121,8 @@ void launch_pinned(const DevGrid &g, int nvar, long long n, const long long *idx
                    hipStream_t st);
 void launch_pack_x3(const DevGrid &g, int nvar, int k0, Real *buf, hipStream_t st);
 void launch_unpack_x3(const DevGrid &g, int nvar, int k0, const Real *buf, hipStream_t st);
+void launch_pack_x2(const DevGrid &g, int nvar, int j0, Real *buf, hipStream_t st);      // pencils: the x2 halo (bvals_mhd.c:2462)
+void launch_unpack_x2(const DevGrid &g, int nvar, int j0, const Real *buf, hipStream_t st);
 void launch_test_fluxes(int nscal, Real gamma, int n, const Real *Ul, const Real *Ur, const Real *eta,
                         Real *F, hipStream_t st);
 void launch_test_lr(int nscal, Real gamma, int n, const Real *W, Real dt, Real dx, int il, int iu,

@@ -1494,6 +1494,26 @@ __global__ void k_pack_x3(DevGrid g, int nvar, int k0, Real *buf)
   const long m = (long)(k0 + kk)*g.sK + (long)j*g.sJ + i;
   for (int v = 0; v < nvar; v++) buf[(long)v*ntot + lin] = Uf(g, v)[m];
 }
+// bvals_mhd.c:2462 pack_ix2 / pack_ox2 and :2896 unpack_ix2 / unpack_ox2: four rows j0 .. j0+3, all i incl. the x1 ghost
+// zones (x1 comes first, so the x1-x2 corners travel), the active k-planes only (x3 comes after)
+__global__ void k_pack_x2(DevGrid g, int nvar, int j0, Real *buf)
+{
+  const long nk = g.ke - g.ks + 1, ntot = (long)g.N1*AA_NGHOST_*nk;
+  const long lin = (long)blockIdx.x*blockDim.x + threadIdx.x;
+  if (lin >= ntot) return;
+  const int i = (int)(lin % g.N1), jj = (int)((lin / g.N1) % AA_NGHOST_), kk = (int)(lin / ((long)g.N1*AA_NGHOST_));
+  const long m = (long)(g.ks + kk)*g.sK + (long)(j0 + jj)*g.sJ + i;
+  for (int v = 0; v < nvar; v++) buf[(long)v*ntot + lin] = Uf(g, v)[m];
+}
+__global__ void k_unpack_x2(DevGrid g, int nvar, int j0, const Real *buf)
+{
+  const long nk = g.ke - g.ks + 1, ntot = (long)g.N1*AA_NGHOST_*nk;
+  const long lin = (long)blockIdx.x*blockDim.x + threadIdx.x;
+  if (lin >= ntot) return;
+  const int i = (int)(lin % g.N1), jj = (int)((lin / g.N1) % AA_NGHOST_), kk = (int)(lin / ((long)g.N1*AA_NGHOST_));
+  const long m = (long)(g.ks + kk)*g.sK + (long)(j0 + jj)*g.sJ + i;
+  for (int v = 0; v < nvar; v++) Uf(g, v)[m] = buf[(long)v*ntot + lin];
+}
 __global__ void k_unpack_x3(DevGrid g, int nvar, int k0, const Real *buf)
 {
   const long plane = (long)g.N1*g.N2, ntot = plane*AA_NGHOST_;
@@ -1800,6 +1820,10 @@ void launch_pack_x3(const DevGrid &g, int nvar, int k0, Real *buf, hipStream_t s
 { const long n = (long)g.N1*g.N2*4; hipLaunchKernelGGL(k_pack_x3, dim3(nblk(n, 256)), dim3(256), 0, st, g, nvar, k0, buf); }
 void launch_unpack_x3(const DevGrid &g, int nvar, int k0, const Real *buf, hipStream_t st)
 { const long n = (long)g.N1*g.N2*4; hipLaunchKernelGGL(k_unpack_x3, dim3(nblk(n, 256)), dim3(256), 0, st, g, nvar, k0, buf); }
+void launch_pack_x2(const DevGrid &g, int nvar, int j0, Real *buf, hipStream_t st)
+{ const long n = (long)g.N1*4*(g.ke - g.ks + 1); hipLaunchKernelGGL(k_pack_x2, dim3(nblk(n, 256)), dim3(256), 0, st, g, nvar, j0, buf); }
+void launch_unpack_x2(const DevGrid &g, int nvar, int j0, const Real *buf, hipStream_t st)
+{ const long n = (long)g.N1*4*(g.ke - g.ks + 1); hipLaunchKernelGGL(k_unpack_x2, dim3(nblk(n, 256)), dim3(256), 0, st, g, nvar, j0, buf); }
 
 void launch_test_fluxes(int nscal, Real gamma, int n, const Real *Ul, const Real *Ur, const Real *eta, Real *F, hipStream_t st)
 {

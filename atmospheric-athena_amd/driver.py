@@ -26,7 +26,7 @@ from typing import List, Optional
 
 import numpy as np
 
-from .config import GridConfig, RunConfig, slab
+from .config import pencil, GridConfig, RunConfig, slab
 
 MAXCELLCOUNT = 20   # ionrad.h:38
 
@@ -60,6 +60,9 @@ class HipEngine:
         self.words_all = torch.zeros(lib.ION_WORDS * max(1, grid.nranks), dtype=torch.float64, device=dev)
         self.send = [torch.empty(n, dtype=torch.float64, device=dev) for _ in range(2)]
         self.recv = [torch.empty(n, dtype=torch.float64, device=dev) for _ in range(2)]
+        n2 = self.g.halo_doubles_x2() if (nslab == 1 and grid.p2 > 1) else 0      # x2 x x3 pencils: the x2 halo as well
+        self.send2 = [torch.empty(n2, dtype=torch.float64, device=dev) for _ in range(2)]
+        self.recv2 = [torch.empty(n2, dtype=torch.float64, device=dev) for _ in range(2)]
         self.scalar_device = dev
 
     # slab arithmetic
@@ -103,6 +106,13 @@ class HipEngine:
 
     def recv_buffer(self, side: int): return self.recv[side]
     def unpack_x3(self, side: int): self.g.unpack_x3(side, self.recv[side].data_ptr())
+
+    def pack_x2(self, side: int):
+        self.g.pack_x2(side, self.send2[side].data_ptr()); return self.send2[side]
+
+    def recv_buffer_x2(self, side: int): return self.recv2[side]
+    def unpack_x2(self, side: int): self.g.unpack_x2(side, self.recv2[side].data_ptr())
+    def bvals_side(self, dir: int, side: int): self.g.bvals_mhd_side(dir, side)
     def sync(self): self.g.sync()
     def download(self) -> np.ndarray: return self.g.download()
     def history(self) -> np.ndarray: return self.g.history()
@@ -113,14 +123,17 @@ class Driver:
     """main() of the reference for one process of an N-process run."""
 
     def __init__(self, run: RunConfig, engine_factory=None, rank: int = 0, nranks: int = 1, device: int = 0,
-                 strict: Optional[bool] = None):
+                 strict: Optional[bool] = None, p2: int = 1):
+        """p2 > 1: an NGrid_x2 x NGrid_x3 = p2 x (nranks / p2) pencil decomposition (init_mesh.c:526-620) instead of x3 slabs"""
         self.run = run
         self.rank, self.nranks = rank, nranks
-        self.grid = slab(run, rank, nranks)
+        if p2 < 1 or nranks % p2:
+            raise ValueError(f"{nranks} ranks cannot be dealt {p2} along x2")
+        self.grid = pencil(run, rank, p2, nranks // p2)
         self.eng = engine_factory(self.grid) if engine_factory else HipEngine(self.grid, device, strict)
         self.time, self.dt, self.nstep = 0.0, 0.0, 0
         self.niter_trace: List[int] = []
-        self._halo = None         # x3 messages in flight (post_x3 .. finish_x3)
+        self._halo = {}           # messages in flight per axis (2: x2, 3: x3): post .. finish
         self._py_syncs = 0        # host round trips of collectives issued from here (bench: host_syncs_per_step)
         # AA_FORCE_DISTRIBUTED=1 runs the Python-orchestrated loop (with its collectives) even on one
         # rank: used to rehearse the N>1 code path on a single GPU
@@ -172,63 +185,87 @@ class Driver:
         self.post_x3()
         self.finish_x3()
 
-    def post_x3(self):
-        """The sends and receives of bvals_mhd.c:423-493 (pack_ix3 / pack_ox3, MPI_Isend / MPI_Irecv) without the wait.
-        With RCCL the messages travel on the communicator's stream from here on; finish_x3() makes the kernel stream
-        wait for them and unpacks.  What is queued in between must not touch the x3 ghost planes or the buffers."""
-        assert self._halo is None
-        if not self.distributed or (self.grid.lx3 < 0 and self.grid.rx3 < 0):
+    def post_x3(self): self._post(3)
+    def finish_x3(self): self._finish(3)
+
+    def _post(self, axis: int):
+        """The sends and receives of bvals_mhd.c:296-493 along one direction (pack_i* / pack_o*, MPI_Isend / MPI_Irecv)
+        without the wait; axis 2 = x2 (pencils only), 3 = x3.  With RCCL the messages travel on the communicator's stream
+        from here on; _finish() makes the kernel stream wait for them and unpacks.  What is queued in between must not
+        touch the ghost zones of that direction or the buffers."""
+        assert axis not in self._halo
+        g, dist = self.grid, self.dist if self.distributed else None
+        lo, hi = (g.lx2, g.rx2) if axis == 2 else (g.lx3, g.rx3)
+        if not self.distributed or (lo < 0 and hi < 0):
             return
-        g, dist = self.grid, self.dist
+        e = self.eng
+        pack = e.pack_x2 if axis == 2 else e.pack_x3
+        recvb = e.recv_buffer_x2 if axis == 2 else e.recv_buffer
         host_stage = (dist.get_backend() == "gloo")   # gloo moves host tensors only
 
         def out(side):
-            t = self.eng.pack_x3(side)
+            t = pack(side)
             return t.cpu() if (host_stage and t.is_cuda) else t
 
         rbuf = {}
 
         def inn(side):
-            t = self.eng.recv_buffer(side)
+            t = recvb(side)
             rbuf[side] = (self.torch.empty(t.shape, dtype=t.dtype) if (host_stage and t.is_cuda) else t)
             return rbuf[side]
 
-        if g.lx3 == g.rx3 and g.lx3 >= 0:
-            # two slabs with periodic wrap: both messages go to the same peer; post them so that the
+        tag0 = 10 * axis
+        if lo == hi and lo >= 0:
+            # two Grids along this direction with periodic wrap: both messages go to the same peer; post them so that the
             # peer's inner planes (its first send) land in my OUTER ghosts (my first receive)
-            ops = [dist.P2POp(dist.isend, out(0), g.lx3, tag=0),
-                   dist.P2POp(dist.isend, out(1), g.rx3, tag=1),
-                   dist.P2POp(dist.irecv, inn(1), g.rx3, tag=0),
-                   dist.P2POp(dist.irecv, inn(0), g.lx3, tag=1)]
+            ops = [dist.P2POp(dist.isend, out(0), lo, tag=tag0),
+                   dist.P2POp(dist.isend, out(1), hi, tag=tag0 + 1),
+                   dist.P2POp(dist.irecv, inn(1), hi, tag=tag0),
+                   dist.P2POp(dist.irecv, inn(0), lo, tag=tag0 + 1)]
         else:
             ops = []
             # my inner planes fill the lower neighbour's outer ghosts, and vice versa
-            if g.lx3 >= 0:
-                ops.append(dist.P2POp(dist.isend, out(0), g.lx3, tag=0))
-                ops.append(dist.P2POp(dist.irecv, inn(0), g.lx3, tag=1))
-            if g.rx3 >= 0:
-                ops.append(dist.P2POp(dist.isend, out(1), g.rx3, tag=1))
-                ops.append(dist.P2POp(dist.irecv, inn(1), g.rx3, tag=0))
-        self._halo = (dist.batch_isend_irecv(ops), rbuf)
+            if lo >= 0:
+                ops.append(dist.P2POp(dist.isend, out(0), lo, tag=tag0))
+                ops.append(dist.P2POp(dist.irecv, inn(0), lo, tag=tag0 + 1))
+            if hi >= 0:
+                ops.append(dist.P2POp(dist.isend, out(1), hi, tag=tag0 + 1))
+                ops.append(dist.P2POp(dist.irecv, inn(1), hi, tag=tag0))
+        self._halo[axis] = (dist.batch_isend_irecv(ops), rbuf)
 
-    def finish_x3(self):
-        """MPI_Waitall + unpack_ix3 / unpack_ox3 of bvals_mhd.c:423-493."""
-        if self._halo is None:
+    def _finish(self, axis: int):
+        """MPI_Waitall + unpack_i* / unpack_o* of bvals_mhd.c:296-493."""
+        if axis not in self._halo:
             return
-        works, rbuf = self._halo
-        self._halo = None
+        works, rbuf = self._halo.pop(axis)
+        e = self.eng
+        recvb = e.recv_buffer_x2 if axis == 2 else e.recv_buffer
+        unpack = e.unpack_x2 if axis == 2 else e.unpack_x3
         for w in works:
             w.wait()
         for side in (0, 1):
             if side in rbuf:
-                dst = self.eng.recv_buffer(side)
+                dst = recvb(side)
                 if rbuf[side] is not dst:
                     dst.copy_(rbuf[side])
-                self.eng.unpack_x3(side)
+                unpack(side)
 
     # ---- the reference's call sites ---------------------------------------------------------
     def bvals_mhd(self, exchange: bool = True, wait: bool = True):
-        self.eng.bvals_local()      # x1, x2 and physical x3 faces
+        if self.grid.p2 == 1:
+            self.eng.bvals_local()      # x1, x2 and physical x3 faces
+        else:
+            # pencils: x1, then x2 (physical sides here, cut faces by messages), then x3 -- the order that carries the
+            # corners (bvals_mhd.c:170); the x2 messages must have landed before x3 is packed
+            for side in (0, 1):
+                self.eng.bvals_side(0, side)
+            for side in (0, 1):
+                self.eng.bvals_side(1, side)
+            if exchange:
+                self._post(2)
+                self._finish(2)
+            for side in (0, 1):
+                self.eng.bvals_side(2, side)
         if exchange:
             self.post_x3()
             if wait:

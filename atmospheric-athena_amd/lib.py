@@ -100,6 +100,7 @@ def load(strict: bool | None = None) -> C.CDLL:
         "aa_ion_is_fused": (I, [P]), "aa_ion_speculate": (I, [P, D]), "aa_ion_pass": (I, [P, I, I, P]), "aa_ion_pick": (I, [P, P, I, I, D]),
         "aa_ion_fetch": (I, [P, dp, ip, dp, dp, llp, dp, ip]), "aa_ion_finish": (I, [P]), "aa_host_syncs": (I, [P, I]),
         "aa_halo_doubles": (LL, [P]), "aa_pack_x3": (I, [P, I, P]), "aa_unpack_x3": (I, [P, I, P]),
+        "aa_halo_doubles_x2": (LL, [P]), "aa_pack_x2": (I, [P, I, P]), "aa_unpack_x2": (I, [P, I, P]),
         "aa_mesh_create": (I, [I, C.POINTER(P), ip, C.POINTER(P)]), "aa_mesh_destroy": (None, [P]),
         "aa_mesh_get_state": (I, [P, dp, dp, ip]), "aa_mesh_set_state": (I, [P, D, D, I]),
         "aa_mesh_set_stream": (I, [P, P]), "aa_mesh_restrict_correct_pair": (I, [P, I]),
@@ -320,6 +321,10 @@ class Grid:
     def halo_doubles(self) -> int: return int(self.L.aa_halo_doubles(self._h))
     def pack_x3(self, side: int, dev_ptr: int): self._chk(self.L.aa_pack_x3(self._h, side, C.c_void_p(dev_ptr)))
     def unpack_x3(self, side: int, dev_ptr: int): self._chk(self.L.aa_unpack_x3(self._h, side, C.c_void_p(dev_ptr)))
+    def halo_doubles_x2(self) -> int: return int(self.L.aa_halo_doubles_x2(self._h))
+    def pack_x2(self, side: int, dev_ptr: int): self._chk(self.L.aa_pack_x2(self._h, side, C.c_void_p(dev_ptr)))
+    def unpack_x2(self, side: int, dev_ptr: int): self._chk(self.L.aa_unpack_x2(self._h, side, C.c_void_p(dev_ptr)))
+    def bvals_mhd_side(self, dir: int, side: int): self._chk(self.L.aa_bvals_mhd_side(self._h, dir, side))
 
     def history(self) -> np.ndarray:
         """Volume integrals of this Grid in .hst column order (dump_history.c:157-200)."""

@@ -356,13 +356,20 @@ def run_window(c, strong, spinup, steps, warmup, nslab=1):
     synchronize pairs, MAX over ranks.  Returns the raw measurements (rank 0 builds the JSON from them)."""
     a, aa, torch = c.a, c.aa, c.torch
     nx, world = a.nx, c.world
-    nx3 = nx if strong else nx * world
+    p2 = a.p2 if nslab == 1 else 1                       # Grids along x2 (pencils); the rest of the ranks along x3
+    if world % p2:
+        sys.exit(f"--p2 {p2} does not divide {world} ranks")
+    nx2 = nx if strong else nx * p2
+    nx3 = nx if strong else nx * (world // p2)
     deck = os.path.join(ROOT, PKG, "decks", "athinput." + a.problem)
     par = aa.athinput.ParTable.from_file(deck)
+    x2min, x2max = par.getd("domain1", "x2min"), par.getd("domain1", "x2max")
     x3min, x3max = par.getd("domain1", "x3min"), par.getd("domain1", "x3max")
-    ov = [f"domain1/Nx1={nx}", f"domain1/Nx2={nx}", f"domain1/Nx3={nx3}"]
-    if not strong:      # weak scaling: the box grows along x3 with the same dx
-        ov.append(f"domain1/x3max={x3min + (x3max - x3min) * world!r}")
+    ov = [f"domain1/Nx1={nx}", f"domain1/Nx2={nx2}", f"domain1/Nx3={nx3}"]
+    if not strong:      # weak scaling: the box grows along the cut directions with the same dx
+        ov.append(f"domain1/x3max={x3min + (x3max - x3min) * (world // p2)!r}")
+        if p2 > 1:
+            ov.append(f"domain1/x2max={x2min + (x2max - x2min) * p2!r}")
     par.cmdline(ov)
     run = aa.config.from_par(par, a.problem)
     run.integrator = a.integrator
@@ -372,7 +379,7 @@ def run_window(c, strong, spinup, steps, warmup, nslab=1):
         fac = lambda grid: c.driver.HipEngine(grid, c.local, True if a.strict else None, nslab=nslab)
         drv = c.driver.Driver(run, fac, 0, 1, c.local)
     else:
-        drv = c.driver.Driver(run, None, c.rank, world, c.local, strict=True if a.strict else None)
+        drv = c.driver.Driver(run, None, c.rank, world, c.local, strict=True if a.strict else None, p2=p2)
     if a.ionized_slab:
         if not run.ion:
             sys.exit("--ionized-slab needs a problem with ion radiation")
@@ -413,8 +420,8 @@ def run_window(c, strong, spinup, steps, warmup, nslab=1):
     hist1 = drv.history()      # volume integrals (dump_history.c): a NaN or Inf anywhere in the state shows up here
     w = {"run": run, "nx": nx, "nx3": nx3, "strong": strong, "elapsed": elapsed, "steps": steps, "warmup": warmup, "prof": prof,
          "nsync": nsync, "hist0": hist0, "hist1": hist1, "spin_log": spin_log, "t_spin": t_spin, "t_setup": t_setup,
-         "niter": list(drv.niter_trace), "dt": drv.dt, "time": drv.time, "hbm": eng.g.device_bytes(), "spinup": spinup,
-         "zones": nx * nx * nx3, "zones_gpu": (nx * nx * nx3) // (world * nslab) if (strong or nslab > 1) else nx ** 3, "nslab": nslab}
+         "niter": list(drv.niter_trace), "dt": drv.dt, "time": drv.time, "hbm": eng.g.device_bytes(), "spinup": spinup, "nx2": nx2, "p2": p2,
+         "zones": nx * nx2 * nx3, "zones_gpu": (nx * nx2 * nx3) // (world * nslab) if (strong or nslab > 1) else nx ** 3, "nslab": nslab}
     eng.close()
     return w
 
@@ -425,7 +432,7 @@ def chain_traffic(a, w, world, names):
     try:
         tf = {"auto": "r03_traffic.json", "burst": "r03_burst_traffic.json", "19": "r03_burst_traffic.json"}.get(w["spinup"])
         tj = json.load(open(os.path.join(ROOT, "profiles", tf)))
-        if tj.get("workload", "").startswith(f"{a.problem} {w['nx']}x{w['nx']}x{w['nx3']}") and a.integrator == "ctu" and a.order == 2 \
+        if tj.get("workload", "").startswith(f"{a.problem} {w['nx']}x{w['nx2']}x{w['nx3']}") and a.integrator == "ctu" and a.order == 2 \
                 and world == 1 and w["nslab"] == 1 and not a.ionized_slab and not a.strict:
             return {k: tj["kernels"].get(k) for k in names}
     except Exception:
@@ -452,7 +459,7 @@ def analyse(c, w):
         "higher_is_better": True, "scaling": "strong" if w["strong"] else "weak", "vs_baseline": None, "dtype": "f64",
         "data": "synthetic (deck values on a uniform grid, generated in place"
                 + ("; neutral fraction reset to 1e-4 everywhere: fully ionized slab" if a.ionized_slab else "") + ")",
-        "config": {"workload": f"{a.problem} {nx}x{nx}x{nx3} single level, "
+        "config": {"workload": f"{a.problem} {nx}x{w['nx2']}x{nx3} single level, "
                                + ((f"CTU+{'PPM' if a.order == 3 else 'PLM'}+Roe+H-correction") if a.integrator == "ctu" else "VL+PLM+Roe")
                                + (" + static gravity + plane-parallel ion radiation" if a.problem == "ioniz_sphere"
                                   else (" + plane-parallel ion radiation" if a.problem == "ifront" else ""))
@@ -460,7 +467,8 @@ def analyse(c, w):
                    "build": "libathena_amd_strict.so (-ffp-contract=off)" if a.strict else "libathena_amd.so",
                    "zones_per_gpu": zones_gpu,
                    "partition": (f"x3 slabs x{w['nslab']} inside the library (one process, aa_params.nslab)" if w["nslab"] > 1 else
-                                 f"x3 slabs x{world}" + (" of one box (strong scaling)" if w["strong"] else "")),
+                                 (f"x2 x x3 pencils {w['p2']}x{world // w['p2']}" if w["p2"] > 1 else f"x3 slabs x{world}")
+                                 + (" of one box (strong scaling)" if w["strong"] else "")),
                    "nvar": nvar, "spinup_steps": len(w["spin_log"]), "spinup_subcycle_trace": w["spin_log"], "spinup_s": w["t_spin"],
                    "radiation_subcycles_per_step": nsub, "subcycle_trace": niter,
                    "final_dt": w["dt"], "final_time": w["time"], "hbm_resident_GB": w["hbm"] / 1e9, "setup_s": w["t_setup"]},
@@ -573,6 +581,8 @@ def main():
                     help="N>1: weak (nx^3 per GPU, the box grows along x3), strong (ONE nx^3 box cut into N x3 slabs: BASELINE "
                          "configs[3]) or both (default for N>1: the weak line with the strong window under `strong_scaling`)")
     ap.add_argument("--strong", action="store_true", help="same as --scaling strong")
+    ap.add_argument("--p2", type=int, default=1, metavar="P2",
+                    help="N>1: P2 Grids along x2 and N/P2 along x3 (x2 x x3 pencils, init_mesh.c:526-620) instead of x3 slabs")
     ap.add_argument("--inlib", type=int, default=0, metavar="N",
                     help="ONE process, the library cuts the Grid into N x3 slabs itself (aa_params.nslab; AA_SLAB_DEVICES picks the "
                          "devices): the multi-GPU path of the drop-in executables, strong scaling, no launcher involved")

@@ -156,6 +156,12 @@ int aa_host_syncs(aa_grid *g, int reset);   /* stream synchronisations that retu
 long long aa_halo_doubles(const aa_grid *g);
 int aa_pack_x3(aa_grid *g, int side, double *dev_buf);
 int aa_unpack_x3(aa_grid *g, int side, const double *dev_buf);
+/* x2 x x3 pencils (init_mesh.c:526-620 NGrid_x2 x NGrid_x3; x1 is never cut: the rays): the x2 halo, four rows x all i incl.
+ * the x1 ghost zones x the ACTIVE k-planes (bvals_mhd.c:2462 pack_ix2 / pack_ox2, :2896 unpack_ix2 / unpack_ox2).  A bvals_mhd
+ * call of such a driver: aa_bvals_mhd_side for x1; this exchange and aa_bvals_mhd_side for the physical x2 sides; then x3. */
+long long aa_halo_doubles_x2(const aa_grid *g);
+int aa_pack_x2(aa_grid *g, int side, double *dev_buf);
+int aa_unpack_x2(aa_grid *g, int side, const double *dev_buf);
 
 /* ---- static mesh refinement (reference built with --enable-smr): nested levels, one Domain per
  *      level, all resident on one GPU.  levels[l] was created with aa_params.level = l, Nx = the

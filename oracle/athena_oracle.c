@@ -860,6 +860,12 @@ void orc_bvals(OrcSim *s)
   }
 }
 
+/* one (*BCFun)(pGrid) call of bvals_mhd.c:196-420: for drivers that put an exchange between the directions (pencils) */
+void orc_bvals_side(OrcSim *s, int d, int side)
+{
+  if (s->p.Nx[d] > 1 && s->p.bc[2*d + side]) bc_fill(s, d, side, s->p.bc[2*d + side]);
+}
+
 /* bvals_ionrad.c:63 + outflow_flux_ix1 :308 (dir=-1), outflow_flux_ix2 :357 (dir=-2); bvals_ionrad_init :176-232
  * enrols the function of the lit face only */
 void orc_bvals_ionrad(OrcSim *s)

@@ -68,6 +68,7 @@ void orc_add_radplane(OrcSim *s, int dir, double flux);
 /* main.c steps */
 void   orc_start(OrcSim *s);            /* bvals + bvals_ionrad + first new_dt (main.c:412-451) */
 void   orc_bvals(OrcSim *s);            /* bvals_mhd.c:174                                      */
+void   orc_bvals_side(OrcSim *s, int d, int side);   /* one side of it (bvals_mhd.c:196-420)          */
 void   orc_bvals_ionrad(OrcSim *s);     /* bvals_ionrad.c:63                                    */
 double orc_new_dt_local(OrcSim *s);     /* new_dt.c:72-170: returns CourNo/max_dti of this grid */
 void   orc_new_dt(OrcSim *s);           /* new_dt.c:32                                          */

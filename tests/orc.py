@@ -67,6 +67,7 @@ def lib():
         for f in ("orc_start", "orc_bvals", "orc_bvals_ionrad", "orc_new_dt", "orc_integrate",
                   "orc_userwork", "orc_ion_begin"):
             getattr(L, f).argtypes = [P]; getattr(L, f).restype = None
+        L.orc_bvals_side.argtypes = [P, C.c_int, C.c_int]; L.orc_bvals_side.restype = None
         L.orc_ion_radtransfer.restype = C.c_int; L.orc_ion_radtransfer.argtypes = [P]
         L.orc_step.restype = C.c_int; L.orc_step.argtypes = [P]
         L.orc_ion_rates.argtypes = [P, dp, dp]
@@ -176,6 +177,7 @@ class Sim:
     def start(self): self.L.orc_start(self.h); return self
     def step(self): return self.L.orc_step(self.h)
     def bvals(self): self.L.orc_bvals(self.h)
+    def bvals_side(self, d, side): self.L.orc_bvals_side(self.h, int(d), int(side))
     def bvals_ionrad(self): self.L.orc_bvals_ionrad(self.h)
     def new_dt(self): self.L.orc_new_dt(self.h)
     def new_dt_local(self): return self.L.orc_new_dt_local(self.h)

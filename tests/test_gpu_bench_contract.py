@@ -151,3 +151,16 @@ def test_one_rank_over_rccl():
     assert d["config"]["subcycle_trace"] == one["config"]["subcycle_trace"] and d["config"]["final_dt"] == one["config"]["final_dt"]
     assert d["state_check"]["mass_after"] == one["state_check"]["mass_after"]
     assert d["host_syncs_per_subcycle"] <= 1.0 + 1e-9
+
+
+def test_two_ranks_as_pencils():
+    """bench.py --gpus 2 --p2 2: the two ranks cut x2 instead of x3 (x2 x x3 pencils 2x1), rehearsed on the one GPU over gloo."""
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    d = run_bench("--gpus", "2", "--p2", "2", "--nx", "64", "--steps", "2", "--warmup", "1", "--spinup", "2", "--scaling", "strong",
+                  env={"AA_BENCH_REHEARSAL": "1"},
+                  launcher=("-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                            "--master-port", str(port)))
+    one = run_bench("--nx", "64", "--steps", "2", "--warmup", "1", "--spinup", "2", "--no-cpu-baseline")
+    assert d["n_gpus"] == 2 and "pencils 2x1" in d["config"]["partition"] and d["state_check"]["ok"] is True
+    assert d["config"]["subcycle_trace"] == one["config"]["subcycle_trace"]
+    assert abs(d["state_check"]["mass_after"] / one["state_check"]["mass_after"] - 1) < 1e-9

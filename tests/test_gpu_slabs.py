@@ -16,17 +16,20 @@ sys.path.insert(0, HERE)
 sys.path.insert(0, os.path.dirname(HERE))
 
 
-def _worker(rank, world, port, problem, overrides, nsteps, q):
+def _worker(rank, world, port, problem, overrides, nsteps, q, p2=1, strict=False):
     import torch.distributed as dist
     dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
     aa = importlib.import_module("atmospheric-athena_amd")
     driver = importlib.import_module("atmospheric-athena_amd.driver")
     run = aa.config.load(os.path.join(os.path.dirname(HERE), "atmospheric-athena_amd", "decks", "athinput." + problem),
                          overrides, problem)
-    d = driver.Driver(run, None, rank, world, device=0, strict=False)
+    d = driver.Driver(run, None, rank, world, device=0, strict=strict, p2=p2)
     d.start()
     its = [d.step() for _ in range(nsteps)]
-    q.put((rank, d.grid.disp[2], d.grid.Nx[2], d.eng.download()[4:-4, 4:-4, 4:-4].copy(), its, d.time, d.dt))
+    if p2 > 1:
+        q.put((rank, d.grid.disp, d.grid.Nx, d.eng.download()[4:-4, 4:-4, 4:-4].copy(), its, d.time, d.dt))
+    else:
+        q.put((rank, d.grid.disp[2], d.grid.Nx[2], d.eng.download()[4:-4, 4:-4, 4:-4].copy(), its, d.time, d.dt))
     d.eng.close()
     dist.barrier()
     dist.destroy_process_group()
@@ -74,4 +77,41 @@ def test_two_slabs_equal_one(problem, nx, nsteps, correct_all, monkeypatch):
             assert (np.nanmax(np.abs(U - U1[disp:disp + n3]), axis=(0, 1, 2)) / scale).max() < 1e-9
         else:
             assert np.array_equal(U, U1[disp:disp + n3]), f"slab {rank}"
+    one.eng.close()
+
+
+@pytest.mark.parametrize("problem,nx,nsteps,p2,p3", [("blast", (24, 16, 16), 3, 2, 2),          # periodic in x2 and x3: corners by messages
+                                                      ("ifront", (64, 12, 12), 3, 2, 2),         # the one-kernel sub-cycle over four pencils
+                                                      ("blast", (24, 24, 8), 2, 3, 1)])
+def test_pencils_equal_one_grid(problem, nx, nsteps, p2, p3):
+    """x2 x x3 pencils with the HIP engine (every rank on cuda:0, messages staged through the host by gloo): k_pack_x2 /
+    k_unpack_x2, the x1 -> x2 -> x3 order of a bvals_mhd call with an exchange between the directions, the reductions.
+    Strict build: every pencil equals its part of the one-Grid run bit for bit."""
+    import torch.multiprocessing as mp
+    aa = importlib.import_module("atmospheric-athena_amd")
+    driver = importlib.import_module("atmospheric-athena_amd.driver")
+    ov = [f"domain1/Nx{d + 1}={nx[d]}" for d in range(3)]
+    run = aa.config.load(os.path.join(os.path.dirname(HERE), "atmospheric-athena_amd", "decks", "athinput." + problem), ov, problem)
+    one = driver.Driver(run, None, 0, 1, device=0, strict=True)
+    one.start()
+    its1 = [one.step() for _ in range(nsteps)]
+    U1 = one.eng.download()[4:-4, 4:-4, 4:-4]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    world = p2 * p3
+    ps = [ctx.Process(target=_worker, args=(r, world, port, problem, ov, nsteps, q, p2, True)) for r in range(world)]
+    for p in ps:
+        p.start()
+    res = sorted(q.get(timeout=300) for _ in range(world))
+    for p in ps:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    seen = np.zeros(U1.shape[:3], dtype=bool)
+    for rank, disp, n, U, its, t, dt in res:
+        assert its == its1 and t == one.time and dt == one.dt
+        sl = (slice(disp[2], disp[2] + n[2]), slice(disp[1], disp[1] + n[1]), slice(None))
+        seen[sl] = True
+        assert np.array_equal(U, U1[sl], equal_nan=True), f"pencil {rank}"
+    assert seen.all()
     one.eng.close()
