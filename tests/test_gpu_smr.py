@@ -96,7 +96,18 @@ def test_sphere_two_levels_vs_reference(aa, lib, strict):
         niter = []
         for _ in range(int(g["nstep"])):
             niter += m.step()
-        assert niter == [int(x) for x in g["niter"]], "radiation sub-cycle counts on both levels"
+        if niter != [int(x) for x in g["niter"]]:
+            # seen ONCE in eleven full-suite runs of round 3 and never in isolation: say what a second Mesh in the same
+            # process does, so that the next occurrence tells a persistent state from a transient one
+            m2 = make_gpu_mesh(aa, lib, "ioniz_sphere", [str(o) for o in g["overrides"]], strict)
+            m2.start()
+            again = []
+            for _ in range(int(g["nstep"])):
+                again += m2.step()
+            same0 = [bool(np.array_equal(a.download(), b.download(), equal_nan=True)) for a, b in zip(m.lev, m2.lev)]
+            m2.close()
+            raise AssertionError(f"radiation sub-cycle counts on both levels: {niter} (a second Mesh in this process: {again}; "
+                                 f"final states equal: {same0}) against the reference's {[int(x) for x in g['niter']]}")
         assert abs(m.time / float(g["time"]) - 1) < 1e-9 and abs(m.dt / float(g["dt"]) - 1) < 1e-9
         for l, lev in enumerate(m.lev):
             U = lev.download()[4:-4, 4:-4, 4:-4, :]
