@@ -162,6 +162,44 @@ def test_bench_helpers():
     assert p2 * p3 <= 12 and 96 % p2 == 0 and 96 % p3 == 0
 
 
+def test_bench_line_from_a_window_without_a_gpu(aa):
+    """bench.analyse(): the JSON object of one measurement window, fed with made-up timings (no GPU): the contract's keys, the
+    roofline on SURVEY 8(d)'s unit (hydro chain on 96 B in a quiet window, radiation sub-cycle on 64 B in a burst window), the
+    dominant kernel's own figure beside it."""
+    import sys
+    import types
+    sys.path.insert(0, ROOT)
+    import bench
+    run = aa.config.load(os.path.join(ROOT, "atmospheric-athena_amd", "decks", "athinput.ioniz_sphere"),
+                         ["domain1/Nx1=512", "domain1/Nx2=512", "domain1/Nx3=512"], "ioniz_sphere")
+    a = types.SimpleNamespace(problem="ioniz_sphere", integrator="ctu", order=2, ionized_slab=False, strict=False)
+    c = types.SimpleNamespace(a=a, world=1, multi=False)
+    steps, z = 20, 512 ** 3
+
+    def window(prof, niter, ms, spinup):
+        return {"run": run, "nx": 512, "nx2": 512, "nx3": 512, "p2": 1, "strong": False, "elapsed": ms * 1e-3 * steps, "steps": steps, "warmup": 5,
+                "prof": prof, "nsync": 2 * steps, "hist0": [1.0, 2.0], "hist1": [1.0, 2.0], "spin_log": [4] * 10, "t_spin": 1.0, "t_setup": 1.0,
+                "niter": niter, "dt": 5.4, "time": 900.0, "hbm": 9e10, "spinup": spinup, "zones": z, "zones_gpu": z, "nslab": 1}
+
+    quiet = {"correct_all": (20.0 * steps, steps), "flux2_update": (14.0 * steps, steps), "sweep_x1": (5.0 * steps, steps),
+             "sweep_x2": (4.5 * steps, steps), "ion_pass_begin": (3.0 * steps, steps), "bvals_mhd": (0.5 * steps, 6 * steps)}
+    d = bench.analyse(c, window(quiet, [1] * steps, 48.0, "auto"))
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+              "data", "config", "roofline", "phases", "step_roofline", "state_check"):
+        assert k in d, k
+    assert abs(d["value"] - z / 48.0e-3) < 1e-3 and d["scaling"] == "weak" and d["dtype"] == "f64" and d["vs_baseline"] is None
+    r = d["roofline"]
+    assert r["kernel"] == "chain(correct_all+flux2_update+sweep_x1+sweep_x2)" and r["bytes_per_launch"] == 96 * z
+    assert abs(r["avg_launch_ms"] - 43.5) < 1e-9 and abs(r["frac"] - 96 * z / 43.5e-3 / 1e9 / 8000.0) < 1e-12
+    assert r["dominant_kernel"] == "correct_all" and r["kernel_own_bytes_per_zone"] == bench.CORRECT_ALL_X3_BYTES      # no sweep_x3 in the profile
+    assert d["step_roofline"]["bytes_per_cell_update"] == 160.0 and d["state_check"]["ok"] is True
+    burst = dict(quiet); burst["ion_pass"] = (2.65 * 47 * steps, 47 * steps)
+    b = bench.analyse(c, window(burst, [47] * steps, 175.0, "burst"))
+    rb = b["roofline"]
+    assert rb["kernel"] == "chain(ion_pass+ion_pass_begin)" and rb["bytes_per_launch"] == 64 * z and "64 B" in rb["bytes_basis"]
+    assert abs(b["phases"]["subcycle"]["full_pass_ms"] - 2.65) < 1e-9 and 0.39 < b["phases"]["subcycle"]["full_pass_frac_hbm"] < 0.42
+
+
 def test_boundary_docs_match_the_shim():
     """The shim's defaults and the C header are the contract a maintainer of the reference reads: INTEGRATION.md's table of
     environment knobs must state the default the code has, and list every value the code accepts."""
