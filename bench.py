@@ -618,6 +618,9 @@ def main():
         a.gpus = world
     if not torch.cuda.is_available():
         sys.exit("bench.py needs an MI355X: the hot path has no CPU fallback")
+    if not REHEARSAL and local >= torch.cuda.device_count():
+        sys.exit(f"bench.py: rank {rank} wants HIP device {local}, this node shows {torch.cuda.device_count()} "
+                 f"(one rank per GPU; AA_BENCH_REHEARSAL=1 puts every rank on cuda:0 over gloo -- a rehearsal, not a measurement)")
     torch.cuda.set_device(local)
     if a.smr:
         return bench_smr(a, aa, torch, rank, world, local)
