@@ -900,6 +900,32 @@ int aa_unpack_x2(aa_grid *g, int side, const double *buf)
   return 0;
 }
 
+// The same halos for a driver that moves them itself through HOST buffers (the reference's own MPI ranks on the shim,
+// bvals_mhd.c:296-493 with MPI_Isend / MPI_Irecv): dir 1 = x2, 2 = x3; get = pack_i* / pack_o* into host_buf, put = the
+// ghost planes from host_buf.  The packed block is staged in the face-state area (idle outside the integrator).
+long long aa_halo_doubles_dir(const aa_grid *g, int dir) { return dir == 1 ? aa_halo_doubles_x2(g) : (dir == 2 ? aa_halo_doubles(g) : 0LL); }
+int aa_halo_get(aa_grid *g, int dir, int side, double *host_buf)
+{
+  NO_SLABS("aa_halo_get");
+  if ((dir != 1 && dir != 2) || side < 0 || side > 1 || !host_buf) return fail(-1, "[aa_halo_get]: dir=%d side=%d", dir, side);
+  g->inner_swept = false;
+  int rc = dir == 1 ? aa_pack_x2(g, side, g->d.LR) : aa_pack_x3(g, side, g->d.LR); if (rc) return rc;
+  HIPCHK(hipMemcpyAsync(host_buf, g->d.LR, (size_t)aa_halo_doubles_dir(g, dir)*sizeof(Real), hipMemcpyDeviceToHost, g->st));
+  HIPCHK(hipStreamSynchronize(g->st));
+  return 0;
+}
+int aa_halo_put(aa_grid *g, int dir, int side, const double *host_buf)
+{
+  NO_SLABS("aa_halo_put");
+  if ((dir != 1 && dir != 2) || side < 0 || side > 1 || !host_buf) return fail(-1, "[aa_halo_put]: dir=%d side=%d", dir, side);
+  g->inner_swept = false; g->cfl_ready = false;
+  HIPCHK(hipMemcpyAsync(g->d.LR, host_buf, (size_t)aa_halo_doubles_dir(g, dir)*sizeof(Real), hipMemcpyHostToDevice, g->st));
+  int rc = dir == 1 ? aa_unpack_x2(g, side, g->d.LR) : aa_unpack_x3(g, side, g->d.LR); if (rc) return rc;
+  HIPCHK(hipStreamSynchronize(g->st));      // (host_buf and the staging area are the caller's again)
+  return 0;
+}
+int aa_device_count(void) { int n = 0; if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); n = 0; } return n; }
+
 // ---- function-level tests -------------------------------------------------------------------
 int aa_test_fluxes(int nscal, double gamma, int n, const double *Ul, const double *Ur, const double *etah, double *F)
 {

@@ -7,6 +7,13 @@
  * nested levels of static mesh refinement, where it also provides SMR_init, RestrictCorrect,
  * Prolongate and ionradRestrictCorrect (smr.c) on top of aa_mesh_*.
  *
+ * Compiled with -DAA_MPI against the reference's --enable-mpi build (single level), every MPI rank of the reference drives
+ * ONE GPU through this shim: the Domain is cut by the reference's own init_mesh (NGrid_x2 x NGrid_x3; NGrid_x1 must be 1:
+ * the rays), the ghost zones between neighbouring Grids travel as in bvals_mhd.c:296-493 -- pack on the device, MPI_Isend /
+ * MPI_Irecv of host buffers in pD->Comm_Domain, unpack on the device, x1 then x2 then x3 --, new_dt reduces with
+ * MPI_Allreduce(MIN) (new_dt.c:177) and the radiation sub-cycle with the reference's own two rounds of reductions
+ * (ionrad_3d.c:275,399,554,672).  HIP device of a rank: AA_DEVICE, else rank modulo the visible devices.
+ *
  * Host/device coherence (the reference's problem files and outputs index pG->U on the host):
  *   AA_COHERENCE=step  (default) the host block is refreshed after Integrate() (so that
  *                      Userwork_in_loop sees and may edit it; re-uploaded before new_dt) and
@@ -50,6 +57,16 @@ extern double par_getd_def(char *block, char *name, double def);
 extern int par_geti_def(char *block, char *name, int def);
 extern int par_exist(char *block, char *name);
 extern void ath_error(char *fmt, ...);
+#ifdef AA_MPI
+#ifdef AA_SMR
+#error "AA_MPI and AA_SMR together are not built: nested levels stay on one GPU"
+#endif
+extern int myID_Comm_world;                 /* globals.h:27 */
+static MPI_Comm comm_dom;                   /* pD->Comm_Domain of the root Domain */
+static int nb_id[4] = {-1, -1, -1, -1};     /* lx2, rx2, lx3, rx3 neighbour Grids (ID_Comm_Domain; -1: none) */
+static double *hbuf[2][2][2];               /* [dir - 1][side][send, recv] host buffers of the halo */
+static int nranks_dom = 1;
+#endif
 
 #define MAXLEV 8
 static int NL = 0;                          /* levels (1 without SMR) */
@@ -143,7 +160,29 @@ static void ensure_grid(MeshS *pM)
   env = getenv("AA_SYNC_EVERY"); sync_every = env ? atoi(env) : 1; if (sync_every < 1) sync_every = 1;
   for (l = 0, irefine = 1; l < pM->NLevels; l++, irefine *= 2) {
     pD = &pM->Domain[l][0]; PG[l] = pD->Grid;
+#ifdef AA_MPI
+    if (pD->NGrid[0] != 1) ath_error("[athena_amd]: NGrid_x1 = %d: x1 is never cut (the rays travel along it)\n", pD->NGrid[0]);
+    comm_dom = pD->Comm_Domain;
+    MPI_Comm_size(comm_dom, &nranks_dom);
+    { /* bvals_init (bvals_mhd.c:537-821, which this shim replaces): on a periodic Domain the Grids at either end of a
+       * direction are each other's neighbours */
+      int L = -1, Mi = -1, Ni = -1, a, b, c;
+      for (c = 0; c < pD->NGrid[2]; c++) for (b = 0; b < pD->NGrid[1]; b++) for (a = 0; a < pD->NGrid[0]; a++)
+        if (pD->GData[c][b][a].ID_Comm_world == myID_Comm_world) { L = a; Mi = b; Ni = c; }
+      if (L < 0) ath_error("[athena_amd]: this rank holds no Grid of the root Domain\n");
+      if (pM->BCFlag_ix2 == 4 && pM->BCFlag_ox2 == 4 && pD->NGrid[1] > 1) {
+        if (Mi == 0 && PG[l]->lx2_id < 0) PG[l]->lx2_id = pD->GData[Ni][pD->NGrid[1] - 1][L].ID_Comm_Domain;
+        if (Mi == pD->NGrid[1] - 1 && PG[l]->rx2_id < 0) PG[l]->rx2_id = pD->GData[Ni][0][L].ID_Comm_Domain;
+      }
+      if (pM->BCFlag_ix3 == 4 && pM->BCFlag_ox3 == 4 && pD->NGrid[2] > 1) {
+        if (Ni == 0 && PG[l]->lx3_id < 0) PG[l]->lx3_id = pD->GData[pD->NGrid[2] - 1][Mi][L].ID_Comm_Domain;
+        if (Ni == pD->NGrid[2] - 1 && PG[l]->rx3_id < 0) PG[l]->rx3_id = pD->GData[0][Mi][L].ID_Comm_Domain;
+      }
+    }
+    nb_id[0] = PG[l]->lx2_id; nb_id[1] = PG[l]->rx2_id; nb_id[2] = PG[l]->lx3_id; nb_id[3] = PG[l]->rx3_id;
+#else
     if (pD->NGrid[0]*pD->NGrid[1]*pD->NGrid[2] != 1) ath_error("[athena_amd]: one Grid per Domain only\n");
+#endif
     memset(&p, 0, sizeof p);
     for (d = 0; d < 3; d++) {
       p.Nx[d] = PG[l]->Nx[d]; p.rootNx[d] = pM->Nx[d];
@@ -158,6 +197,11 @@ static void ensure_grid(MeshS *pM)
       if (pD->Disp[d] != 0) p.bc[2*d] = 0;
       if ((pD->Disp[d] + pD->Nx[d])/irefine != pM->Nx[d]) p.bc[2*d + 1] = 0;
     }
+#ifdef AA_MPI
+    for (d = 0; d < 4; d++) if (nb_id[d] >= 0) p.bc[2 + d] = 0;     /* a neighbour Grid fills these ghost zones */
+    p.nslab = 1;                                   /* the reference's ranks ARE the decomposition */
+    if (nranks_dom > 1) p.ion_path = 2;            /* the two-kernel sub-cycle: its reductions sit where the reference's are */
+#endif
     p.level = l;
 #ifdef AA_SMR
     p.nslab = 1;                                   /* nested levels stay on one GPU */
@@ -184,6 +228,9 @@ static void ensure_grid(MeshS *pM)
       p.maxiter = (int)par_getd("ionradiation", "maxiter");
     }
     env = getenv("AA_DEVICE"); p.device = env ? atoi(env) : 0;
+#ifdef AA_MPI
+    if (!env) { const int nd = aa_device_count(); p.device = nd > 0 ? myID_Comm_world % nd : 0; }
+#endif
     p.integrator = use_vl();
     p.order = recon_order();
     CHK(aa_create(&p, &G[l]));
@@ -319,6 +366,28 @@ static void refresh_for_output(void)
   if (due) { for (l = 0; l < NL; l++) to_host(l); steps_since_sync = 0; if (automode && learned) verify_next = 1; }
 }
 
+#ifdef AA_MPI
+/* bvals_mhd.c:296-493 for one direction (dir 1 = x2, 2 = x3): the four planes either side travel between neighbouring Grids.
+ * Tag = the way the message travels (down / up), so that two Grids that are each other's neighbour on both sides (periodic
+ * Domain cut in two) keep their messages apart. */
+static void halo_exchange(int dir)
+{
+  const int lo = nb_id[2*(dir - 1)], hi = nb_id[2*(dir - 1) + 1];
+  const long long n = aa_halo_doubles_dir(G[0], dir);
+  MPI_Request rq[4]; MPI_Status st[4]; int nrq = 0, side, w;
+  if (lo < 0 && hi < 0) return;
+  for (side = 0; side < 2; side++) for (w = 0; w < 2; w++)
+    if (!hbuf[dir - 1][side][w]) hbuf[dir - 1][side][w] = (double*)malloc((size_t)n*sizeof(double));
+  if (lo >= 0) MPI_Irecv(hbuf[dir - 1][0][1], (int)n, MPI_DOUBLE, lo, 100 + 2*dir + 1, comm_dom, &rq[nrq++]);   /* travelled up   */
+  if (hi >= 0) MPI_Irecv(hbuf[dir - 1][1][1], (int)n, MPI_DOUBLE, hi, 100 + 2*dir,     comm_dom, &rq[nrq++]);   /* travelled down */
+  if (lo >= 0) { CHK(aa_halo_get(G[0], dir, 0, hbuf[dir - 1][0][0])); MPI_Isend(hbuf[dir - 1][0][0], (int)n, MPI_DOUBLE, lo, 100 + 2*dir, comm_dom, &rq[nrq++]); }
+  if (hi >= 0) { CHK(aa_halo_get(G[0], dir, 1, hbuf[dir - 1][1][0])); MPI_Isend(hbuf[dir - 1][1][0], (int)n, MPI_DOUBLE, hi, 100 + 2*dir + 1, comm_dom, &rq[nrq++]); }
+  MPI_Waitall(nrq, rq, st);
+  if (lo >= 0) CHK(aa_halo_put(G[0], dir, 0, hbuf[dir - 1][0][1]));
+  if (hi >= 0) CHK(aa_halo_put(G[0], dir, 1, hbuf[dir - 1][1][1]));
+}
+#endif
+
 void bvals_mhd(DomainS *pD)
 {
   VGFun_t usr[6]; int d, side, any = 0; const int l = pD->Level;
@@ -327,15 +396,26 @@ void bvals_mhd(DomainS *pD)
   usr[0] = pD->ix1_BCFun; usr[1] = pD->ox1_BCFun; usr[2] = pD->ix2_BCFun;
   usr[3] = pD->ox2_BCFun; usr[4] = pD->ix3_BCFun; usr[5] = pD->ox3_BCFun;
   for (d = 0; d < 6; d++) any |= (usr[d] != NULL);
+#ifdef AA_MPI
+  any = 1;                      /* side by side: the exchanges sit between the directions */
+#endif
   if (!any) CHK(aa_bvals_mhd(G[l]));
   else {
     /* bvals_mhd.c:196-420: ix1, ox1, ix2, ox2, ix3, ox3 in this order; a user function sees the host
      * block with everything filled so far and its ghost zones travel back before the next side */
-    for (d = 0; d < 3; d++) for (side = 0; side < 2; side++) {
-      if (usr[2*d + side] == NULL) { CHK(aa_bvals_mhd_side(G[l], d, side)); continue; }
-      CHK(aa_download_cons(G[l], host_block(l)));
-      (*usr[2*d + side])(PG[l]);
-      CHK(aa_upload_cons(G[l], host_block(l)));
+    for (d = 0; d < 3; d++) {
+      for (side = 0; side < 2; side++) {
+#ifdef AA_MPI
+        if (d > 0 && nb_id[2*(d - 1) + side] >= 0) continue;         /* not a physical side of this Grid */
+#endif
+        if (usr[2*d + side] == NULL) { CHK(aa_bvals_mhd_side(G[l], d, side)); continue; }
+        CHK(aa_download_cons(G[l], host_block(l)));
+        (*usr[2*d + side])(PG[l]);
+        CHK(aa_upload_cons(G[l], host_block(l)));
+      }
+#ifdef AA_MPI
+      if (d > 0) halo_exchange(d);
+#endif
     }
   }
   /* main.c calls bvals_mhd after the ion step (:552; nothing on the host looks at U before
@@ -430,6 +510,14 @@ void new_dt(MeshS *pM)
   CHK(aa_mesh_set_state(MM, pM->time, pM->dt, pM->nstep));
   CHK(aa_mesh_new_dt(MM));
   CHK(aa_mesh_get_state(MM, &t, &dt, &n));
+#elif defined(AA_MPI)
+  { double mine, all;                                /* new_dt.c:159-185 with the MIN over the Grids of the Domain (:177) */
+    CHK(aa_new_dt_local(G[0], &mine));
+    MPI_Allreduce(&mine, &all, 1, MPI_DOUBLE, MPI_MIN, MPI_COMM_WORLD);
+    dt = (pM->nstep == 0) ? all : ((2.0*pM->dt < all) ? 2.0*pM->dt : all);
+    t = pM->time; n = pM->nstep;
+    { const double tlim = par_getd("time", "tlim"); if (t < tlim && (tlim - t) < dt) dt = tlim - t; }
+    CHK(aa_set_mesh_state(G[0], t, dt, n)); }
 #else
   CHK(aa_new_dt(G[0]));
   CHK(aa_get_mesh_state(G[0], &t, &dt, &n));
@@ -482,6 +570,31 @@ static void ion_radtransfer_3d_amd(DomainS *pD)
 #ifdef AA_SMR
   CHK(aa_mesh_set_state(MM, pM->time, pM->dt, pM->nstep));
   CHK(aa_mesh_ion_radtransfer(MM, l, &niter));
+#elif defined(AA_MPI)
+  if (nranks_dom > 1) {
+    /* ionrad_3d.c:862-1047 with the reference's own reductions: MIN of dt_chem / dt_therm behind the rates (:275, :399),
+     * SUM of the cells out of range and MIN of dt_hydro behind the update (:554, :672); MAXCELLCOUNT ionrad.h:38 */
+    double dt_done = 0.0, hdt = pG->dt; int hydro_done = 0;
+    CHK(aa_ion_begin(G[l]));
+    while (!hydro_done) {
+      double a[2], b[2], dts, dth, dth_all; long long cnt; long cl, cl_all;
+      CHK(aa_ion_rates(G[l], &a[0], &a[1]));
+      MPI_Allreduce(a, b, 2, MPI_DOUBLE, MPI_MIN, comm_dom);
+      dts = (b[1] < b[0]) ? b[1] : b[0];
+      if (dt_done + dts > hdt) { dts = hdt - dt_done; hydro_done = 1; }
+      CHK(aa_ion_update(G[l], dts, &cnt, &dth));
+      cl = (long)cnt;
+      MPI_Allreduce(&cl, &cl_all, 1, MPI_LONG, MPI_SUM, comm_dom);
+      MPI_Allreduce(&dth, &dth_all, 1, MPI_DOUBLE, MPI_MIN, comm_dom);
+      dt_done += dts; niter++;
+      if (cl_all > 20) { hdt = dt_done; break; }
+      if (hydro_done) break;
+      if (dth_all < dt_done) { hdt = dt_done; break; }
+    }
+    if (niter == (int)par_getd("ionradiation", "maxiter")) hdt = dt_done;
+    if (hdt < 0) ath_error("[ion_radtransfer_3d]: dt = %e, dt_done = %e\n", hdt, dt_done);
+    CHK(aa_set_mesh_state(G[l], pM->time, hdt, pM->nstep));
+  } else CHK(aa_ion_radtransfer_3d(G[l], &niter));
 #else
   CHK(aa_ion_radtransfer_3d(G[l], &niter));
 #endif

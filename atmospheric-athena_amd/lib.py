@@ -101,6 +101,7 @@ def load(strict: bool | None = None) -> C.CDLL:
         "aa_ion_fetch": (I, [P, dp, ip, dp, dp, llp, dp, ip]), "aa_ion_finish": (I, [P]), "aa_host_syncs": (I, [P, I]),
         "aa_halo_doubles": (LL, [P]), "aa_pack_x3": (I, [P, I, P]), "aa_unpack_x3": (I, [P, I, P]),
         "aa_halo_doubles_x2": (LL, [P]), "aa_pack_x2": (I, [P, I, P]), "aa_unpack_x2": (I, [P, I, P]),
+        "aa_halo_doubles_dir": (LL, [P, I]), "aa_halo_get": (I, [P, I, I, dp]), "aa_halo_put": (I, [P, I, I, dp]), "aa_device_count": (I, []),
         "aa_mesh_create": (I, [I, C.POINTER(P), ip, C.POINTER(P)]), "aa_mesh_destroy": (None, [P]),
         "aa_mesh_get_state": (I, [P, dp, dp, ip]), "aa_mesh_set_state": (I, [P, D, D, I]),
         "aa_mesh_set_stream": (I, [P, P]), "aa_mesh_restrict_correct_pair": (I, [P, I]),

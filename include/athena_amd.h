@@ -162,6 +162,12 @@ int aa_unpack_x3(aa_grid *g, int side, const double *dev_buf);
 long long aa_halo_doubles_x2(const aa_grid *g);
 int aa_pack_x2(aa_grid *g, int side, double *dev_buf);
 int aa_unpack_x2(aa_grid *g, int side, const double *dev_buf);
+/* The same halos through HOST buffers, for a driver that moves them itself (the reference's own MPI ranks linked on the shim:
+ * MPI_Isend / MPI_Irecv of bvals_mhd.c:296-493): dir 1 = x2, 2 = x3; aa_halo_doubles_dir doubles per buffer. */
+long long aa_halo_doubles_dir(const aa_grid *g, int dir);
+int aa_halo_get(aa_grid *g, int dir, int side, double *host_buf);        /* pack_i* (side 0) / pack_o* (side 1) -> host_buf */
+int aa_halo_put(aa_grid *g, int dir, int side, const double *host_buf);  /* host_buf -> the ghost planes of that side      */
+int aa_device_count(void);                                               /* visible HIP devices (0: none)                  */
 
 /* ---- static mesh refinement (reference built with --enable-smr): nested levels, one Domain per
  *      level, all resident on one GPU.  levels[l] was created with aa_params.level = l, Nx = the

@@ -1,8 +1,8 @@
 /* include/athena_compat.h -- the reference's host-side data structures, restated for the one
  * configuration this package accelerates:
  *   HYDRO, ADIABATIC, CARTESIAN, NSCALARS = AA_NSCALARS (default 1), ION_RADIATION + ION_RADPLANE,
- *   NO_MPI_PARALLEL, NO_MESH_REFINEMENT (or STATIC_MESH_REFINEMENT with -DAA_SMR), no particles /
- *   self-gravity / shearing box.
+ *   NO_MPI_PARALLEL (or MPI_PARALLEL with -DAA_MPI), NO_MESH_REFINEMENT (or STATIC_MESH_REFINEMENT with -DAA_SMR; not both),
+ *   no particles / self-gravity / shearing box.
  * A driver or problem file compiled against the reference's athena.h with those macros and one
  * compiled against this header agree on every offset, so the reference's own main.o, init_mesh.o,
  * problem.o ... can be linked against host/athena_shim.c unchanged.  Field order
@@ -19,6 +19,9 @@
 #define AA_ION_RADPLANE (AA_NSCALARS > 0)
 #endif
 
+#ifdef AA_MPI                              /* the reference configured with --enable-mpi (MPI_PARALLEL) */
+#include <mpi.h>
+#endif
 typedef double Real;                       /* athena.h:33-34 (DOUBLE_PREC) */
 struct Mesh_s;
 
@@ -84,6 +87,10 @@ typedef struct Domain_s {                  /* athena.h:340-386 */
   VGFun_t ix1_BCFun, ox1_BCFun, ix2_BCFun, ox2_BCFun, ix3_BCFun, ox3_BCFun;
 #if AA_ION_RADPLANE
   struct Mesh_s *Mesh;                     /* athena.h:383-385 */
+#endif
+#ifdef AA_MPI
+  MPI_Comm Comm_Domain;                    /* athena.h:387-389 */
+  MPI_Group Group_Domain;
 #endif
 } DomainS;
 

@@ -34,19 +34,25 @@ def rank_grid(cores, nx):
     return best
 
 
-def run(nx, nlim, overrides=(), cores=None):
-    """-> dict(U [Nx3][Nx2][Nx1][6] of the whole Domain after `nlim` steps, niter per step, time, dt, ranks)."""
+def run(nx, nlim, overrides=(), cores=None, exe=None, problem="ioniz_sphere", grid=None, env_extra=None):
+    """-> dict(U [Nx3][Nx2][Nx1][6] of the whole Domain after `nlim` steps, niter per step, time, dt, ranks, stderr).
+    exe: another MPI executable of oracle/_ref (e.g. the drop-in athena_<cfg>_mpi_amd); grid = (NGrid_x2, NGrid_x3)."""
+    exe = exe or EXE
+    ion = problem != "blast"
+    deck0 = os.path.join(ROOT, "atmospheric-athena_amd", "decks", "athinput." + problem)
     cores = cores or min(len(os.sched_getaffinity(0)), 16)
-    p2, p3 = rank_grid(cores, nx)
+    p2, p3 = grid if grid else rank_grid(cores, nx)
     tmp = tempfile.mkdtemp(prefix="refmpi_")
     try:
-        txt = open(DECK).read().replace("<domain1>", f"<domain1>\nNGrid_x1 = 1\nNGrid_x2 = {p2}\nNGrid_x3 = {p3}", 1)
+        txt = open(deck0).read().replace("<domain1>", f"<domain1>\nNGrid_x1 = 1\nNGrid_x2 = {p2}\nNGrid_x3 = {p3}", 1)
         txt = re.sub(r"(?m)^maxout\s*=.*$", "maxout = 1", txt, count=1) + "\n<output1>\nout_fmt = rst\ndt = 1e300\n"
         deck = os.path.join(tmp, "athinput")
         open(deck, "w").write(txt)
         rundir = os.path.join(tmp, "run")
-        env = dict(os.environ); env["LD_LIBRARY_PATH"] = "/opt/conda/lib:" + env.get("LD_LIBRARY_PATH", "")
-        args = [MPIEXEC, "-n", str(p2 * p3), EXE, "-i", deck, "-d", rundir] + [f"domain1/Nx{d + 1}={nx[d]}" for d in range(3)] \
+        env = dict(os.environ); env.update(env_extra or {})
+        if exe == EXE or not exe.endswith("_amd"):       # (the drop-in carries its own search path: conda's libstdc++ must not come first)
+            env["LD_LIBRARY_PATH"] = "/opt/conda/lib:" + env.get("LD_LIBRARY_PATH", "")
+        args = [MPIEXEC, "-n", str(p2 * p3), exe, "-i", deck, "-d", rundir] + [f"domain1/Nx{d + 1}={nx[d]}" for d in range(3)] \
             + [f"time/nlim={nlim}"] + list(overrides)
         pr = subprocess.run(args, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, cwd=tmp, timeout=1800, env=env)
         if pr.returncode != 0:
@@ -58,11 +64,11 @@ def run(nx, nlim, overrides=(), cores=None):
         for r in range(p2 * p3):
             d = os.path.join(rundir, f"id{r}")
             f = sorted(x for x in os.listdir(d) if x.endswith(".rst"))[-1]
-            g = read_rst(os.path.join(d, f), (nx[0], l2, l3), 1, True)
+            g = read_rst(os.path.join(d, f), (nx[0], l2, l3), 1 if ion else 0, ion)
             assert g["nstep"] == nlim
             j, k = r % p2, r // p2                  # ranks are dealt x1-fastest, then x2, then x3 (init_mesh.c:589-596)
             U[k * l3:(k + 1) * l3, j * l2:(j + 1) * l2] = g["U"]
             time, dt = g["time"], g["dt"]
-        return dict(U=U, niter=niter, time=time, dt=dt, ranks=p2 * p3)
+        return dict(U=U, niter=niter, time=time, dt=dt, ranks=p2 * p3, stderr=pr.stderr)
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
