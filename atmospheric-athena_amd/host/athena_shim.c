@@ -314,6 +314,9 @@ void integrate_destruct(void)
   if (MM) { aa_mesh_destroy(MM); MM = NULL; }
 #endif
   for (l = 0; l < NL; l++) { if (G[l]) { aa_destroy(G[l]); G[l] = NULL; } free(snap[l]); snap[l] = NULL; }
+#ifdef AA_MPI
+  { int a, b, c; for (a = 0; a < 2; a++) for (b = 0; b < 2; b++) for (c = 0; c < 2; c++) { free(hbuf[a][b][c]); hbuf[a][b][c] = NULL; } }
+#endif
   NL = 0;
 }
 
