@@ -232,6 +232,31 @@ int aa_download_cons(aa_grid *g, double *U)
   HIPCHK(hipStreamSynchronize(g->st));
   return 0;
 }
+// Only the GHOST zones of the host block [N3][N2][N1][nvar] (the caller knows its active zones are current: nothing but
+// boundary calls ran on the device since the block last travelled).  The shell is 9 % of a 256^3 block: six strided copies
+// out of the staging area instead of the whole block over PCIe.
+int aa_download_ghost_zones(aa_grid *g, double *U)
+{
+  if (!g->slab.empty()) return slabs_download_cons(g, U);
+  g->inner_swept = false;
+  const int nvar = 5 + g->p.nscal, N1 = g->d.N1, N2 = g->d.N2, N3 = g->d.N3, ng = AA_NGHOST;
+  const size_t row = (size_t)N1*nvar*sizeof(Real), plane = row*N2;
+  launch_soa_to_aos(g->d, nvar, g->d.LR, g->st);
+  const char *S = (const char*)g->d.LR; char *D = (char*)U;
+  // x3: the four planes at either end, whole
+  HIPCHK(hipMemcpyAsync(D, S, ng*plane, hipMemcpyDeviceToHost, g->st));
+  HIPCHK(hipMemcpyAsync(D + (size_t)(N3 - ng)*plane, S + (size_t)(N3 - ng)*plane, ng*plane, hipMemcpyDeviceToHost, g->st));
+  const size_t mid = (size_t)ng*plane;      // the planes in between
+  // x2: four rows at either end of every such plane
+  HIPCHK(hipMemcpy2DAsync(D + mid, plane, S + mid, plane, ng*row, N3 - 2*ng, hipMemcpyDeviceToHost, g->st));
+  HIPCHK(hipMemcpy2DAsync(D + mid + (size_t)(N2 - ng)*row, plane, S + mid + (size_t)(N2 - ng)*row, plane, ng*row, N3 - 2*ng, hipMemcpyDeviceToHost, g->st));
+  // x1: four zones at either end of every row of those planes (the rows are one constant stride apart across j and k)
+  const size_t w = (size_t)ng*nvar*sizeof(Real), nrows = (size_t)(N3 - 2*ng)*N2;
+  HIPCHK(hipMemcpy2DAsync(D + mid, row, S + mid, row, w, nrows, hipMemcpyDeviceToHost, g->st));
+  HIPCHK(hipMemcpy2DAsync(D + mid + row - w, row, S + mid + row - w, row, w, nrows, hipMemcpyDeviceToHost, g->st));
+  HIPCHK(hipStreamSynchronize(g->st));
+  return 0;
+}
 // planes [k_first, k_first + nplanes) of the host block [N3][N2][N1][nvar]
 int aa_download_cons_planes(aa_grid *g, int k_first, int nplanes, double *dst)
 {

@@ -77,6 +77,7 @@ static MeshS *M = NULL, *M0 = NULL;
 static aa_mesh *MM = NULL;
 #endif
 static int host_newer[MAXLEV];      /* the host block of this level holds data the device has not seen */
+static int active_same[MAXLEV];     /* host and device agree on the ACTIVE zones of this level (only ghost zones may differ) */
 static int learn = 0, learned = 0, sync_every = 1;
 /* AA_COHERENCE=auto: the write set of Userwork_in_loop must repeat before it is trusted; the output schedule */
 static int automode = 0, gave_up = 0;
@@ -258,17 +259,25 @@ static void ensure_grid(MeshS *pM)
 
 static void to_device(int l)
 {
-  if (host_newer[l]) { CHK(aa_upload_cons(G[l], host_block(l))); host_newer[l] = 0; }
+  if (host_newer[l]) { CHK(aa_upload_cons(G[l], host_block(l))); host_newer[l] = 0; active_same[l] = 1; }
   CHK(aa_set_mesh_state(G[l], M->time, PG[l]->dt, M->nstep));
 }
 
-static void to_host(int l)
+/* ghosts_only: the caller is refresh_for_output, i.e. only boundary calls have run on the device since the block last
+ * travelled (active_same): then the ghost shell is all that differs */
+static void to_host_x(int l, int ghosts_only)
 {
-  CHK(aa_download_cons(G[l], host_block(l)));
+  static int shell_ok = -1;      /* AA_GHOST_REFRESH=0: always the whole block (A/B measurements) */
+  if (shell_ok < 0) { const char *e = getenv("AA_GHOST_REFRESH"); shell_ok = !(e && atoi(e) == 0); }
+  if (shell_ok && ghosts_only && active_same[l] && !host_newer[l]) CHK(aa_download_ghost_zones(G[l], host_block(l)));
+  else CHK(aa_download_cons(G[l], host_block(l)));
+  active_same[l] = 1;
 #if AA_ION_RADPLANE
   if (M->radplanelist != NULL && M->radplanelist->nradplane > 0) CHK(aa_download_edgeflux(G[l], host_edgeflux(l)));
 #endif
 }
+
+static void to_host(int l) { to_host_x(l, 0); }
 
 /* after the integrator (and, with SMR, RestrictCorrect): Userwork_in_loop reads and may write pG->U */
 static void refresh_for_userwork(int l)
@@ -277,7 +286,7 @@ static void refresh_for_userwork(int l)
     verify_now = verify_next || (++steps_since_reval >= reval_every);
     verify_next = 0;
   }
-  if (learn && learned && !(automode && verify_now)) { CHK(aa_apply_pinned_cells(G[l])); return; }
+  if (learn && learned && !(automode && verify_now)) { CHK(aa_apply_pinned_cells(G[l])); active_same[l] = 0; return; }
   to_host(l);
   host_newer[l] = 1;
   if (learn) {
@@ -294,6 +303,7 @@ static void integrate_3d_amd(DomainS *pD)
 {
   const int l = pD->Level;
   to_device(l);
+  active_same[l] = 0;
   if (use_vl()) CHK(aa_integrate_3d_vl(G[l])); else CHK(aa_integrate_3d_ctu(G[l]));
   integrated = 1;
   if (NL == 1) refresh_for_userwork(0);         /* with SMR, RestrictCorrect (main.c:591) still follows */
@@ -366,7 +376,7 @@ static void refresh_for_output(void)
   if (!(learn && learned)) due = 1;
   else if (automode) due = host_read_due();
   else due = (++steps_since_sync >= sync_every);
-  if (due) { for (l = 0; l < NL; l++) to_host(l); steps_since_sync = 0; if (automode && learned) verify_next = 1; }
+  if (due) { for (l = 0; l < NL; l++) to_host_x(l, 1); steps_since_sync = 0; if (automode && learned) verify_next = 1; }
 }
 
 #ifdef AA_MPI
@@ -444,7 +454,7 @@ void new_dt(MeshS *pM)
     for (l = 0; l < NL; l++) { free(snap[l]); snap[l] = NULL; }
     verify_now = 0; steps_since_reval = 0;
     if (ok) {
-      for (l = 0; l < NL; l++) CHK(aa_apply_pinned_cells(G[l]));      /* this step's Userwork, on the device */
+      for (l = 0; l < NL; l++) { CHK(aa_apply_pinned_cells(G[l])); active_same[l] = 0; }   /* this step's Userwork, on the device */
     } else {
       /* the host blocks hold what Userwork_in_loop really did on this step's state: they travel back (host_newer is set),
        * and from here on every step does */
@@ -486,7 +496,7 @@ void new_dt(MeshS *pM)
     } else {
       for (l = 0; l < NL; l++) {
         CHK(aa_set_pinned_cells(G[l], cnt_l[l], idx_l[l], val_l[l]));
-        CHK(aa_apply_pinned_cells(G[l]));          /* this step's Userwork, on the device */
+        CHK(aa_apply_pinned_cells(G[l])); active_same[l] = 0;   /* this step's Userwork, on the device */
         fprintf(stderr, "[athena_amd] Userwork_in_loop pins %lld cells on level %d; re-imposed on the device from now on\n", cnt_l[l], l);
         if (automode) { pin_n[l] = cnt_l[l]; pin_idx[l] = idx_l[l]; pin_val[l] = val_l[l]; }     /* kept for re-validation */
         else { free(idx_l[l]); free(val_l[l]); }
@@ -539,7 +549,7 @@ void RestrictCorrect(MeshS *pM)                        /* main.c:401, :591 */
 {
   int l;
   ensure_grid(pM);
-  for (l = 0; l < NL; l++) to_device(l);
+  for (l = 0; l < NL; l++) { to_device(l); active_same[l] = 0; }
   CHK(aa_mesh_restrict_correct(MM));
   if (integrated) { integrated = 0; for (l = 0; l < NL; l++) refresh_for_userwork(l); }
 }
@@ -557,7 +567,9 @@ void Prolongate(MeshS *pM)                             /* main.c:446, :647 */
 
 void ionradRestrictCorrect(MeshS *pM)                  /* main.c:561 */
 {
+  int l;
   (void)pM;
+  for (l = 0; l < NL; l++) active_same[l] = 0;
   CHK(aa_mesh_ionrad_restrict_correct(MM));
 }
 #endif /* AA_SMR */
@@ -570,6 +582,7 @@ static void ion_radtransfer_3d_amd(DomainS *pD)
 {
   GridS *pG = pD->Grid; MeshS *pM = pD->Mesh; int niter = 0; double t, dt; int n; const int l = pD->Level;
   to_device(l);
+  active_same[l] = 0;
 #ifdef AA_SMR
   CHK(aa_mesh_set_state(MM, pM->time, pM->dt, pM->nstep));
   CHK(aa_mesh_ion_radtransfer(MM, l, &niter));

@@ -85,7 +85,7 @@ def load(strict: bool | None = None) -> C.CDLL:
         "aa_set_stream": (I, [P, P]),
         "aa_sync": (I, [P]),
         "aa_device_bytes": (LL, [P]),
-        "aa_upload_cons": (I, [P, dp]), "aa_download_cons": (I, [P, dp]),
+        "aa_upload_cons": (I, [P, dp]), "aa_download_cons": (I, [P, dp]), "aa_download_ghost_zones": (I, [P, dp]),
         "aa_upload_edgeflux": (I, [P, dp]), "aa_download_edgeflux": (I, [P, dp]),
         "aa_get_mesh_state": (I, [P, dp, dp, ip]), "aa_set_mesh_state": (I, [P, D, D, I]),
         "aa_set_static_grav_pot": (I, [P, GRAVPOT]),
@@ -215,6 +215,10 @@ class Grid:
         U = self.new_host_block()
         self._chk(self.L.aa_download_cons(self._h, _dp(U)))
         return U
+
+    def download_ghost_zones(self, U: np.ndarray):
+        """refresh only the ghost zones of a host block whose active zones are current"""
+        self._chk(self.L.aa_download_ghost_zones(self._h, _dp(U)))
 
     def download_edgeflux(self) -> np.ndarray:
         nx = self.cfg.Nx

@@ -505,6 +505,29 @@ def test_round_trip_and_bc(aa, lib):
         g.close()
 
 
+def test_ghost_zone_refresh(aa, lib):
+    """aa_download_ghost_zones rewrites exactly the ghost shell of the caller's block: after bvals_mhd it equals a full
+    download, and a block whose active zones were scribbled on keeps the scribble (the shim's end-of-step refresh)."""
+    for prob, nx in (("ifront", (8, 12, 16)), ("blast", (12, 8, 10)), ("blast", (70, 9, 5))):
+        ov = [f"domain1/Nx{d + 1}={nx[d]}" for d in range(3)]
+        run = aa.config.load(os.path.join(orc.DECKS, "athinput." + prob), ov, prob)
+        g = lib.setup_problem(aa.config.slab(run), 0, True)
+        rng = np.random.default_rng(11)
+        U = g.new_host_block(); U[...] = rng.uniform(0.5, 2.0, U.shape)
+        g.upload(U)
+        g.bvals_mhd()
+        full = g.download()
+        H = U.copy()                      # host copy: active zones current, ghost zones stale
+        g.download_ghost_zones(H)
+        assert np.array_equal(H, full)
+        H = np.full_like(U, -7.0)
+        g.download_ghost_zones(H)
+        assert np.all(H[4:-4, 4:-4, 4:-4] == -7.0)
+        shell = np.ones(U.shape[:3], bool); shell[4:-4, 4:-4, 4:-4] = False
+        assert np.array_equal(H[shell], full[shell])
+        g.close()
+
+
 def test_missing_library_is_loud(lib, monkeypatch):
     monkeypatch.setattr(lib, "HERE", "/nonexistent")
     lib._libs.clear()
