@@ -458,6 +458,9 @@ template <int D> AA_DEV void to_sweep(const Real wg[6], Real p, Real ws[6])
   ws[4] = p;
 }
 
+#ifndef AA_NT_ST
+#define AA_NT_ST 1
+#endif
 struct CellFlux {            // first-pass fluxes across one zone
   Real dF[3][6];             // F_e(upper face) - F_e(lower face), global frame
   Real gm[3], ge[3];         // gravity: q_e (phi_r - phi_l) d   and   q_e (F_lo (phi_c - phi_l) + F_hi (phi_r - phi_c))
@@ -516,7 +519,10 @@ AA_DEV void cell_finish(const DevGrid &g, long m, const Real q[3], const CellFlu
   }
   if (store) {
 #pragma unroll
-    for (int v = 0; v < NV; v++) { LRf(g, D, 0, v)[m + sD] = ul[v]; LRf(g, D, 1, v)[m] = ur[v]; }
+    for (int v = 0; v < NV; v++) {      // written here, read once by the next kernel: non-temporal (AA_NT_ST=0: plain stores)
+      if (AA_NT_ST) { __builtin_nontemporal_store(ul[v], LRf(g, D, 0, v) + m + sD); __builtin_nontemporal_store(ur[v], LRf(g, D, 1, v) + m); }
+      else { LRf(g, D, 0, v)[m + sD] = ul[v]; LRf(g, D, 1, v)[m] = ur[v]; }
+    }
   }
 #pragma unroll
   for (int n = 0; n < 6; n++) { sl[n] = ul[gv<D>(n)]; sr[n] = ur[gv<D>(n)]; }
@@ -1077,6 +1083,10 @@ k_flux2_update(DevGrid g, const Real *dhalf, Real dt, int kchunk, KeepPlanes kp,
       Real u[6];
 #pragma unroll
       for (int v = 0; v < NV; v++) u[v] = Uf(g, v)[m];
+      // (the mask byte with the zone's other operands, not behind the stores of U: a load that is consumed at once waits
+      //  for everything issued before it, i.e. the wave sat out the six stores' round trip in every plane)
+      unsigned char pinned = 0;
+      if (CFL && pinmask) pinned = pinmask[m];
       if (GRAV) {   // :2741-2782, with the mass fluxes (sweep component 0) of the faces just solved
         const Real phic = Pf(g, 0)[m], dh = dhalf[m];
         { const Real phir = Pf(g, 1)[m + 1], phil = Pf(g, 1)[m];
@@ -1099,7 +1109,7 @@ k_flux2_update(DevGrid g, const Real *dhalf, Real dt, int kchunk, KeepPlanes kp,
 #pragma unroll
       for (int v = 0; v < NV; v++) Uf(g, v)[m] = u[v];
       if (CFL) {
-        if (!pinmask || !pinmask[m]) {
+        if (!pinned) {
           Real cmx[3] = {s_cmx[0][row][lane], s_cmx[1][row][lane], s_cmx[2][row][lane]};
           cfl_zone(u[0], u[1], u[2], u[3], u[4], g.Gamma, g.Gamma_1, cmx);
           s_cmx[0][row][lane] = cmx[0]; s_cmx[1][row][lane] = cmx[1]; s_cmx[2][row][lane] = cmx[2];
