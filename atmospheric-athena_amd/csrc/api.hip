@@ -115,7 +115,7 @@ int aa_create(const aa_params *p, aa_grid **out)
     rootdx[a] = (p->xmax[a] - p->xmin[a])/(Real)(p->rootNx[a]);   // init_mesh.c:225
     d.dx[a] = rootdx[a]/(Real)(1 << p->level);                    // :245
   }
-  d.Gamma = p->gamma; d.Gamma_1 = p->gamma - 1.0;
+  d.Gamma = p->gamma; d.Gamma_1 = p->gamma - 1.0; d.rGamma_1 = 1.0/d.Gamma_1;
   // one pool: U 6 | LR 36 | F 18 | eta 3 | dhalf 1 | phi 4 | ion 5 + sign(1) | edgeflux
   const size_t nc = (size_t)d.nc;
   const size_t nef = (size_t)(d.Nx1 + 1)*(d.Nx2 + 1)*(d.Nx3 + 1);
@@ -987,6 +987,22 @@ int aa_test_lr_states(int nscal, double gamma, int n, const double *W, double dt
 { return test_lr_any(2, nscal, gamma, n, W, dt, dx, il, iu, Wl, Wr); }
 int aa_test_lr_states_ppm(int nscal, double gamma, int n, const double *W, double dt, double dx, int il, int iu, double *Wl, double *Wr)
 { return test_lr_any(3, nscal, gamma, n, W, dt, dx, il, iu, Wl, Wr); }
+
+// the scaling-free quotient / square root of hydro_dev.h beside hipcc's own: out[5][n] = x_div(a,b), a/b, x_sqrt(a), sqrt(a),
+// x_div_r(a, b, 1/b)
+int aa_test_xdiv(int n, const double *a, const double *b, double *out)
+{
+  if (n <= 0) return fail(-1, "[aa_test_xdiv]: n = %d", n);
+  Real *d = nullptr;
+  HIPCHK(hipMalloc(&d, 7*(size_t)n*sizeof(Real)));
+  HIPCHK(hipMemcpy(d, a, (size_t)n*sizeof(Real), hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(d + n, b, (size_t)n*sizeof(Real), hipMemcpyHostToDevice));
+  launch_test_xdiv(n, d, d + n, d + 2*(size_t)n, 0);
+  HIPCHK(hipDeviceSynchronize());
+  HIPCHK(hipMemcpy(out, d + 2*(size_t)n, 5*(size_t)n*sizeof(Real), hipMemcpyDeviceToHost));
+  hipFree(d);
+  return 0;
+}
 
 // exp / log of the one-kernel sub-cycle (ion_pass.hip) on n values (n a multiple of 4): ye = exp(x), yl = ln|x|
 int aa_test_explog(int n, const double *x, double *ye, double *yl)

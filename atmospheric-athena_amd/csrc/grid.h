@@ -30,6 +30,7 @@ struct DevGrid {
   long sJ, sK, nc;                // strides of j and k (i stride is 1); doubles per field
   Real dx[3];
   Real Gamma, Gamma_1;
+  Real rGamma_1;                  // 1/(gamma-1), correctly rounded (host division): prim_to_cons' quotient in three instructions (hydro_dev.h, AA_XDIV)
   Real *U, *LR, *F, *eta, *dhalf;
   Real *phi;                      // null when StaticGravPot == NULL; [0]=centre, [1+d]=lower face d
   Real *slope;                    // --with-order=3 only: 18*nc, [dir][prim var] monotonised slopes (lr_states_ppm.c dWm)
@@ -127,6 +128,7 @@ void launch_test_fluxes(int nscal, Real gamma, int n, const Real *Ul, const Real
                         Real *F, hipStream_t st);
 void launch_test_lr(int nscal, Real gamma, int n, const Real *W, Real dt, Real dx, int il, int iu,
                     Real *Wl, Real *Wr, hipStream_t st);
+void launch_test_xdiv(int n, const Real *a, const Real *b, Real *out, hipStream_t st);     // out[5][n]: x_div, a/b, x_sqrt, sqrt, x_div_r
 void launch_test_lr_ppm(int nscal, Real gamma, int n, const Real *W, Real dt, Real dx, int il, int iu,
                         Real *Wl, Real *Wr, hipStream_t st);
 

@@ -75,6 +75,57 @@ AA_DEV Real q_div_checked(Real a, Real b)
   return (ab > 1.0e-280 && ab < 1.0e280) ? a*q_rcp(b) : a/b;
 }
 
+// ---- both builds (AA_XDIV): IEEE quotients and square roots without the range scaling of hipcc's expansions.  a/b compiles to
+// v_div_scale x2, v_rcp, four Newton fmas, q = n r, rem = fma(-d, q, n), v_div_fmas, v_div_fixup (11 instructions); sqrt(x) to a
+// compare + select + v_ldexp in front of and v_ldexp + class test + 3 selects behind v_rsq and nine mul / fma (20).  The scaling
+// only acts on denormal / huge denominators, quotients near the ends of the range, numerators below 2^-969 and x < 2^-767; the
+// special-case selects only on zero / infinite operands.  For the operands of the Riemann solver (densities, sound speeds,
+// total enthalpies, momenta squared: positive normal numbers in any unit system a run survives in, or exactly zero as a
+// numerator) the SAME instruction sequence without those parts gives the SAME bits -- correctly rounded, so the strict build
+// stays bit-identical to the CPU and no Roe -> HLLE switch can move (tests: x_div / x_sqrt against the compiler's forms on
+// random and on edge operands; every bitwise parity test of the strict build runs on them).  A NaN operand gives NaN either way.
+// With a loop-invariant denominator the refined reciprocal is the correctly rounded one the host supplies (g.rGamma_1 =
+// 1/(gamma-1) in IEEE arithmetic) and a quotient is three instructions: q = a y, rem = fma(-b, q, a), fma(rem, y, q) is the
+// correctly rounded a/b (Markstein 1990; the excluded denominators have an all-ones significand).
+#ifndef AA_XDIV
+#define AA_XDIV 1
+#endif
+AA_DEV Real x_rcp_ref(Real b)                    // the reciprocal hipcc's division refines (two Newton steps on v_rcp_f64)
+{
+  Real r = __builtin_amdgcn_rcp(b);
+  Real e = fma(-b, r, 1.0); r = fma(r, e, r);
+  e = fma(-b, r, 1.0); r = fma(r, e, r);
+  return r;
+}
+AA_DEV Real x_div_r(Real a, Real b, Real r)      // a/b with r = x_rcp_ref(b) or the correctly rounded 1/b
+{
+  const Real q = a*r;
+  const Real rem = fma(-b, q, a);
+  return fma(rem, r, q);
+}
+template <bool XD = true> AA_DEV Real x_div(Real a, Real b)
+{
+#if AA_XDIV
+  if (XD) return x_div_r(a, b, x_rcp_ref(b));
+#endif
+  return a/b;
+}
+template <bool XD = true> AA_DEV Real x_sqrt(Real x)
+{
+#if AA_XDIV
+  if (!XD) return sqrt(x);
+  const Real y = __builtin_amdgcn_rsq(x);
+  Real g = x*y, h = y*0.5;
+  const Real r = fma(-h, g, 0.5);
+  g = fma(g, r, g); h = fma(h, r, h);
+  Real d = fma(-g, g, x); g = fma(d, h, g);
+  d = fma(-g, g, x); g = fma(d, h, g);
+  return g;
+#else
+  return sqrt(x);
+#endif
+}
+
 // convert_var.c:389 Cons1D_to_Prim1D
 template <int NS>
 AA_DEV void cons_to_prim(const Real u[6], Real w[6], Real Gamma_1)
@@ -92,11 +143,14 @@ AA_DEV void cons_to_prim(const Real u[6], Real w[6], Real Gamma_1)
 }
 
 // convert_var.c:432 Prim1D_to_Cons1D
+// rG_1: the correctly rounded 1/(gamma-1) (DevGrid.rGamma_1): the quotient P/(gamma-1) in three instructions, same bits
 template <int NS>
-AA_DEV void prim_to_cons(const Real w[6], Real u[6], Real Gamma_1)
+AA_DEV void prim_to_cons(const Real w[6], Real u[6], Real Gamma_1, Real rG_1)
 {
   u[0] = w[0]; u[1] = w[0]*w[1]; u[2] = w[0]*w[2]; u[3] = w[0]*w[3];
-#if AA_FD_P2C
+#if AA_XDIV
+  u[4] = x_div_r(w[4], Gamma_1, rG_1) + 0.5*w[0]*(sqr(w[1]) + sqr(w[2]) + sqr(w[3]));
+#elif AA_FD_P2C
   u[4] = w[4]*(1.0/Gamma_1) + 0.5*w[0]*(sqr(w[1]) + sqr(w[2]) + sqr(w[3]));      // (the quotient is loop-invariant: one division per thread)
 #else
   u[4] = w[4]/Gamma_1 + 0.5*w[0]*(sqr(w[1]) + sqr(w[2]) + sqr(w[3]));
@@ -136,18 +190,19 @@ AA_DEV Real lambda_face(const Real u[6], Real Gamma, Real Gamma_1, Real sign)
 }
 
 // rsolvers/hlle.c:62 (compiled into roe.c as flux_hlle, roe.c:339-341)
-template <int NS>
+template <int NS, bool XD = true>
 AA_DEV void flux_hlle(const Real ul[6], const Real ur[6], const Real wl[6], const Real wr[6],
                       Real Gamma, Real Gamma_1, Real f[6])
 {
-  Real sqrtdl = sqrt(wl[0]), sqrtdr = sqrt(wr[0]);
-  Real isdlpdr = 1.0/(sqrtdl + sqrtdr);
+  // (the same scaling-free forms as in flux_roe, whose values these are: one evaluation serves both)
+  Real sqrtdl = x_sqrt<XD>(wl[0]), sqrtdr = x_sqrt<XD>(wr[0]);
+  Real isdlpdr = x_div<XD>(1.0, sqrtdl + sqrtdr);
   Real v1 = (sqrtdl*wl[1] + sqrtdr*wr[1])*isdlpdr;
   Real v2 = (sqrtdl*wl[2] + sqrtdr*wr[2])*isdlpdr;
   Real v3 = (sqrtdl*wl[3] + sqrtdr*wr[3])*isdlpdr;
-  Real h  = ((ul[4] + wl[4] + 0.0)/sqrtdl + (ur[4] + wr[4] + 0.0)/sqrtdr)*isdlpdr;
+  Real h  = (x_div<XD>(ul[4] + wl[4] + 0.0, sqrtdl) + x_div<XD>(ur[4] + wr[4] + 0.0, sqrtdr))*isdlpdr;
   Real vsq = v1*v1 + v2*v2 + v3*v3;
-  Real a = sqrt(Gamma_1*rmax((h - 0.5*vsq), AA_TINY));
+  Real a = x_sqrt<XD>(Gamma_1*rmax((h - 0.5*vsq), AA_TINY));
   Real ev0 = v1 - a, ev4 = v1 + a;
 
   Real asq = Gamma*wl[4]/wl[0];
@@ -179,7 +234,9 @@ AA_DEV void flux_hlle(const Real ul[6], const Real ur[6], const Real wl[6], cons
 // rsolvers/roe.c:59 fluxes() with the H-correction etah and the HLLE fallback;
 // eigensystem rsolvers/esystem_roe.c:132
 // FAST: the reciprocal forms (AA_FD_ROE, off: see above; k_flux2_update, at its register limit, was also slower with them)
-template <int NS, bool FAST = (AA_FD_ROE != 0)>
+// XD: the scaling-free quotients / square roots (AA_XDIV) -- everywhere but in k_flux2_update, which is not bound by its
+// instruction count and lost 4 % with them (13.9 -> 14.4 ms at 512^3, same-box ABAB: three more registers spilled)
+template <int NS, bool FAST = (AA_FD_ROE != 0), bool XD = true>
 AA_DEV void flux_roe(const Real ul[6], const Real ur[6], const Real wl[6], const Real wr[6],
                      Real etah, Real Gamma, Real Gamma_1, Real f[6])
 {
@@ -198,15 +255,15 @@ AA_DEV void flux_roe(const Real ul[6], const Real ur[6], const Real wl[6], const
     iasq = ia*ia;
     a = asq*ia;
   } else {
-    sqrtdl = sqrt(wl[0]); sqrtdr = sqrt(wr[0]);
-    isdlpdr = 1.0/(sqrtdl + sqrtdr);
+    sqrtdl = x_sqrt<XD>(wl[0]); sqrtdr = x_sqrt<XD>(wr[0]);
+    isdlpdr = x_div<XD>(1.0, sqrtdl + sqrtdr);
     v1 = (sqrtdl*wl[1] + sqrtdr*wr[1])*isdlpdr;
     v2 = (sqrtdl*wl[2] + sqrtdr*wr[2])*isdlpdr;
     v3 = (sqrtdl*wl[3] + sqrtdr*wr[3])*isdlpdr;
-    h  = ((ul[4] + wl[4] + 0.0)/sqrtdl + (ur[4] + wr[4] + 0.0)/sqrtdr)*isdlpdr;
+    h  = (x_div<XD>(ul[4] + wl[4] + 0.0, sqrtdl) + x_div<XD>(ur[4] + wr[4] + 0.0, sqrtdr))*isdlpdr;
     vsq = v1*v1 + v2*v2 + v3*v3;
     asq = Gamma_1*rmax((h - 0.5*vsq), AA_TINY);
-    a = sqrt(asq);
+    a = x_sqrt<XD>(asq);
   }
   Real ev0 = v1 - a, ev4 = v1 + a;
 
@@ -232,13 +289,14 @@ AA_DEV void flux_roe(const Real ul[6], const Real ur[6], const Real wl[6], const
     return;
   }
 
-  Real na = FAST ? 0.5*iasq : 0.5/asq;
+  const Real rasq = (FAST || !XD || !AA_XDIV) ? 0.0 : x_rcp_ref(asq);      // one refined reciprocal for the two quotients by a^2
+  Real na = FAST ? 0.5*iasq : ((XD && AA_XDIV) ? x_div_r(0.5, asq, rasq) : 0.5/asq);
   Real l00 = na*(0.5*Gamma_1*vsq + v1*a);
   Real l01 = -na*(Gamma_1*v1 + a);
   Real l02 = -na*Gamma_1*v2;
   Real l03 = -na*Gamma_1*v3;
   Real l04 = na*Gamma_1;
-  Real qa = FAST ? Gamma_1*iasq : Gamma_1/asq;
+  Real qa = FAST ? Gamma_1*iasq : ((XD && AA_XDIV) ? x_div_r(Gamma_1, asq, rasq) : Gamma_1/asq);
   Real l30 = 1.0 - na*Gamma_1*vsq;
   Real l31 = qa*v1, l32 = qa*v2, l33 = qa*v3, l34 = -qa;
   Real l40 = na*(0.5*Gamma_1*vsq - v1*a);
@@ -260,7 +318,7 @@ AA_DEV void flux_roe(const Real ul[6], const Real ur[6], const Real wl[6], const
   if (v1 > ev0) {
     if (u0 <= 0.0) hlle = true;
     else {
-      Real p_inter = FAST ? u4 - q_div_checked(0.5*(sqr(u1) + sqr(u2) + sqr(u3)), u0) : u4 - 0.5*(sqr(u1) + sqr(u2) + sqr(u3))/u0;
+      Real p_inter = FAST ? u4 - q_div_checked(0.5*(sqr(u1) + sqr(u2) + sqr(u3)), u0) : u4 - x_div<XD>(0.5*(sqr(u1) + sqr(u2) + sqr(u3)), u0);
       if (p_inter < 0.0) hlle = true;
     }
   }
@@ -271,12 +329,12 @@ AA_DEV void flux_roe(const Real ul[6], const Real ur[6], const Real wl[6], const
     if (ev4 > v1) {
       if (u0 <= 0.0) hlle = true;
       else {
-      Real p_inter = FAST ? u4 - q_div_checked(0.5*(sqr(u1) + sqr(u2) + sqr(u3)), u0) : u4 - 0.5*(sqr(u1) + sqr(u2) + sqr(u3))/u0;
+      Real p_inter = FAST ? u4 - q_div_checked(0.5*(sqr(u1) + sqr(u2) + sqr(u3)), u0) : u4 - x_div<XD>(0.5*(sqr(u1) + sqr(u2) + sqr(u3)), u0);
       if (p_inter < 0.0) hlle = true;
     }
     }
   }
-  if (hlle) { flux_hlle<NS>(ul, ur, wl, wr, Gamma, Gamma_1, f); return; }
+  if (hlle) { flux_hlle<NS, XD>(ul, ur, wl, wr, Gamma, Gamma_1, f); return; }
 
   Real c0 = 0.5*rmax(fabs(ev0), etah)*aa_[0];
   Real c1 = 0.5*rmax(fabs(v1), etah)*aa_[1];

@@ -182,8 +182,8 @@ AA_DEV void face_work(const DevGrid &g, long m, int i, int j, int k, Real dt, Re
     wr[1] -= dtodx*(phicr - phifc);
   }
   Real ul[6], ur[6];
-  prim_to_cons<NS>(wl, ul, g.Gamma_1);
-  prim_to_cons<NS>(wr, ur, g.Gamma_1);
+  prim_to_cons<NS>(wl, ul, g.Gamma_1, g.rGamma_1);
+  prim_to_cons<NS>(wr, ur, g.Gamma_1, g.rGamma_1);
   if (MODE == MODE_CORR) { face_correct<NS, D, GRAV>(g, m, i, j, k, dt, ul, ur); return; }
   Real f[6];
   flux_roe<NS>(ul, ur, wl, wr, 0.0, g.Gamma, g.Gamma_1, f);
@@ -499,8 +499,8 @@ AA_DEV void cell_finish(const DevGrid &g, long m, const Real q[3], const CellFlu
   constexpr int NV = 5 + NS;
   const long sD = stride<D>(g);
   Real sl[6], sr[6], ul[6], ur[6];
-  prim_to_cons<NS>(wl, sl, g.Gamma_1);
-  prim_to_cons<NS>(wr, sr, g.Gamma_1);
+  prim_to_cons<NS>(wl, sl, g.Gamma_1, g.rGamma_1);
+  prim_to_cons<NS>(wr, sr, g.Gamma_1, g.rGamma_1);
 #pragma unroll
   for (int n = 0; n < 6; n++) { ul[gv<D>(n)] = sl[n]; ur[gv<D>(n)] = sr[n]; }   // to the global frame
 #pragma unroll
@@ -633,8 +633,8 @@ k_correct_all(DevGrid g, Real dt, int kchunk)
         }
         if (k >= kstart - 1) {   // (B) first-pass flux of face k+1 (face_work<MODE_FLUX1>), sweep frame -> global variables
           Real ul[6], ur[6], f[6];
-          prim_to_cons<NS>(wl3, ul, g.Gamma_1);
-          prim_to_cons<NS>(wrN, ur, g.Gamma_1);
+          prim_to_cons<NS>(wl3, ul, g.Gamma_1, g.rGamma_1);
+          prim_to_cons<NS>(wrN, ur, g.Gamma_1, g.rGamma_1);
           flux_roe<NS>(ul, ur, wl3, wrN, 0.0, g.Gamma, g.Gamma_1, f);
 #pragma unroll
           for (int n = 0; n < NV; n++) f3n[gv<2>(n)] = f[n];
@@ -903,6 +903,9 @@ k_update(DevGrid g, const Real *dhalf, Real dt, Order ord)
 #endif
 // operands of one second-pass Riemann problem: the corrected face states (sweep frame) and the 9 etas
 struct FaceIn { Real ul[6], ur[6], eta[9]; };
+#ifndef FU_ABL
+#define FU_ABL 0          // timing experiments only (wrong results): 1 = update operands not loaded, 2 = only the face's own eta
+#endif
 template <int NS, int D>
 AA_DEV void face_load(const DevGrid &g, long m, FaceIn &in)
 {
@@ -910,9 +913,14 @@ AA_DEV void face_load(const DevGrid &g, long m, FaceIn &in)
   constexpr int E1 = (D == 0) ? 1 : 0, E2 = (D == 2) ? 1 : 2;
   const long s1 = stride<E1>(g), s2 = stride<E2>(g);
   const Real *e1 = Ef(g, E1), *e2 = Ef(g, E2);
+  in.eta[8] = Ef(g, D)[m];
+  if (FU_ABL & 2) {
+#pragma unroll
+    for (int n = 0; n < 8; n++) in.eta[n] = in.eta[8];
+  } else {
   in.eta[0] = e1[ml]; in.eta[1] = e1[m]; in.eta[2] = e1[ml + s1]; in.eta[3] = e1[m + s1];
   in.eta[4] = e2[ml]; in.eta[5] = e2[m]; in.eta[6] = e2[ml + s2]; in.eta[7] = e2[m + s2];
-  in.eta[8] = Ef(g, D)[m];
+  }
   load_sweep<D, NS>(LRf(g, D, 0, 0), g.nc, m, in.ul);
   load_sweep<D, NS>(LRf(g, D, 1, 0), g.nc, m, in.ur);
 }
@@ -925,7 +933,7 @@ AA_DEV void face_solve(const DevGrid &g, const FaceIn &in, Real f[6])
   Real wl[6], wr[6];
   cons_to_prim<NS>(in.ul, wl, g.Gamma_1);
   cons_to_prim<NS>(in.ur, wr, g.Gamma_1);
-  flux_roe<NS, false>(in.ul, in.ur, wl, wr, etah, g.Gamma, g.Gamma_1, f);      // (see flux_roe: faster without the AA_FAST_DIV forms here)
+  flux_roe<NS, false, false>(in.ul, in.ur, wl, wr, etah, g.Gamma, g.Gamma_1, f);      // (see flux_roe: faster without the AA_FAST_DIV and AA_XDIV forms here)
 }
 template <int NS, int D>
 AA_DEV void face_flux2(const DevGrid &g, long m, Real f[6])
@@ -1082,12 +1090,12 @@ k_flux2_update(DevGrid g, const Real *dhalf, Real dt, int kchunk, KeepPlanes kp,
       for (int n = 0; n < NV; n++) f3lo[n] = f3[n];
       Real u[6];
 #pragma unroll
-      for (int v = 0; v < NV; v++) u[v] = Uf(g, v)[m];
+      for (int v = 0; v < NV; v++) u[v] = (FU_ABL & 1) ? f3lo[v] : Uf(g, v)[m];
       // (the mask byte with the zone's other operands, not behind the stores of U: a load that is consumed at once waits
       //  for everything issued before it, i.e. the wave sat out the six stores' round trip in every plane)
       unsigned char pinned = 0;
-      if (CFL && pinmask) pinned = pinmask[m];
-      if (GRAV) {   // :2741-2782, with the mass fluxes (sweep component 0) of the faces just solved
+      if (CFL && pinmask && !(FU_ABL & 1)) pinned = pinmask[m];
+      if (GRAV && !(FU_ABL & 1)) {   // :2741-2782, with the mass fluxes (sweep component 0) of the faces just solved
         const Real phic = Pf(g, 0)[m], dh = dhalf[m];
         { const Real phir = Pf(g, 1)[m + 1], phil = Pf(g, 1)[m];
           u[1] -= dtodx[0]*(phir - phil)*dh;
@@ -1184,8 +1192,8 @@ k_vl_flux1(DevGrid g)
   Real u[6], wl[6], wr[6], ul[6], ur[6], f[6];
   load_sweep<D, NS>(g.U, g.nc, m - s, u); cons_to_prim<NS>(u, wl, g.Gamma_1);
   load_sweep<D, NS>(g.U, g.nc, m, u);     cons_to_prim<NS>(u, wr, g.Gamma_1);
-  prim_to_cons<NS>(wl, ul, g.Gamma_1);                     // the reference round-trips through W (:166-169)
-  prim_to_cons<NS>(wr, ur, g.Gamma_1);
+  prim_to_cons<NS>(wl, ul, g.Gamma_1, g.rGamma_1);                     // the reference round-trips through W (:166-169)
+  prim_to_cons<NS>(wr, ur, g.Gamma_1, g.rGamma_1);
   flux_roe<NS>(ul, ur, wl, wr, 0.0, g.Gamma, g.Gamma_1, f);
   store_sweep<D, NS>(Ff(g, D, 0), g.nc, m, f);
 }
@@ -1215,7 +1223,7 @@ AA_DEV void vl_state(const DevGrid &g, long m, VlState &q)
     Real us[6], ws[6], ub[6];
     us[0] = u[0]; us[1] = u[1 + D]; us[2] = u[1 + (D + 1) % 3]; us[3] = u[1 + (D + 2) % 3]; us[4] = u[4]; us[5] = u[5];
     cons_to_prim<NS>(us, ws, g.Gamma_1);
-    prim_to_cons<NS>(ws, ub, g.Gamma_1);
+    prim_to_cons<NS>(ws, ub, g.Gamma_1, g.rGamma_1);
     q.p[D] = ws[4]; q.e[D] = ub[4];
     if (D == 0) { q.w[0] = ws[0]; q.w[1] = ws[1]; q.w[2] = ws[2]; q.w[3] = ws[3]; q.w[4] = 0.0; q.w[5] = ws[5]; }
   }
@@ -1547,6 +1555,16 @@ __global__ void k_test_fluxes(Real Gamma, int n, const Real *Ul, const Real *Ur,
   flux_roe<NS>(ul, ur, wl, wr, eta[t], Gamma, Gamma - 1.0, f);
   for (int v = 0; v < NV; v++) F[(long)t*NV + v] = f[v];
 }
+// x_div / x_sqrt / x_div_r (hydro_dev.h) beside hipcc's own a/b and sqrt(a): out = [5][n]
+__global__ void k_test_xdiv(int n, const Real *a, const Real *b, Real *out)
+{
+  const int t = blockIdx.x*blockDim.x + threadIdx.x;
+  if (t >= n) return;
+  const Real x = a[t], y = b[t];
+  out[t] = x_div(x, y); out[(long)n + t] = x/y;
+  out[2L*n + t] = x_sqrt(x); out[3L*n + t] = sqrt(x);
+  out[4L*n + t] = x_div_r(x, y, 1.0/y);                 // with the correctly rounded reciprocal (what the host supplies for gamma-1)
+}
 template <int NS>
 __global__ void k_test_lr_ppm(Real Gamma, int n, const Real *W, Real dt, Real dx, int il, int iu, Real *Wl, Real *Wr)
 {
@@ -1574,6 +1592,8 @@ __global__ void k_test_lr(Real Gamma, int n, const Real *W, Real dt, Real dx, in
 // =============================================================================================
 // host-side launchers
 // =============================================================================================
+void launch_test_xdiv(int n, const Real *a, const Real *b, Real *out, hipStream_t st)
+{ hipLaunchKernelGGL(k_test_xdiv, dim3((n + 255)/256), dim3(256), 0, st, n, a, b, out); }
 static inline unsigned nblk(long n, int b) { return (unsigned)((n + b - 1)/b); }
 static Order zone_order()
 {

@@ -114,6 +114,7 @@ def load(strict: bool | None = None) -> C.CDLL:
         "aa_test_lr_states": (I, [I, D, I, dp, D, D, I, I, dp, dp]),
         "aa_test_lr_states_ppm": (I, [I, D, I, dp, D, D, I, I, dp, dp]),
         "aa_test_explog": (I, [I, dp, dp, dp]),
+        "aa_test_xdiv": (I, [I, dp, dp, dp]),
         "aa_history": (I, [P, dp]),
         "aa_profile_enable": (I, [P, I]), "aa_profile_reset": (I, [P]), "aa_profile_count": (I, [P]),
         "aa_profile_name": (C.c_char_p, [P, I]), "aa_profile_get": (I, [P, I, dp, llp]),

@@ -219,6 +219,9 @@ int aa_test_lr_states(int nscal, double gamma, int n, const double *W, double dt
 int aa_test_lr_states_ppm(int nscal, double gamma, int n, const double *W, double dt, double dx,
                           int il, int iu, double *Wl, double *Wr);      /* lr_states_ppm.c:91  */
 
+int aa_test_xdiv(int n, const double *a, const double *b, double *out);  /* csrc/hydro_dev.h x_div / x_sqrt beside the compiler's
+                                                                            a/b and sqrt(a): out[5][n] = x_div, a/b, x_sqrt,
+                                                                            sqrt, x_div_r(a, b, 1/b) */
 int aa_test_explog(int n, const double *x, double *y_exp, double *y_log);  /* the exp / ln of csrc/ion_pass.hip
                                                                              (n a multiple of 4): exp(x), ln|x|  */
 

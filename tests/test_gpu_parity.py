@@ -87,6 +87,36 @@ def run_pair(aa, lib, problem, nx, nsteps, strict, integrator="ctu"):
     return o, g, nv, trace
 
 
+@pytest.mark.parametrize("strict", [True, False])
+def test_scaling_free_quotient_and_square_root_are_the_ieee_ones(lib, strict):
+    """hydro_dev.h x_div / x_sqrt / x_div_r (the compiler's division and square-root sequences without their range
+    scaling) against hipcc's own a/b and sqrt(a) on the device AND against numpy's correctly rounded ones, bit for bit:
+    operands over 400 decades (far beyond what a run holds), zero numerators, the deck's gamma - 1 as a
+    loop-invariant denominator with the host's reciprocal."""
+    L = lib.load(strict)
+    rng = np.random.default_rng(5)
+    n = 1 << 20
+    a = np.concatenate([10.0 ** rng.uniform(-200, 200, n) * rng.uniform(1.0, 10.0, n), rng.uniform(0.5, 2.0, n),
+                        np.zeros(64), 10.0 ** rng.uniform(-30, 30, n)])
+    b = np.concatenate([10.0 ** rng.uniform(-200, 200, n) * rng.uniform(1.0, 10.0, n), rng.uniform(0.5, 2.0, n),
+                        10.0 ** rng.uniform(-30, 30, 64), rng.choice(np.array([5.0 / 3.0 - 1.0, 1.4 - 1.0, 1.1 - 1.0, 1.0001 - 1.0]), n)])
+    keep = (np.abs(np.log10(np.maximum(a, 1e-300) / b)) < 290) | (a == 0)        # quotients away from the ends of the range
+    a = np.ascontiguousarray(a[keep]); b = np.ascontiguousarray(b[keep])
+    out = np.zeros((5, len(a)))
+    assert L.aa_test_xdiv(len(a), _dp(a), _dp(b), _dp(out)) == 0
+    bits = lambda x: x.view(np.int64)
+    assert np.array_equal(bits(out[0]), bits(out[1])), "x_div differs from the compiler's a/b"
+    assert np.array_equal(bits(out[0]), bits(a / b)), "x_div differs from the IEEE quotient"
+    assert np.array_equal(bits(out[4]), bits(a / b)), "x_div_r with the correctly rounded reciprocal differs from the IEEE quotient"
+    pos = a > 0
+    assert np.array_equal(bits(out[2][pos]), bits(out[3][pos])), "x_sqrt differs from the compiler's sqrt"
+    assert np.array_equal(bits(out[2][pos]), bits(np.sqrt(a[pos]))), "x_sqrt differs from the IEEE square root"
+    # NaN in, NaN out
+    z = np.array([np.nan, 1.0, -1.0, 4.0]); w = np.array([2.0, np.nan, 3.0, 2.0]); o = np.zeros((5, 4))
+    assert L.aa_test_xdiv(4, _dp(z), _dp(w), _dp(o)) == 0
+    assert np.isnan(o[0][0]) and np.isnan(o[0][1]) and np.isnan(o[2][0]) and np.isnan(o[2][2]) and o[0][3] == 2.0 and o[2][3] == 2.0
+
+
 @pytest.mark.parametrize("nx,nsteps", [((16, 16, 16), 5), ((12, 20, 16), 4), ((40, 24, 32), 3)])
 def test_blast_hydro_bitwise_strict(aa, lib, nx, nsteps):
     """Hydro only (CTU + PLM + Roe/HLLE + H-correction, periodic BCs, CFL): the strict build
