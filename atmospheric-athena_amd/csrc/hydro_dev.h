@@ -494,14 +494,27 @@ AA_DEV void limited_slopes(const Real wm[6], const Real w[6], const Real wp[6], 
 {
   constexpr int NV = 5 + NS;
   Real d = w[0];
+#if AA_FD_PLM      // (default build: the reciprocal forms of plm_cell)
+  const Real id = q_rcp(d);
+  Real asq = (Gamma*w[4])*id;
+  const Real ia = q_rsqrt(asq), iasq = ia*ia;
+  Real a = asq*ia;
+  Real r10 = -a*id, r14 = -r10;
+  Real l01 = -0.5*d*ia, l04 = 0.5*iasq, l14 = -iasq, l41 = -l01;
+#else
   Real asq = (Gamma*w[4])/d, a = sqrt(asq);
   Real r10 = -a/d, r14 = -r10;
   Real l01 = -0.5*d/a, l04 = 0.5/asq, l14 = -1.0/asq, l41 = -l01;
+#endif
   Real dWc[6], dWl[6], dWr[6], dWg[6];
 #pragma unroll
   for (int n = 0; n < NV; n++) {
     dWc[n] = wp[n] - wm[n]; dWl[n] = w[n] - wm[n]; dWr[n] = wp[n] - w[n];
+#if AA_FD_PLM
+    dWg[n] = (dWl[n]*dWr[n] > 0.0) ? 2.0*dWl[n]*dWr[n]*q_rcp(dWl[n] + dWr[n]) : 0.0;
+#else
     dWg[n] = (dWl[n]*dWr[n] > 0.0) ? 2.0*dWl[n]*dWr[n]/(dWl[n] + dWr[n]) : 0.0;
+#endif
   }
   Real dac[6], dal[6], dar[6], dag[6];
 #define AA_PROJ(o, x) { o[0] = l01*x[1]; o[0] += l04*x[4]; o[1] = x[0]; o[1] += l14*x[4]; \
@@ -539,20 +552,33 @@ AA_DEV void ppm_cell(const Real wm[6], const Real w[6], const Real wp[6], const 
   constexpr Real FOUR_3RDS = 1.333333333333333, TWO_3RDS = 0.6666666666666667;     // defs.h.in:158-159
   const Real gamma_curv = 0.0, qxx1 = 0.0, qxx2 = 0.0;
   Real d = w[0], vx = w[1];
+#if AA_FD_PLM      // (default build: the reciprocal forms of plm_cell; the sixths as products)
+  const Real id = q_rcp(d);
+  Real asq = (Gamma*w[4])*id;
+  const Real ia = q_rsqrt(asq), iasq = ia*ia;
+  Real a = asq*ia;
+  Real ev0 = vx - a, ev4 = vx + a;
+  Real r10 = -a*id, r14 = -r10;
+  Real l01 = -0.5*d*ia, l04 = 0.5*iasq, l14 = -iasq, l41 = -l01;
+#define AA_SIXTH(x) ((x)*(1.0/6.0))
+#else
   Real asq = (Gamma*w[4])/d, a = sqrt(asq);
   Real ev0 = vx - a, ev4 = vx + a;
   Real r10 = -a/d, r14 = -r10;
   Real l01 = -0.5*d/a, l04 = 0.5/asq, l14 = -1.0/asq, l41 = -l01;
+#define AA_SIXTH(x) ((x)/6.0)
+#endif
   Real Wlv[6], Wrv[6], dW[6], W6[6];
 #pragma unroll
   for (int n = 0; n < 5; n++) {
-    Wlv[n] = 0.5*(w[n] + wm[n]) - (D0[n] - Dm[n])/6.0;
-    Wrv[n] = 0.5*(wp[n] + w[n]) - (Dp[n] - D0[n])/6.0;
+    Wlv[n] = 0.5*(w[n] + wm[n]) - AA_SIXTH(D0[n] - Dm[n]);
+    Wrv[n] = 0.5*(wp[n] + w[n]) - AA_SIXTH(Dp[n] - D0[n]);
   }
   if (NS) {
     Wlv[5] = Wrv[0];
-    Wrv[5] = 0.5*(wp[5] + w[5]) - (Dp[5] - Dp[0])/6.0;
+    Wrv[5] = 0.5*(wp[5] + w[5]) - AA_SIXTH(Dp[5] - Dp[0]);
   }
+#undef AA_SIXTH
 #pragma unroll
   for (int n = 0; n < NV; n++) {
     Real qa = (Wrv[n] - w[n])*(w[n] - Wlv[n]);
