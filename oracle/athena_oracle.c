@@ -47,6 +47,8 @@ long orc_dbg_hlle = 0, orc_dbg_supersonic = 0;
 
 struct OrcSim {
   OrcParams p;
+  int cool;              /* 0: CoolingFunc == NULL, 1: KoyInut (microphysics/cool.c:48) */
+  Real *phalf;
   int N[3], is, ie, js, je, ks, ke;
   Real dx[3], rootdx[3];
   Real Gamma, Gamma_1;
@@ -486,6 +488,30 @@ static void lr_states_ppm(const P1 *W, Real dt, Real dx, int il, int iu, P1 *Wl,
 }
 
 /* ------------------------------------------------------------------------------------ */
+/* microphysics/cool.c:34-86 KoyInut(): analytic fit to the cooling of the diffuse ISM (Koyama & Inutsuka 2002, eq. 4); the
+ * only cooling function the reference ships (enrolled as CoolingFunc = KoyInut, prob/ti.c:474).  cgs constants :35-38. */
+static Real cool_koyinut(Real dens, Real Press, Real dt, Real Gamma_1)
+{
+  const Real mbar = (1.37)*(1.6733e-24), kb = 1.380658e-16, HeatRate = 2.0e-26, Tmin = 10;
+  Real n, coolrate = 0.0, T, coolratepp, MaxdT, dT, Teq, logn, lognT;
+  n = dens/mbar;
+  logn = log10(n);
+  T = MAXR((Press/(n*kb)), Tmin);
+  Teq = Tmin;
+  coolratepp = HeatRate*
+   (n*(1.0e7*exp(-1.184e5/(T+1000.)) + 0.014*sqrt(T)*exp(-92.0/T)) - 1.0);
+  dT = coolratepp*dt*Gamma_1/kb;
+  if ((T-dT) <= 185.0){
+    lognT = 3.9247499 - 1.8479378*logn + 1.5335032*logn*logn
+     -0.47665872*pow(logn,3) + 0.076789136*pow(logn,4)-0.0049052587*pow(logn,5);
+    Teq = pow(10.0,lognT) / n;
+  }
+  MaxdT = kb*(T-Teq)/(dt*Gamma_1);
+  coolrate = MINR(coolratepp,MaxdT);
+  return n*coolrate;
+}
+void orc_set_cooling(OrcSim *s, int kind) { s->cool = kind; }
+
 /* static gravitational potential: prob/ioniz_sphere.c:316-330 (PlanetPot, non-shearing-box) */
 
 static Real potential(const OrcSim *s, Real x1, Real x2, Real x3)
@@ -580,6 +606,14 @@ void orc_integrate(OrcSim *s)
           Wr[c].Vx -= dtodx[d]*(phicr - phifc);
         }
       }
+      if (s->cool) {                                                   /* :359-368, :662-671, :846-855 */
+        for (c = l[d]+1; c <= u[d]; c++) {
+          Real coolfl = cool_koyinut(Wl[c].d, Wl[c].P, (0.5*dt), Gamma_1);
+          Real coolfr = cool_koyinut(Wr[c].d, Wr[c].P, (0.5*dt), Gamma_1);
+          Wl[c].P -= 0.5*dt*Gamma_1*coolfl;
+          Wr[c].P -= 0.5*dt*Gamma_1*coolfr;
+        }
+      }
       for (c = l[d]+1; c <= u[d]; c++) {                               /* :515-524 */
         C1 ul = prim_to_cons(&Wl[c], Gamma_1, nscal), ur = prim_to_cons(&Wr[c], Gamma_1, nscal), f;
         size_t m = base + c*str[d];
@@ -630,13 +664,41 @@ void orc_integrate(OrcSim *s)
   }
 
   /* === Step 8a: d^{n+1/2} (:2104-2125) === */
-  if (grav) {
+  if (grav || s->cool) {
     for (k = l[2]+1; k <= u[2]-1; k++) for (j = l[1]+1; j <= u[1]-1; j++) for (i = l[0]+1; i <= u[0]-1; i++) {
       size_t m = IDX(s,k,j,i);
       s->dhalf[m] = s->U[m].d
         - q[0]*(s->F[0][m + str[0]].d - s->F[0][m].d)
         - q[1]*(s->F[1][m + str[1]].d - s->F[1][m].d)
         - q[2]*(s->F[2][m + str[2]].d - s->F[2][m].d);
+    }
+  }
+
+  /* === Step 8b: P^{n+1/2}, needed with cooling (:2133-2266) === */
+  if (s->cool) {
+    for (k = l[2]+1; k <= u[2]-1; k++) for (j = l[1]+1; j <= u[1]-1; j++) for (i = l[0]+1; i <= u[0]-1; i++) {
+      size_t m = IDX(s,k,j,i);
+      Real Mh[3], Eh;
+      for (e = 0; e < 3; e++)
+        Mh[e] = s->U[m].M[e]
+          - q[0]*(s->F[0][m + str[0]].M[e] - s->F[0][m].M[e])
+          - q[1]*(s->F[1][m + str[1]].M[e] - s->F[1][m].M[e])
+          - q[2]*(s->F[2][m + str[2]].M[e] - s->F[2][m].M[e]);
+      Eh = s->U[m].E
+        - q[0]*(s->F[0][m + str[0]].E - s->F[0][m].E)
+        - q[1]*(s->F[1][m + str[1]].E - s->F[1][m].E)
+        - q[2]*(s->F[2][m + str[2]].E - s->F[2][m].E);
+      if (grav) {
+        Real x[3], phir, phil;
+        cc_pos(s, i, j, k, x);
+        for (e = 0; e < 3; e++) {
+          phir = phi_at(s, x, e, 0.5, e, 0.0);
+          phil = phi_at(s, x, e, -0.5, e, 0.0);
+          Mh[e] -= q[e]*(phir-phil)*s->U[m].d;
+        }
+      }
+      s->phalf[m] = Eh - 0.5*(Mh[0]*Mh[0] + Mh[1]*Mh[1] + Mh[2]*Mh[2])/s->dhalf[m];
+      s->phalf[m] *= Gamma_1;
     }
   }
 
@@ -692,6 +754,15 @@ void orc_integrate(OrcSim *s)
         s->U[m].M[e] -= dtodx[e]*(phir-phil)*s->dhalf[m];
         s->U[m].E -= dtodx[e]*(s->F[e][m].d*(phic - phil) + s->F[e][m + str[e]].d*(phir - phic));
       }
+    }
+  }
+
+  /* === Step 11c: optically thin cooling for the full step (:2943-2953) === */
+  if (s->cool) {
+    for (k = s->ks; k <= s->ke; k++) for (j = s->js; j <= s->je; j++) for (i = s->is; i <= s->ie; i++) {
+      size_t m = IDX(s,k,j,i);
+      Real coolf = cool_koyinut(s->dhalf[m], s->phalf[m], dt, Gamma_1);
+      s->U[m].E -= dt*coolf;
     }
   }
 
@@ -1834,6 +1905,7 @@ OrcSim *orc_create(const OrcParams *p)
     s->F[d] = (Cons*)calloc(nc, sizeof(Cons));  s->eta[d] = (Real*)calloc(nc, sizeof(Real));
   }
   s->dhalf = (Real*)calloc(nc, sizeof(Real));
+  s->phalf = (Real*)calloc(nc, sizeof(Real));
   s->EdgeFlux = (Real*)calloc((size_t)(p->Nx[0]+1)*(p->Nx[1]+1)*(p->Nx[2]+1), sizeof(Real));
   if (p->ion) {
     Real a1, a2, a3, maxdx;
@@ -1855,7 +1927,7 @@ void orc_destroy(OrcSim *s)
 {
   int d;
   if (!s) return;
-  free(s->U); free(s->EdgeFlux); free(s->dhalf);
+  free(s->U); free(s->EdgeFlux); free(s->dhalf); free(s->phalf);
   for (d = 0; d < 3; d++) { free(s->Ul[d]); free(s->Ur[d]); free(s->F[d]); free(s->eta[d]); }
   free(s->ph_rate); free(s->edot); free(s->nHdot); free(s->e_init); free(s->e_th_init); free(s->x_init);
   free(s->last_sign); free(s->sign_count);

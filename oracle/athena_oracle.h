@@ -55,6 +55,7 @@ int     orc_get_nstep(const OrcSim *s);
 void    orc_set_time(OrcSim *s, double t);
 void    orc_set_dt(OrcSim *s, double dt);
 void    orc_set_nstep(OrcSim *s, int n);
+void    orc_set_cooling(OrcSim *s, int kind);   /* CoolingFunc: 0 = NULL, 1 = KoyInut (microphysics/cool.c:48); CTU integrator only */
 
 /* problem generators (prob/ifront.c, prob/ioniz_sphere.c, prob/blast.c, prob/shkset1d.c) */
 void orc_problem_ifront(OrcSim *s, double n_H, double cs, double flux);

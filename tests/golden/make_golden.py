@@ -10,7 +10,7 @@ through oracle/_ref/libref_<cfg>.so to produce function-level known-answer vecto
 
 Fixtures are DATA (arrays + the scalar trace of each run); no reference text is stored.
 
-usage: python tests/golden/make_golden.py [whole] [shk] [dev] [kernels] [ppm] [smr] [hst] [ray]
+usage: python tests/golden/make_golden.py [whole] [shk] [dev] [kernels] [ppm] [smr] [hst] [ray] [cool]
 """
 import ctypes as C
 import os
@@ -137,6 +137,26 @@ def rayplane_runs():
                                  ["job/maxout=3", "output3/out_fmt=rst", "output3/dt=1e300", "output1/dt=1e300", "output2/dt=1e300",
                                   f"problem/raydir={d}"], "ifront", 1, True)
         save(f"rayplane_dir{-d}_{nx[0]}x{nx[1]}x{nx[2]}_n{nlim}", f, l, it, nx, [f"raydir={d}"])
+    shutil.rmtree(tmp)
+
+
+def cooling_runs():
+    """Optically thin cooling (integrate_3d_ctu.c Steps 1c-3c, 8b, 11c with CoolingFunc = KoyInut, microphysics/cool.c:48): our own
+    problem file tests/fixtures/cool_pattern.c (diffuse gas in cgs units, density / temperature / velocity by integer patterns of
+    the zone indices, 150 K ... 6000 K) linked into the reference's blast configuration; the same state without cooling beside
+    it, so that the tests can show the terms matter."""
+    deck0 = open(os.path.join(REF, "tst/3D-hydro/athinput.blast")).read()
+    tmp = tempfile.mkdtemp(prefix="golden_deck_")
+    deck = os.path.join(tmp, "athinput.coolpat")
+    open(deck, "w").write(re.sub(r"(?m)^(radius\s*=.*)$", r"\1\nn0 = 30.0\nT0 = 2500.0\nv0 = 2.0e4\ncool = 1", deck0, count=1))
+    box = []
+    for e in (1, 2, 3):
+        box += [f"domain1/x{e}min=-1.0e18", f"domain1/x{e}max=1.0e18"]
+    for cool, nx, nlim in ((1, (16, 12, 10), 4), (0, (16, 12, 10), 4), (1, (12, 8, 20), 3)):
+        over = box + ["time/tlim=1.0e30", f"problem/cool={cool}"]
+        f, l, it = run_reference("coolpat", deck, nx, nlim,
+                                 ["job/num_domains=1", "job/maxout=1", "output1/out_fmt=rst", "output1/dt=1e300"] + over, "Blast", 0, False)
+        save(f"coolpat_c{cool}_{nx[0]}x{nx[1]}x{nx[2]}_n{nlim}", f, l, it, nx, over + ["n0=30.0", "T0=2500.0", "v0=2.0e4"])
     shutil.rmtree(tmp)
 
 
@@ -403,7 +423,9 @@ def kernel_vectors():
 if __name__ == "__main__":
     if not os.path.isdir(REF) or not os.path.isdir(REFBIN):
         sys.exit("needs /root/reference and oracle/_ref (make -C oracle ref)")
-    which = sys.argv[1:] or ["whole", "shk", "dev", "kernels", "ppm", "smr", "hst", "ray"]
+    which = sys.argv[1:] or ["whole", "shk", "dev", "kernels", "ppm", "smr", "hst", "ray", "cool"]
+    if "cool" in which:
+        cooling_runs()
     if "ray" in which:
         rayplane_runs()
     if "hst" in which:

@@ -64,6 +64,7 @@ def lib():
         L.orc_problem_blast.argtypes = [P, D, D, D, D, D]
         L.orc_problem_shkset1d.argtypes = [P, dp, dp, C.c_int]
         L.orc_add_radplane.argtypes = [P, C.c_int, D]
+        L.orc_set_cooling.argtypes = [P, C.c_int]; L.orc_set_cooling.restype = None
         for f in ("orc_start", "orc_bvals", "orc_bvals_ionrad", "orc_new_dt", "orc_integrate",
                   "orc_userwork", "orc_ion_begin"):
             getattr(L, f).argtypes = [P]; getattr(L, f).restype = None
@@ -174,6 +175,7 @@ class Sim:
     nstep = property(lambda s: s.L.orc_get_nstep(s.h), lambda s, v: s.L.orc_set_nstep(s.h, v))
 
     def add_radplane(self, dir, flux): self.L.orc_add_radplane(self.h, int(dir), float(flux))
+    def set_cooling(self, kind=1): self.L.orc_set_cooling(self.h, int(kind))     # CoolingFunc = KoyInut (CTU only)
     def start(self): self.L.orc_start(self.h); return self
     def step(self): return self.L.orc_step(self.h)
     def bvals(self): self.L.orc_bvals(self.h)
@@ -233,6 +235,42 @@ def make_rayplane_sim(nx, raydir):
     r = s.grid.run
     s.active[...] = rayplane_pattern(nx, r.prob["n_H"], r.ionp["m_H"], r.prob["cs"], r.gamma)
     s.add_radplane(raydir, r.prob["flux"])
+    return s
+
+
+def cool_pattern(nx, n0, T0, v0, gamma):
+    """Initial state of tests/fixtures/cool_pattern.c on the active zones [k][j][i][6]: diffuse gas in cgs units, number
+    density, temperature and velocity by fixed integer patterns of the zone indices (the same expressions, operation by
+    operation)."""
+    mbar = 1.37 * 1.6733e-24; kb = 1.380658e-16
+    c, b, a = np.meshgrid(np.arange(nx[2]), np.arange(nx[1]), np.arange(nx[0]), indexing="ij")
+    n = n0 * (0.5 + 0.25 * ((7 * a + 3 * b + 5 * c) % 11).astype(np.float64))
+    T = T0 * (0.06 + 0.4 * ((5 * a + 7 * b + 3 * c) % 7).astype(np.float64))
+    rho = n * mbar
+    v1 = v0 * (((3 * a + 5 * b + 7 * c) % 5).astype(np.float64) - 2.0)
+    v2 = v0 * (((a + 2 * b + 3 * c) % 7).astype(np.float64) - 3.0)
+    v3 = v0 * (((2 * a + b + 4 * c) % 3).astype(np.float64) - 1.0)
+    U = np.zeros(rho.shape + (6,))
+    U[..., 0] = rho; U[..., 1] = rho * v1; U[..., 2] = rho * v2; U[..., 3] = rho * v3
+    U[..., 4] = n * kb * T / (gamma - 1.0) + 0.5 * rho * (v1 * v1 + v2 * v2 + v3 * v3)
+    return U
+
+
+def coolpat_setup(g):
+    """(deck overrides, n0, T0, v0, cool) of a coolpat_* golden fixture"""
+    kv = dict(str(o).split("=") for o in g["overrides"])
+    ov = [f"domain1/Nx{d + 1}={int(g['nx'][d])}" for d in range(3)]
+    ov += [f"{k}={v}" for k, v in kv.items() if "/" in k and k != "problem/cool"]
+    return ov, float(kv["n0"]), float(kv["T0"]), float(kv["v0"]), int(kv["problem/cool"])
+
+
+def make_coolpat_sim(g):
+    """The oracle set up like the reference built on tests/fixtures/cool_pattern.c: blast deck (hydro, no scalar), the
+    pattern state, CoolingFunc = KoyInut where the fixture had it."""
+    ov, n0, T0, v0, cool = coolpat_setup(g)
+    s = make_sim("blast", ov)
+    s.active[...] = cool_pattern(g["nx"], n0, T0, v0, s.grid.run.gamma)
+    s.set_cooling(cool)
     return s
 
 

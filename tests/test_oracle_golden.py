@@ -60,6 +60,24 @@ def _rayplane(name, g):
     assert _same(s.edgeflux, g["edgeflux"])
 
 
+def _coolpat(name, g):
+    """Optically thin cooling (integrate_3d_ctu.c Steps 1c-3c, 8b, 11c; CoolingFunc = KoyInut, microphysics/cool.c:48) from our own
+    problem file (tests/fixtures/cool_pattern.c) run by the reference, with and without the cooling function enrolled."""
+    s = orc.make_coolpat_sim(g)
+    assert _same(s.active[..., :5], g["U0"][..., :5]), "initial condition"
+    s.start()
+    assert s.dt == float(g["dt0"])
+    for _ in range(int(g["nstep"])): s.step()
+    assert s.time == float(g["time"]) and s.dt == float(g["dt"])
+    assert _same(s.active[..., :5], g["U"][..., :5])
+
+
+def test_cooling_fixtures_differ_from_the_run_without():
+    a = np.load(os.path.join(GOLD, "coolpat_c1_16x12x10_n4.npz")); b = np.load(os.path.join(GOLD, "coolpat_c0_16x12x10_n4.npz"))
+    assert _same(a["U0"], b["U0"]) and float(a["time"]) != float(b["time"])
+    assert np.abs(a["U"][..., 4] / b["U"][..., 4] - 1).max() > 1e-2          # the cooling terms move the energy by per cent
+
+
 RUNS = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLD, "*_n[0-9]*.npz")))
 
 
@@ -68,6 +86,8 @@ def test_whole_run_bitwise(name):
     g = np.load(os.path.join(GOLD, name + ".npz"))
     if name.startswith("rayplane"):
         return _rayplane(name, g)
+    if name.startswith("coolpat"):
+        return _coolpat(name, g)
     prob = name.rsplit("_", 2)[0]
     integrator = "ctu"
     order = 2
