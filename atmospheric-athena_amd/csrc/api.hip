@@ -195,6 +195,7 @@ void aa_destroy(aa_grid *g)
   if (g->pin_idx) hipFree(g->pin_idx);
   if (g->pin_val) hipFree(g->pin_val);
   if (g->pin_mask) hipFree(g->pin_mask);
+  if (g->d.phalf) hipFree(g->d.phalf);
   if (g->own_stream) hipStreamDestroy(g->st);
   delete g;
 }
@@ -331,6 +332,25 @@ int aa_set_static_grav_pot(aa_grid *g, aa_gravpot_fn fn)
   std::vector<double> t[4];
   aa_eval_grav_tables(g->p, dx, N1, N2, N3, fn, t);
   return aa_set_static_grav_tables(g, t[0].data(), t[1].data(), t[2].data(), t[3].data());
+}
+
+// globals.h:25 CoolingFunc.  The reference calls the enrolled function per state on the host; on the device the function has to
+// be one the library carries: AA_COOL_KOYINUT = KoyInut (microphysics/cool.c:48), the one the reference ships.  The CTU
+// integrator then runs the second compilation of its kernels (namespace aa_cool: hydro_kernels.hip with -DAA_COOLING=1) and
+// keeps P^{n+1/2} beside d^{n+1/2}.  The van Leer integrator of the reference has no cooling terms (integrate_3d_vl.c).
+int aa_set_cooling(aa_grid *g, int kind)
+{
+  if (kind != AA_COOL_NONE && kind != AA_COOL_KOYINUT) return fail(-1, "[aa_set_cooling]: kind=%d: only AA_COOL_NONE and AA_COOL_KOYINUT", kind);
+  if (kind && g->p.integrator != 0) return fail(-1, "[aa_set_cooling]: the van Leer integrator has no cooling terms in the reference (integrate_3d_vl.c)");
+  if (!g->slab.empty() || g->link) return slabs_set_cooling(g, kind);
+  g->inner_swept = false;
+  if (kind && !g->d.phalf) {
+    HIPCHK(hipMalloc(&g->d.phalf, (size_t)g->d.nc*sizeof(Real)));
+    HIPCHK(hipMemsetAsync(g->d.phalf, 0, (size_t)g->d.nc*sizeof(Real), g->st));
+    g->bytes += (long long)g->d.nc*sizeof(Real);
+  }
+  g->cool = kind;
+  return 0;
 }
 
 int aa_set_pinned_cells(aa_grid *g, long long n, const long long *index, const double *values)
@@ -487,13 +507,15 @@ static bool x3_fused(const aa_grid *g)      // default: always (round 3; until t
 // halo, unpacks it and calls aa_integrate_3d_ctu, which then sweeps only the four ghost planes in x1 / x2: the messages
 // travel under ~10 ms of kernels at 512^3.  Same bits as without the call.  Does nothing (returns 0) where the split
 // does not apply: composite Grids, third order (the slope arrays come first), the unfused correct / update chains, VL.
+// the kernels of a run with a cooling function are the second compilation of hydro_kernels.hip (namespace aa_cool)
+#define HL(f) (g->cool ? aa_cool::f : aa::f)
 int aa_integrate_begin(aa_grid *g)
 {
   if (!g->slab.empty() || g->p.integrator != 0 || g->d.slope || !g->correct_all || !g->fused_update || g->inner_swept) return 0;
   const DevGrid &d = g->d; const int ns = g->p.nscal; const Real dt = g->dt;
   const int nk = d.ke - d.ks + 1;
-  { Scope s(g, "sweep_x2"); launch_sweep(d, ns, 1, dt, g->grav, g->st, 2, nk); }
-  { Scope s(g, "sweep_x1"); launch_sweep(d, ns, 0, dt, g->grav, g->st, 2, nk); }
+  { Scope s(g, "sweep_x2"); HL(launch_sweep)(d, ns, 1, dt, g->grav, g->st, 2, nk); }
+  { Scope s(g, "sweep_x1"); HL(launch_sweep)(d, ns, 0, dt, g->grav, g->st, 2, nk); }
   g->inner_swept = true;
   g->inner_dt = dt;
   HIPCHK(hipGetLastError());
@@ -509,42 +531,43 @@ int aa_integrate_3d_ctu(aa_grid *g)
     if (g->inner_dt != dt) return fail(-1, "[aa_integrate_3d_ctu]: dt changed after aa_integrate_begin");
     g->inner_swept = false;
     const int nk = d.ke - d.ks + 1;
-    { Scope s(g, "sweep_x2"); launch_sweep(d, ns, 1, dt, g->grav, g->st, 0, 2); launch_sweep(d, ns, 1, dt, g->grav, g->st, 2 + nk, 2); }
-    { Scope s(g, "sweep_x1"); launch_sweep(d, ns, 0, dt, g->grav, g->st, 0, 2); launch_sweep(d, ns, 0, dt, g->grav, g->st, 2 + nk, 2); }
-    if (!x3_fused(g)) { Scope s(g, "sweep_x3"); launch_sweep(d, ns, 2, dt, g->grav, g->st); }
-    { Scope s(g, "correct_all"); launch_correct_all(d, ns, dt, g->grav, x3_fused(g), g->st); }
+    { Scope s(g, "sweep_x2"); HL(launch_sweep)(d, ns, 1, dt, g->grav, g->st, 0, 2); HL(launch_sweep)(d, ns, 1, dt, g->grav, g->st, 2 + nk, 2); }
+    { Scope s(g, "sweep_x1"); HL(launch_sweep)(d, ns, 0, dt, g->grav, g->st, 0, 2); HL(launch_sweep)(d, ns, 0, dt, g->grav, g->st, 2 + nk, 2); }
+    if (!x3_fused(g)) { Scope s(g, "sweep_x3"); HL(launch_sweep)(d, ns, 2, dt, g->grav, g->st, 0, -1); }
+    { Scope s(g, "correct_all"); HL(launch_correct_all)(d, ns, dt, g->grav, x3_fused(g), g->st); }
     Scope s(g, "flux2_update");
     cfl_arm(g);
-    launch_flux2_update(d, ns, dt, g->grav, g->keep_flux ? &g->keep : nullptr, g->st, g->cfl_ready ? g->sc : nullptr, g->pin_mask);
+    HL(launch_flux2_update)(d, ns, dt, g->grav, g->keep_flux ? &g->keep : nullptr, g->st, g->cfl_ready ? g->sc : nullptr, g->pin_mask);
     HIPCHK(hipGetLastError());
     return 0;
   }
-  if (d.slope) { Scope s(g, "ppm_slopes"); for (int dir = 0; dir < 3; dir++) launch_slopes(d, ns, dir, g->st); }
+  if (d.slope) { Scope s(g, "ppm_slopes"); for (int dir = 0; dir < 3; dir++) HL(launch_slopes)(d, ns, dir, g->st); }
   // x2 and x3 first, so that the x1 sweep can do its first pass and its correct pass in one go
-  { Scope s(g, "sweep_x2"); launch_sweep(d, ns, 1, dt, g->grav, g->st); }
-  if (!(g->correct_all && x3_fused(g))) { Scope s(g, "sweep_x3"); launch_sweep(d, ns, 2, dt, g->grav, g->st); }
+  { Scope s(g, "sweep_x2"); HL(launch_sweep)(d, ns, 1, dt, g->grav, g->st, 0, -1); }
+  if (!(g->correct_all && x3_fused(g))) { Scope s(g, "sweep_x3"); HL(launch_sweep)(d, ns, 2, dt, g->grav, g->st, 0, -1); }
   if (g->correct_all) {
-    { Scope s(g, "sweep_x1"); launch_sweep(d, ns, 0, dt, g->grav, g->st); }
-    { Scope s(g, "correct_all"); launch_correct_all(d, ns, dt, g->grav, x3_fused(g), g->st); }
+    { Scope s(g, "sweep_x1"); HL(launch_sweep)(d, ns, 0, dt, g->grav, g->st, 0, -1); }
+    { Scope s(g, "correct_all"); HL(launch_correct_all)(d, ns, dt, g->grav, x3_fused(g), g->st); }
   } else {
-    { Scope s(g, "sweep_correct_x1"); launch_sweep_correct_x1(d, ns, dt, g->grav, g->st); }
-    { Scope s(g, "correct_x2"); launch_correct(d, ns, 1, dt, g->grav, g->st); }
-    { Scope s(g, "correct_x3"); launch_correct(d, ns, 2, dt, g->grav, g->st); }
+    { Scope s(g, "sweep_correct_x1"); HL(launch_sweep_correct_x1)(d, ns, dt, g->grav, g->st); }
+    { Scope s(g, "correct_x2"); HL(launch_correct)(d, ns, 1, dt, g->grav, g->st); }
+    { Scope s(g, "correct_x3"); HL(launch_correct)(d, ns, 2, dt, g->grav, g->st); }
   }
   if (g->fused_update) {
     Scope s(g, "flux2_update");
     cfl_arm(g);
-    launch_flux2_update(d, ns, dt, g->grav, g->keep_flux ? &g->keep : nullptr, g->st, g->cfl_ready ? g->sc : nullptr, g->pin_mask);
+    HL(launch_flux2_update)(d, ns, dt, g->grav, g->keep_flux ? &g->keep : nullptr, g->st, g->cfl_ready ? g->sc : nullptr, g->pin_mask);
   } else {
-    { Scope s(g, "flux2_x1"); launch_flux2(d, ns, 0, g->st); }
-    { Scope s(g, "flux2_x2"); launch_flux2(d, ns, 1, g->st); }
-    { Scope s(g, "flux2_x3"); launch_flux2(d, ns, 2, g->st); }
-    { Scope s(g, "update");   launch_update(d, ns, d.dhalf, dt, g->grav, g->st); }
+    { Scope s(g, "flux2_x1"); HL(launch_flux2)(d, ns, 0, g->st); }
+    { Scope s(g, "flux2_x2"); HL(launch_flux2)(d, ns, 1, g->st); }
+    { Scope s(g, "flux2_x3"); HL(launch_flux2)(d, ns, 2, g->st); }
+    { Scope s(g, "update");   HL(launch_update)(d, ns, d.dhalf, dt, g->grav, g->st); }
   }
   HIPCHK(hipGetLastError());
   return 0;
 }
 
+#undef HL
 int aa_integrate_3d_vl(aa_grid *g)
 {
   if (!g->slab.empty()) return slabs_integrate(g, 1);

@@ -33,6 +33,7 @@ struct aa_grid {
   bool cfl_step = true;                // aa_step does so by itself (AA_CFL_FUSED=0: k_cfl)
   bool cfl_ready = false;              //   ... and has done so for the state as it is now
   bool grav = false;
+  int cool = 0;                        // aa_set_cooling: 1 = KoyInut; the integrator then launches the kernels of namespace aa_cool
   int rad_dir = 0, nradplane = 0; aa::Real flux_i = 0;
   int level = 0;                       // DomainS.Level: > 0 only as a level of an aa_mesh
   bool fused_update = false;           // second-pass fluxes + update in one kernel (AA_FUSED_UPDATE=0 at aa_create: the unfused chain)
@@ -87,6 +88,7 @@ int slabs_download_cons(aa_grid *g, double *U);
 int slabs_upload_edgeflux(aa_grid *g, const double *ef);
 int slabs_download_edgeflux(aa_grid *g, double *ef);
 int slabs_set_grav_tables(aa_grid *g, const double *pc, const double *p1, const double *p2, const double *p3);
+int slabs_set_cooling(aa_grid *g, int kind);
 int slabs_set_pinned_cells(aa_grid *g, long long n, const long long *index, const double *values);
 int slabs_apply_pinned_cells(aa_grid *g);
 int slabs_add_radplane(aa_grid *g, int dir, double flux);

@@ -21,7 +21,19 @@
 #include "grid.h"
 #include "hydro_dev.h"
 
+// Compiled twice: as it stands into namespace aa, and with -DAA_COOLING=1 into namespace aa_cool -- the same kernels with the
+// optically thin cooling terms of integrate_3d_ctu.c (Steps 1c-3c :359-368, :662-671, :846-855; 8b :2133-2266; 11c :2943-2953) for the
+// cooling function the reference ships (KoyInut, microphysics/cool.c:48).  api.hip launches the second set when a cooling
+// function is enrolled (aa_set_cooling); the kernels of every other run do not carry a register or an instruction of it.
+#ifndef AA_COOLING
+#define AA_COOLING 0
+#endif
+#if AA_COOLING
+namespace aa_cool {
+using namespace aa;
+#else
 namespace aa {
+#endif
 
 // ---- field accessors ------------------------------------------------------------------
 AA_DEV Real *Uf(const DevGrid &g, int v) { return g.U + (long)v*g.nc; }
@@ -29,6 +41,51 @@ AA_DEV Real *LRf(const DevGrid &g, int d, int side, int v) { return g.LR + (long
 AA_DEV Real *Ff(const DevGrid &g, int d, int v) { return g.F + (long)(d*6 + v)*g.nc; }
 AA_DEV Real *Ef(const DevGrid &g, int d) { return g.eta + (long)d*g.nc; }
 AA_DEV Real *Pf(const DevGrid &g, int which) { return g.phi + (long)which*g.nc; }   // 0 centre, 1+d face
+
+#if AA_COOLING
+// microphysics/cool.c:48-86 KoyInut(): the cooling rate [erg cm^-3 s^-1] of the diffuse ISM (Koyama & Inutsuka 2002, eq. 4) from
+// density and pressure in cgs units, limited so that the temperature stays above its equilibrium value over dt
+AA_DEV Real cool_koyinut(Real dens, Real Press, Real dt, Real Gamma_1)
+{
+  const Real mbar = (1.37)*(1.6733e-24), kb = 1.380658e-16, HeatRate = 2.0e-26, Tmin = 10;
+  const Real n = dens/mbar;
+  const Real logn = log10(n);
+  const Real T = rmax((Press/(n*kb)), Tmin);
+  Real Teq = Tmin;
+  const Real coolratepp = HeatRate*(n*(1.0e7*exp(-1.184e5/(T+1000.)) + 0.014*sqrt(T)*exp(-92.0/T)) - 1.0);
+  const Real dT = coolratepp*dt*Gamma_1/kb;
+  if ((T-dT) <= 185.0) {
+    const Real lognT = 3.9247499 - 1.8479378*logn + 1.5335032*logn*logn
+     -0.47665872*pow(logn,3.0) + 0.076789136*pow(logn,4.0)-0.0049052587*pow(logn,5.0);
+    Teq = pow(10.0,lognT) / n;
+  }
+  const Real MaxdT = kb*(T-Teq)/(dt*Gamma_1);
+  return n*rmin(coolratepp,MaxdT);
+}
+// Steps 1c / 2c / 3c (cont): the L/R primitive states lose pressure over half a step
+AA_DEV void cool_states(const DevGrid &g, Real dt, Real wl[6], Real wr[6])
+{
+  const Real coolfl = cool_koyinut(wl[0], wl[4], (0.5*dt), g.Gamma_1);
+  const Real coolfr = cool_koyinut(wr[0], wr[4], (0.5*dt), g.Gamma_1);
+  wl[4] -= 0.5*dt*g.Gamma_1*coolfl;
+  wr[4] -= 0.5*dt*g.Gamma_1*coolfr;
+}
+// Step 8b: P^{n+1/2} of zone m from U^n, the first-pass flux differences across the zone (global frame) and, with a static
+// potential, q_e (phi_r - phi_l) d
+AA_DEV Real p_half(const DevGrid &g, long m, const Real q[3], const Real dF[3][6], bool grav, const Real gm[3], Real dhalf)
+{
+  Real Mh[3];
+#pragma unroll
+  for (int e = 0; e < 3; e++) {
+    Mh[e] = Uf(g, 1 + e)[m] - q[0]*dF[0][1 + e] - q[1]*dF[1][1 + e] - q[2]*dF[2][1 + e];
+    if (grav) Mh[e] -= gm[e];
+  }
+  const Real Eh = Uf(g, 4)[m] - q[0]*dF[0][4] - q[1]*dF[1][4] - q[2]*dF[2][4];
+  Real ph = Eh - 0.5*(Mh[0]*Mh[0] + Mh[1]*Mh[1] + Mh[2]*Mh[2])/dhalf;
+  ph *= g.Gamma_1;
+  return ph;
+}
+#endif
 
 // sweep-frame component n of direction D lives in global field gv<D>(n):
 // (Mx,My,Mz) = (M[D], M[D+1], M[D+2])   integrate_3d_ctu.c:206-208, :544-546, :727-729
@@ -162,12 +219,26 @@ AA_DEV void face_correct(const DevGrid &g, long m, int i, int j, int k, Real dt,
   for (int n = 0; n < 6; n++) { sl[n] = ul[gv<D>(n)]; sr[n] = ur[gv<D>(n)]; }
   Real lambdar = lambda_face(sr, g.Gamma, g.Gamma_1, 1.0), lambdal = lambda_face(sl, g.Gamma, g.Gamma_1, -1.0);
   Ef(g, D)[m] = 0.5*fabs(lambdar - lambdal);
-  if (GRAV && D == 1 && j <= g.je + 1) {       // d^{n+1/2}, :2104-2125 (needs all first-pass fluxes:
+  if ((GRAV || AA_COOLING) && D == 1 && j <= g.je + 1) {       // d^{n+1/2}, :2104-2125 (needs all first-pass fluxes:
                                                // done in the x2 correct pass, which runs after them)
-    g.dhalf[m] = Uf(g, 0)[m]
+    const Real dh = Uf(g, 0)[m]
       - q[0]*(Ff(g, 0, 0)[m + 1]    - Ff(g, 0, 0)[m])
       - q[1]*(Ff(g, 1, 0)[m + g.sJ] - Ff(g, 1, 0)[m])
       - q[2]*(Ff(g, 2, 0)[m + g.sK] - Ff(g, 2, 0)[m]);
+    g.dhalf[m] = dh;
+#if AA_COOLING
+    {   // P^{n+1/2}, :2133-2266
+      Real dF[3][6], gm[3] = {0.0, 0.0, 0.0};
+#pragma unroll
+      for (int e = 0; e < 3; e++) {
+        const long se = stride_rt(g, e);
+#pragma unroll
+        for (int v = 0; v < 6; v++) dF[e][v] = (v < NV) ? Ff(g, e, v)[m + se] - Ff(g, e, v)[m] : 0.0;
+        if (GRAV) gm[e] = q[e]*(Pf(g, 1 + e)[m + se] - Pf(g, 1 + e)[m])*Uf(g, 0)[m];
+      }
+      g.phalf[m] = p_half(g, m, q, dF, GRAV, gm, dh);
+    }
+#endif
   }
 }
 
@@ -181,6 +252,9 @@ AA_DEV void face_work(const DevGrid &g, long m, int i, int j, int k, Real dt, Re
     wl[1] -= dtodx*(phifc - phicl);
     wr[1] -= dtodx*(phicr - phifc);
   }
+#if AA_COOLING
+  if (MODE != MODE_VL) cool_states(g, dt, wl, wr);       // :359-368, :662-671, :846-855 (the van Leer integrator has no such term)
+#endif
   Real ul[6], ur[6];
   prim_to_cons<NS>(wl, ul, g.Gamma_1, g.rGamma_1);
   prim_to_cons<NS>(wr, ur, g.Gamma_1, g.rGamma_1);
@@ -480,6 +554,9 @@ AA_DEV void cell_recon(const DevGrid &g, long m, Real dt, const Real wm[6], cons
     wl[1] -= dtodx*(phi_up - phic);
     wr[1] -= dtodx*(phic - phi_lo);
   }
+#if AA_COOLING
+  cool_states(g, dt, wl, wr);
+#endif
 }
 // the same with the kicks of the zone taken from its CellFlux (formed at the head of the iteration from the potential
 // values loaded there: a load inside the direction blocks would wait for the stores of the block before it)
@@ -489,6 +566,9 @@ AA_DEV void cell_recon(const DevGrid &g, long m, Real dt, const CellFlux &cf, co
 {
   recon_cell<NS, true, ORD, D>(g, m, wm, w, wp, dt/g.dx[D], wl, wr);
   if (GRAV) { wl[1] -= cf.kl[D]; wr[1] -= cf.kr[D]; }
+#if AA_COOLING
+  cool_states(g, dt, wl, wr);
+#endif
 }
 // second half: conversion, transverse correction, face states stored; returns the wave speeds eta needs: lam_l of the
 // left state the zone gave to its UPPER face, lam_r of the right state it gave to its LOWER face
@@ -710,8 +790,13 @@ k_correct_all(DevGrid g, Real dt, int kchunk)
       }
       if (full && k > g.ks - 1) Ef(g, 2)[m] = 0.5*fabs(lr - lam3);      // lam3 = lambda_l the zone below gave to this zone's lower face
       lam3 = ll;
-      if (GRAV && full)   // d^{n+1/2}, :2104-2125
-        g.dhalf[m] = wc[0] - q[0]*cf.dF[0][0] - q[1]*cf.dF[1][0] - q[2]*cf.dF[2][0];
+      if ((GRAV || AA_COOLING) && full) {   // d^{n+1/2}, :2104-2125
+        const Real dh = wc[0] - q[0]*cf.dF[0][0] - q[1]*cf.dF[1][0] - q[2]*cf.dF[2][0];
+        g.dhalf[m] = dh;
+#if AA_COOLING
+        g.phalf[m] = p_half(g, m, q, cf.dF, GRAV, cf.gm, dh);      // P^{n+1/2}, :2133-2266
+#endif
+      }
     }
     if (full) {
       {   // ---- x1: neighbours by shuffle ----
@@ -877,6 +962,9 @@ k_update(DevGrid g, const Real *dhalf, Real dt, Order ord)
       u[4] -= dtodx[e]*(fd[m]*(phic - phil) + fd[m + se]*(phir - phic));
     }
   }
+#if AA_COOLING
+  u[4] -= dt*cool_koyinut(dhalf[m], g.phalf[m], dt, g.Gamma_1);      // Step 11c, :2943-2953
+#endif
 #pragma unroll
   for (int d = 0; d < 3; d++) {   // :2981-3050, x1 then x2 then x3
     const long sd = stride_rt(g, d);
@@ -1107,6 +1195,9 @@ k_flux2_update(DevGrid g, const Real *dhalf, Real dt, int kchunk, KeepPlanes kp,
           u[3] -= dtodx[2]*(phir - phil)*dh;
           u[4] -= dtodx[2]*(m3lo*(phic - phil) + m3hi*(phir - phic)); }
       }
+#if AA_COOLING
+      u[4] -= dt*cool_koyinut(dhalf[m], g.phalf[m], dt, g.Gamma_1);      // Step 11c, :2943-2953
+#endif
       // :2981-3050, x1 then x2 then x3; sweep component n of direction D is global variable gv<D>(n)
 #pragma unroll
       for (int n = 0; n < NV; n++) u[gv<0>(n)] -= dtodx[0]*d1[n];
@@ -1874,4 +1965,4 @@ void launch_test_lr(int nscal, Real gamma, int n, const Real *W, Real dt, Real d
   else       hipLaunchKernelGGL((k_test_lr<0>), dim3(nblk(nc, 128)), dim3(128), 0, st, gamma, n, W, dt, dx, il, iu, Wl, Wr);
 }
 
-}  // namespace aa
+}  // namespace aa / aa_cool

@@ -260,6 +260,14 @@ int slabs_download_edgeflux(aa_grid *g, double *ef)
 }
 
 // ---- hooks ---------------------------------------------------------------------------------------------
+int slabs_set_cooling(aa_grid *g, int kind)
+{
+  DevGuard keep;
+  SlabLink *L = g->link;
+  for (int s = 0; s < L->n; s++) { SLAB_DEV(L, s); int rc = aa_set_cooling(g->slab[s], kind); if (rc) return rc; }
+  g->cool = kind;
+  return 0;
+}
 int slabs_set_grav_tables(aa_grid *g, const double *pc, const double *p1, const double *p2, const double *p3)
 {
   DevGuard keep;

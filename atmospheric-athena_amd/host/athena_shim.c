@@ -52,6 +52,7 @@
 extern Real CourNo, Gamma, Gamma_1;
 extern GravPotFun_t StaticGravPot;
 extern CoolingFun_t CoolingFunc;
+extern Real KoyInut(const Real dens, const Real Press, const Real dt) __attribute__((weak));   /* microphysics/cool.c:48 */
 extern double par_getd(char *block, char *name);
 extern double par_getd_def(char *block, char *name, double def);
 extern int par_geti_def(char *block, char *name, int def);
@@ -136,7 +137,11 @@ static void ensure_grid(MeshS *pM)
 #endif
   for (l = 0; l < pM->NLevels; l++)
     if (pM->DomainsPerLevel[l] != 1) ath_error("[athena_amd]: one Domain per level only (level %d has %d)\n", l, pM->DomainsPerLevel[l]);
-  if (CoolingFunc != NULL) ath_error("[athena_amd]: CoolingFunc is not supported on this path\n");
+  /* globals.h:25: the device integrator carries the cooling function the reference ships (microphysics/cool.c:48); any other
+   * host function cannot run inside a kernel */
+  if (CoolingFunc != NULL && (KoyInut == NULL || CoolingFunc != KoyInut))
+    ath_error("[athena_amd]: CoolingFunc is a function the device integrator does not carry (only KoyInut, microphysics/cool.c)\n");
+  if (CoolingFunc != NULL && use_vl()) fprintf(stderr, "[athena_amd] CoolingFunc is enrolled, but the van Leer integrator has no cooling terms (integrate_3d_vl.c): ignored, as in the reference\n");
   if (sizeof(ConsS) != (5 + AA_NSCALARS)*sizeof(double)) ath_error("[athena_amd]: ConsS layout\n");
   M = pM;
   env = getenv("AA_COHERENCE");
@@ -241,6 +246,7 @@ static void ensure_grid(MeshS *pM)
     if (p.ion) CHK(aa_add_radplane_3d(G[l], pM->radplanelist->dir[0], pM->radplanelist->flux_i));
 #endif
     if (StaticGravPot != NULL) CHK(aa_set_static_grav_pot(G[l], StaticGravPot));
+    if (CoolingFunc != NULL && !use_vl()) CHK(aa_set_cooling(G[l], AA_COOL_KOYINUT));
     env = getenv("AA_NGPU");
     if (env && atoi(env) > 1 && pM->NLevels == 1)   /* the library cuts the Grid into x3 slabs, one per GPU (csrc/slabs.hip) */
       fprintf(stderr, "[athena_amd] Grid %dx%dx%d in %d slabs along x3 on HIP devices %d.., %.2f GB resident, coherence=%s\n",

@@ -89,6 +89,7 @@ def load(strict: bool | None = None) -> C.CDLL:
         "aa_upload_edgeflux": (I, [P, dp]), "aa_download_edgeflux": (I, [P, dp]),
         "aa_get_mesh_state": (I, [P, dp, dp, ip]), "aa_set_mesh_state": (I, [P, D, D, I]),
         "aa_set_static_grav_pot": (I, [P, GRAVPOT]),
+        "aa_set_cooling": (I, [P, I]),
         "aa_set_static_grav_tables": (I, [P, dp, dp, dp, dp]),
         "aa_set_pinned_cells": (I, [P, LL, llp, dp]), "aa_apply_pinned_cells": (I, [P]),
         "aa_add_radplane_3d": (I, [P, I, D]), "aa_has_radplane": (I, [P]),
@@ -262,6 +263,10 @@ class Grid:
     def bvals_mhd(self): self._chk(self.L.aa_bvals_mhd(self._h))
     def bvals_ionrad(self): self._chk(self.L.aa_bvals_ionrad(self._h))
     def new_dt(self): self._chk(self.L.aa_new_dt(self._h))
+    def set_cooling(self, kind: int = 1):
+        """CoolingFunc = KoyInut (kind 1, AA_COOL_KOYINUT) or NULL (0); CTU integrator only."""
+        self._chk(self.L.aa_set_cooling(self._h, int(kind)))
+
     def integrate_3d_ctu(self): self._chk(self.L.aa_integrate_3d_ctu(self._h))
     def integrate_3d_vl(self): self._chk(self.L.aa_integrate_3d_vl(self._h))
     def integrate_begin(self): self._chk(self.L.aa_integrate_begin(self._h))

@@ -89,6 +89,13 @@ typedef double (*aa_gravpot_fn)(double x1, double x2, double x3);
 int aa_set_static_grav_pot(aa_grid *g, aa_gravpot_fn fn);
 int aa_set_static_grav_tables(aa_grid *g, const double *phi_cc, const double *phi_f1,
                               const double *phi_f2, const double *phi_f3); /* [N3][N2][N1] each */
+/* globals.h:25 CoolingFunc (optically thin cooling in integrate_3d_ctu.c: Steps 1c-3c :359-368 / :662-671 / :846-855 on the L/R
+ * states, 8b :2133-2266 P^{n+1/2}, 11c :2943-2953 the energy).  The reference calls a host function pointer per state; a device
+ * integrator needs the function itself, so the library carries the one the reference ships: AA_COOL_KOYINUT = KoyInut
+ * (microphysics/cool.c:48, cgs units).  CTU integrator only -- the reference's integrate_3d_vl.c has no cooling terms.         */
+#define AA_COOL_NONE    0
+#define AA_COOL_KOYINUT 1
+int aa_set_cooling(aa_grid *g, int kind);
 /* Userwork_in_loop of prob/ioniz_sphere.c:255-306 re-imposes fixed values on a fixed set of
  * cells every step; the device-side equivalent is a list of pinned cells (linear index into
  * the [k][j][i] block incl. ghosts, nvar values each) applied after the integrator.          */

@@ -103,6 +103,38 @@ def test_user_boundary_functions_enrolled_by_problem():
     assert np.abs(b[:, :, 0, 1]).max() > 0
 
 
+def test_cooling_function_enrolled_by_problem():
+    """globals.h:25 CoolingFunc: a user problem file (tests/fixtures/cool_pattern.c) enrols the cooling function the reference
+    ships (KoyInut, microphysics/cool.c:48); the shim recognises it and the device integrator carries its terms
+    (aa_set_cooling).  The reference's own main() on the GPU library against the all-CPU reference run of the same problem
+    object (tests/golden/coolpat_c1_*)."""
+    if not os.path.exists(os.path.join(REFBIN, "athena_coolpat_amd")):
+        pytest.skip("oracle/_ref coolpat executables not built (make -C oracle -f Makefile.ref coolpat)")
+    from make_golden import read_rst
+    gz = np.load(os.path.join(ROOT, "tests", "golden", "coolpat_c1_16x12x10_n4.npz"))
+    nx = tuple(int(x) for x in gz["nx"]); nlim = int(gz["nstep"])
+    kv = dict(str(o).split("=") for o in gz["overrides"])
+    tmp = tempfile.mkdtemp(prefix="coolpat_")
+    deck = os.path.join(tmp, "athinput")
+    text = open(os.path.join(ROOT, "atmospheric-athena_amd", "decks", "athinput.blast")).read()
+    text = text.replace("maxout      = 0", "maxout      = 1") + "\n<output1>\nout_fmt = rst\ndt = 1e300\n"
+    text = text.replace("<problem>", "<problem>\n" + "".join(f"{k} = {kv[k]}\n" for k in ("n0", "T0", "v0")) + "cool = 1")
+    open(deck, "w").write(text)
+    over = [f"{k}={v}" for k, v in kv.items() if "/" in k]
+    pr = subprocess.run([os.path.join(REFBIN, "athena_coolpat_amd"), "-i", deck, "-d", os.path.join(tmp, "run"),
+                         f"domain1/Nx1={nx[0]}", f"domain1/Nx2={nx[1]}", f"domain1/Nx3={nx[2]}", f"time/nlim={nlim}"] + over,
+                        stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, cwd=tmp, timeout=600)
+    assert pr.returncode == 0, pr.stdout[-1500:] + pr.stderr[-1500:]
+    rsts = sorted(f for f in os.listdir(os.path.join(tmp, "run")) if f.endswith(".rst"))
+    gpu = read_rst(os.path.join(tmp, "run", rsts[-1]), nx, 0, False)
+    shutil.rmtree(tmp)
+    assert gpu["nstep"] == nlim
+    assert abs(gpu["time"] / float(gz["time"]) - 1) < 1e-11 and abs(gpu["dt"] / float(gz["dt"]) - 1) < 1e-11
+    a, b = gpu["U"][..., :5], gz["U"][..., :5]
+    scale = np.abs(b).max(axis=(0, 1, 2)); scale[scale == 0] = 1
+    assert (np.abs(a - b).max(axis=(0, 1, 2)) / scale).max() < 1e-10
+
+
 @pytest.mark.parametrize("fixture,cfg,env", [
     ("smr_blast_3lev_s6", "blast_smr", {}),
     ("smr_blast_3lev_edge_s8", "blast_smr", {}),

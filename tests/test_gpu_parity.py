@@ -100,7 +100,8 @@ def test_scaling_free_quotient_and_square_root_are_the_ieee_ones(lib, strict):
                         np.zeros(64), 10.0 ** rng.uniform(-30, 30, n)])
     b = np.concatenate([10.0 ** rng.uniform(-200, 200, n) * rng.uniform(1.0, 10.0, n), rng.uniform(0.5, 2.0, n),
                         10.0 ** rng.uniform(-30, 30, 64), rng.choice(np.array([5.0 / 3.0 - 1.0, 1.4 - 1.0, 1.1 - 1.0, 1.0001 - 1.0]), n)])
-    keep = (np.abs(np.log10(np.maximum(a, 1e-300) / b)) < 290) | (a == 0)        # quotients away from the ends of the range
+    with np.errstate(divide="ignore"):
+        keep = (np.abs(np.log10(np.maximum(a, 1e-300) / b)) < 290) | (a == 0)    # quotients away from the ends of the range
     a = np.ascontiguousarray(a[keep]); b = np.ascontiguousarray(b[keep])
     out = np.zeros((5, len(a)))
     assert L.aa_test_xdiv(len(a), _dp(a), _dp(b), _dp(out)) == 0
@@ -513,6 +514,56 @@ def test_ray_directions_golden_fixtures(aa, lib, name, strict, ion_path):
     assert max(relerr(out, gz["U"])) < 1e-9, relerr(out, gz["U"])            # north_star: 1e-6
     ef = g.download_edgeflux()
     assert np.allclose(ef, gz["edgeflux"], rtol=1e-9, atol=1e-9 * np.abs(gz["edgeflux"]).max())
+    g.close()
+
+
+@pytest.mark.parametrize("chain", ["tiles", "correct_all", "unfused"])
+@pytest.mark.parametrize("strict", [True, False])
+@pytest.mark.parametrize("name", ["coolpat_c1_16x12x10_n4", "coolpat_c1_12x8x20_n3", "coolpat_c0_16x12x10_n4"])
+def test_optically_thin_cooling_against_the_reference(aa, lib, name, strict, chain, monkeypatch):
+    """CoolingFunc = KoyInut (microphysics/cool.c:48) in the CTU integrator -- integrate_3d_ctu.c Steps 1c-3c (:359-368, :662-671,
+    :846-855), 8b (:2133-2266), 11c (:2943-2953) -- against runs of the reference on our own problem file
+    tests/fixtures/cool_pattern.c (diffuse gas in cgs units, 150 K ... 6000 K, density jumps of 6, velocities of either sign),
+    through all three forms of the kernel chain (tile kernels / k_correct_all, fused / unfused update).  The device's log10 /
+    exp / pow differ from glibc's in the last place, so the comparison has a tolerance in both builds; the fixture without the
+    cooling function (c0) runs through the same entry point with AA_COOL_NONE."""
+    if chain == "correct_all": monkeypatch.setenv("AA_CORRECT_ALL", "1")
+    if chain == "unfused": monkeypatch.setenv("AA_FUSED_UPDATE", "0")
+    gz = np.load(os.path.join(GOLD, name + ".npz"))
+    ov, n0, T0, v0, cool = orc.coolpat_setup(gz)
+    run = aa.config.load(os.path.join(orc.DECKS, "athinput.blast"), ov, "blast")
+    g = lib.Grid(aa.config.slab(run), 0, strict)
+    U = g.new_host_block()
+    U[4:-4, 4:-4, 4:-4, :] = orc.cool_pattern(gz["nx"], n0, T0, v0, run.gamma)[..., :U.shape[-1]]
+    assert np.array_equal(U[4:-4, 4:-4, 4:-4, :5], gz["U0"][..., :5])
+    g.upload(U)
+    g.set_cooling(cool)
+    g.start()
+    assert g.dt == float(gz["dt0"])
+    for _ in range(int(gz["nstep"])): g.step()
+    out = g.download()[4:-4, 4:-4, 4:-4, :5]
+    err = max(relerr(out, gz["U"][..., :5]))
+    if cool == 0 and strict:
+        assert g.time == float(gz["time"]) and g.dt == float(gz["dt"]) and np.array_equal(out, gz["U"][..., :5])
+    else:
+        assert abs(g.time / float(gz["time"]) - 1) < 1e-11 and abs(g.dt / float(gz["dt"]) - 1) < 1e-11
+        assert err < 1e-10, err                                      # north_star: 1e-6
+    # and the terms matter: the run without them is per cent away
+    if cool:
+        ref0 = np.load(os.path.join(GOLD, "coolpat_c0_16x12x10_n4.npz"))
+        if tuple(ref0["nx"]) == tuple(gz["nx"]):
+            assert np.abs(out[..., 4] / ref0["U"][..., 4] - 1).max() > 1e-2
+    g.close()
+
+
+def test_cooling_is_refused_where_the_reference_has_none(aa, lib):
+    run = aa.config.load(os.path.join(orc.DECKS, "athinput.blast"), ["domain1/Nx1=8", "domain1/Nx2=8", "domain1/Nx3=8"], "blast")
+    run.integrator = "vl"
+    g = lib.Grid(aa.config.slab(run), 0, False)
+    with pytest.raises(lib.AthenaError, match="van Leer"):
+        g.set_cooling(1)
+    with pytest.raises(lib.AthenaError, match="AA_COOL"):
+        g.set_cooling(7)
     g.close()
 
 
