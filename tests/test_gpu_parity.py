@@ -556,6 +556,36 @@ def test_optically_thin_cooling_against_the_reference(aa, lib, name, strict, cha
     g.close()
 
 
+@pytest.mark.parametrize("chain", ["tiles", "correct_all"])
+@pytest.mark.parametrize("order", [2, 3])
+@pytest.mark.parametrize("strict", [True, False])
+def test_cooling_beside_gravity_scalar_and_radiation_vs_oracle(aa, lib, strict, order, chain, monkeypatch):
+    """The cooling terms in the instantiations the reference fixtures do not reach: with the static potential (its kick on the
+    L/R states before the cooling, its term in P^{n+1/2}, :2166-2189), the passive scalar, third order reconstruction and the
+    ion step in front -- ioniz_sphere 40^3 with KoyInut enrolled on both sides, HIP against the oracle (whose cooling terms the
+    reference fixtures pin bit for bit)."""
+    if chain == "correct_all": monkeypatch.setenv("AA_CORRECT_ALL", "1")
+    nx = (40, 40, 40)
+    ov = [f"domain1/Nx{d + 1}={nx[d]}" for d in range(3)]
+    o = orc.make_sim("ioniz_sphere", ov, order=order)
+    run = aa.config.load(os.path.join(orc.DECKS, "athinput.ioniz_sphere"), ov, "ioniz_sphere")
+    run.order = order
+    g = lib.setup_problem(aa.config.slab(run), 0, strict)
+    o.set_cooling(1); g.set_cooling(1)
+    o.start(); g.start()
+    for _ in range(2):
+        assert o.step() == g.step()
+        assert abs(g.dt / o.dt - 1) < 1e-9
+    a = g.download()[4:-4, 4:-4, 4:-4]; b = o.active
+    assert np.array_equal(np.isnan(a), np.isnan(b))
+    assert max(relerr(a, b)) < 1e-8, relerr(a, b)
+    # the same two steps without the cooling function differ from these
+    o2 = orc.make_sim("ioniz_sphere", ov, order=order); o2.start()
+    for _ in range(2): o2.step()
+    assert max(relerr(o2.active, b)) > 1e-12
+    g.close()
+
+
 def test_cooling_is_refused_where_the_reference_has_none(aa, lib):
     run = aa.config.load(os.path.join(orc.DECKS, "athinput.blast"), ["domain1/Nx1=8", "domain1/Nx2=8", "domain1/Nx3=8"], "blast")
     run.integrator = "vl"
