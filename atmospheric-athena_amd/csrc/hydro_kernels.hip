@@ -1735,7 +1735,10 @@ static void sweep_impl_o(const DevGrid &g, const Real *src, int dir, Real dt, hi
     // 32 interfaces per thread amortise the 3-cell start-up of a chunk on big Grids; small Grids need the
     // parallelism more (80^3 has only 110 wavefronts of columns): halve the chunk until the launch has
     // a few wavefronts per SIMD (1024 SIMDs)
-    int chunk = 32;
+#ifndef SW_CHUNK
+#define SW_CHUNK 32
+#endif
+    int chunk = SW_CHUNK;
     while (chunk > 4 && (long)nblk(ni*nt, 64)*((nfaces + chunk - 1)/chunk) < 4096) chunk >>= 1;
     dim3 grid(nblk(ni*nt, 64), (nfaces + chunk - 1)/chunk);
     if (dir == 1) hipLaunchKernelGGL((k_sweep_march<NS, 1, GRAV, MODE, ORD>), grid, dim3(64), 0, st, g, src, dt, chunk, toff, (int)nt);
