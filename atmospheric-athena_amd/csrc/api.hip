@@ -129,7 +129,6 @@ int aa_create(const aa_params *p, aa_grid **out)
   if (p->ion) n += nc*6 + nef;
   if (g->ion_fused) n += 2*nc + 2*nrays;
   if (p->order != 0 && p->order != 2 && p->order != 3) { delete g; return fail(-1, "[aa_create]: order %d (2: PLM, 3: PPM)", p->order); }
-  if (p->order == 3 && p->integrator == 1) { delete g; return fail(-1, "[aa_create]: order 3 is built for the CTU integrator only"); }
   if (p->order == 3) n += nc*18;
   g->pool_doubles = n;
   n += 16;
@@ -541,7 +540,7 @@ int aa_integrate_3d_ctu(aa_grid *g)
     HIPCHK(hipGetLastError());
     return 0;
   }
-  if (d.slope) { Scope s(g, "ppm_slopes"); for (int dir = 0; dir < 3; dir++) HL(launch_slopes)(d, ns, dir, g->st); }
+  if (d.slope) { Scope s(g, "ppm_slopes"); for (int dir = 0; dir < 3; dir++) HL(launch_slopes)(d, ns, dir, g->st, nullptr); }
   // x2 and x3 first, so that the x1 sweep can do its first pass and its correct pass in one go
   { Scope s(g, "sweep_x2"); HL(launch_sweep)(d, ns, 1, dt, g->grav, g->st, 0, -1); }
   if (!(g->correct_all && x3_fused(g))) { Scope s(g, "sweep_x3"); HL(launch_sweep)(d, ns, 2, dt, g->grav, g->st, 0, -1); }
@@ -572,7 +571,7 @@ int aa_integrate_3d_vl(aa_grid *g)
 {
   if (!g->slab.empty()) return slabs_integrate(g, 1);
   g->cfl_ready = false;
-  // integrate_3d_vl.c:96-: donor-cell fluxes -> U^{n+1/2} -> PLM (no tracing) + Roe -> update
+  // integrate_3d_vl.c:96-: donor-cell fluxes -> U^{n+1/2} -> PLM or PPM (no tracing) + Roe -> update
   const DevGrid &d = g->d; const int ns = g->p.nscal; const Real dt = g->dt;
   // donor-cell fluxes + U^{n+1/2} in one marching kernel from 2^18 zones (512^3: 16.8 -> 9.7 ms; same at 80^3;
   // 10 % slower at 32^3); AA_VL_PREDICT forces either, the results are the same bit for bit
@@ -581,6 +580,8 @@ int aa_integrate_3d_vl(aa_grid *g)
     { Scope s(g, "vl_flux1"); for (int dir = 0; dir < 3; dir++) launch_vl_flux1(d, ns, dir, g->st); }
     { Scope s(g, "vl_uhalf"); launch_vl_uhalf(d, ns, dt, g->grav, g->st); }
   }
+  // --with-order=3: the corrector reconstructs U^{n+1/2} with parabolae (no tracing, lr_states_ppm.c:502-507): their slopes first
+  if (d.slope) { Scope s(g, "ppm_slopes"); for (int dir = 0; dir < 3; dir++) launch_slopes(d, ns, dir, g->st, d.LR); }
   { Scope s(g, "vl_flux2_x1"); launch_vl_flux2(d, ns, 0, dt, g->st); }
   { Scope s(g, "vl_flux2_x2"); launch_vl_flux2(d, ns, 1, dt, g->st); }
   { Scope s(g, "vl_flux2_x3"); launch_vl_flux2(d, ns, 2, dt, g->st); }

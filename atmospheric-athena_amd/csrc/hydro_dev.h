@@ -544,7 +544,8 @@ AA_DEV void limited_slopes(const Real wm[6], const Real w[6], const Real wp[6], 
 // reference's work arrays overlap (NWAVE columns allocated, NWAVE+NSCALARS indexed, :689-692): the
 // scalar's left parabola edge is the density interface value and its right edge mixes the scalar
 // and density slopes of cell i+1; reproduced as is (see oracle/athena_oracle.c lr_states_ppm).
-template <int NS>
+// TRACE=false: the branch for integrators other than CTU (van Leer), lr_states_ppm.c:502-507: the parabola's edges as they are.
+template <int NS, bool TRACE = true>
 AA_DEV void ppm_cell(const Real wm[6], const Real w[6], const Real wp[6], const Real Dm[6], const Real D0[6],
                      const Real Dp[6], Real dtodx, Real Gamma, Real wl_next[6], Real wr_here[6])
 {
@@ -594,6 +595,12 @@ AA_DEV void ppm_cell(const Real wm[6], const Real w[6], const Real wp[6], const 
     Wlv[n] = pmin(pmax(w[n], wm[n]), Wlv[n]);
     Wrv[n] = pmax(pmin(w[n], wp[n]), Wrv[n]);
     Wrv[n] = pmin(pmax(w[n], wp[n]), Wrv[n]);
+  }
+  if (!TRACE) {
+#pragma unroll
+    for (int n = 0; n < NV; n++) { wl_next[n] = Wrv[n]; wr_here[n] = Wlv[n]; }
+    if (!NS) { wl_next[5] = 0.0; wr_here[5] = 0.0; }
+    return;
   }
 #pragma unroll
   for (int n = 0; n < NV; n++) {

@@ -120,7 +120,7 @@ AA_DEV void recon_cell(const DevGrid &g, long mcell, const Real wm[6], const Rea
 #pragma unroll
     for (int n = 0; n < 5 + NS; n++) { const Real *q = Sf(g, D, n) + mcell; Dm[n] = q[-s]; D0[n] = q[0]; Dp[n] = q[s]; }
     if (!NS) { Dm[5] = 0.0; D0[5] = 0.0; Dp[5] = 0.0; }
-    ppm_cell<NS>(wm, w, wp, Dm, D0, Dp, dtodx, g.Gamma, wl_next, wr_here);
+    ppm_cell<NS, TRACE>(wm, w, wp, Dm, D0, Dp, dtodx, g.Gamma, wl_next, wr_here);
   } else plm_cell<NS, TRACE>(wm, w, wp, dtodx, g.Gamma, wl_next, wr_here);
 }
 
@@ -129,7 +129,7 @@ AA_DEV void recon_cell(const DevGrid &g, long mcell, const Real wm[6], const Rea
 // [s-2, e+2] as the sweeps
 template <int NS, int D>
 __global__ void __launch_bounds__(256)
-k_slopes(DevGrid g)
+k_slopes(DevGrid g, const Real *src)
 {
   const int lo[3] = {g.is, g.js, g.ks}, hi[3] = {g.ie, g.je, g.ke};
   int n3[3], o3[3];
@@ -140,9 +140,9 @@ k_slopes(DevGrid g)
   const int i = o3[0] + (int)(lin % n3[0]), j = o3[1] + (int)((lin / n3[0]) % n3[1]), k = o3[2] + (int)(lin / ((long)n3[0]*n3[1]));
   const long m = (long)k*g.sK + (long)j*g.sJ + i, s = stride<D>(g);
   Real u[6], wm[6], w[6], wp[6], dWm[6];
-  load_sweep<D, NS>(g.U, g.nc, m - s, u); cons_to_prim<NS>(u, wm, g.Gamma_1);
-  load_sweep<D, NS>(g.U, g.nc, m,     u); cons_to_prim<NS>(u, w,  g.Gamma_1);
-  load_sweep<D, NS>(g.U, g.nc, m + s, u); cons_to_prim<NS>(u, wp, g.Gamma_1);
+  load_sweep<D, NS>(src, g.nc, m - s, u); cons_to_prim<NS>(u, wm, g.Gamma_1);
+  load_sweep<D, NS>(src, g.nc, m,     u); cons_to_prim<NS>(u, w,  g.Gamma_1);
+  load_sweep<D, NS>(src, g.nc, m + s, u); cons_to_prim<NS>(u, wp, g.Gamma_1);
   limited_slopes<NS>(wm, w, wp, g.Gamma, dWm);
 #pragma unroll
   for (int n = 0; n < 5 + NS; n++) Sf(g, D, n)[m] = dWm[n];
@@ -1748,20 +1748,20 @@ static void sweep_impl_o(const DevGrid &g, const Real *src, int dir, Real dt, hi
 template <int NS, bool GRAV, int MODE>
 static void sweep_impl(const DevGrid &g, const Real *src, int dir, Real dt, hipStream_t st, int koff = 0, int kcnt = -1)
 {
-  // the van Leer integrator is second order only (MODE_VL never sees a slope array)
-  if (MODE != MODE_VL && g.slope) sweep_impl_o<NS, GRAV, MODE, (MODE == MODE_VL ? 2 : 3)>(g, src, dir, dt, st, koff, kcnt);
+  // third order: the slope arrays were filled from the state the sweep reconstructs (U; U^{n+1/2} for the van Leer corrector)
+  if (g.slope) sweep_impl_o<NS, GRAV, MODE, 3>(g, src, dir, dt, st, koff, kcnt);
   else sweep_impl_o<NS, GRAV, MODE, 2>(g, src, dir, dt, st, koff, kcnt);
 }
 template <int NS>
-static void slopes_impl(const DevGrid &g, int dir, hipStream_t st)
+static void slopes_impl(const DevGrid &g, int dir, hipStream_t st, const Real *src)
 {
   long n = 1;
   const int lo[3] = {g.is, g.js, g.ks}, hi[3] = {g.ie, g.je, g.ke};
   for (int d = 0; d < 3; d++) n *= hi[d] - lo[d] + 1 + (d == dir ? 6 : 4);
   dim3 grid(nblk(n, 256)), blk(256);
-  if (dir == 0) hipLaunchKernelGGL((k_slopes<NS, 0>), grid, blk, 0, st, g);
-  else if (dir == 1) hipLaunchKernelGGL((k_slopes<NS, 1>), grid, blk, 0, st, g);
-  else hipLaunchKernelGGL((k_slopes<NS, 2>), grid, blk, 0, st, g);
+  if (dir == 0) hipLaunchKernelGGL((k_slopes<NS, 0>), grid, blk, 0, st, g, src);
+  else if (dir == 1) hipLaunchKernelGGL((k_slopes<NS, 1>), grid, blk, 0, st, g, src);
+  else hipLaunchKernelGGL((k_slopes<NS, 2>), grid, blk, 0, st, g, src);
 }
 // the correct passes of all three directions in one kernel (after the three first passes)
 template <int NS, bool GRAV>
@@ -1793,8 +1793,8 @@ void launch_correct_all(const DevGrid &g, int nscal, Real dt, bool grav, bool x3
   else       { if (grav) correct_all_impl<0, true>(g, dt, x3f, st); else correct_all_impl<0, false>(g, dt, x3f, st); }
 }
 
-void launch_slopes(const DevGrid &g, int nscal, int dir, hipStream_t st)
-{ if (nscal) slopes_impl<1>(g, dir, st); else slopes_impl<0>(g, dir, st); }
+void launch_slopes(const DevGrid &g, int nscal, int dir, hipStream_t st, const Real *src)
+{ if (!src) src = g.U; if (nscal) slopes_impl<1>(g, dir, st, src); else slopes_impl<0>(g, dir, st, src); }
 
 void launch_sweep(const DevGrid &g, int nscal, int dir, Real dt, bool grav, hipStream_t st, int koff, int kcnt)
 {

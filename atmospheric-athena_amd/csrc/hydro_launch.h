@@ -2,7 +2,7 @@
 // and once more inside `aa_cool` for the second compilation of the same file with -DAA_COOLING=1 (optically thin cooling in the
 // CTU integrator: integrate_3d_ctu.c Steps 1c-3c, 8b, 11c), whose kernels api.hip launches when a cooling function is enrolled.
 // ---- launch wrappers (hydro_kernels.hip) ------------------------------------------
-void launch_slopes(const DevGrid &g, int nscal, int dir, hipStream_t st);          // order 3: before the sweeps of a step
+void launch_slopes(const DevGrid &g, int nscal, int dir, hipStream_t st, const Real *src = nullptr);   // order 3: before the sweeps of a step (src: the conserved state they reconstruct; null = U)
 // first-pass sweep of one direction; for dir 0 / 1 optionally only the k-planes ks-2+koff .. +kcnt-1 (kcnt < 0: to the end)
 void launch_sweep(const DevGrid &g, int nscal, int dir, Real dt, bool grav, hipStream_t st, int koff = 0, int kcnt = -1);
 void launch_correct(const DevGrid &g, int nscal, int dir, Real dt, bool grav, hipStream_t st);

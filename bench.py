@@ -460,7 +460,7 @@ def analyse(c, w):
         "data": "synthetic (deck values on a uniform grid, generated in place"
                 + ("; neutral fraction reset to 1e-4 everywhere: fully ionized slab" if a.ionized_slab else "") + ")",
         "config": {"workload": f"{a.problem} {nx}x{w['nx2']}x{nx3} single level, "
-                               + ((f"CTU+{'PPM' if a.order == 3 else 'PLM'}+Roe+H-correction") if a.integrator == "ctu" else "VL+PLM+Roe")
+                               + ((f"CTU+{'PPM' if a.order == 3 else 'PLM'}+Roe+H-correction") if a.integrator == "ctu" else f"VL+{'PPM' if a.order == 3 else 'PLM'}+Roe")
                                + (" + static gravity + plane-parallel ion radiation" if a.problem == "ioniz_sphere"
                                   else (" + plane-parallel ion radiation" if a.problem == "ifront" else ""))
                                + (f"; timed after {len(w['spin_log'])} spin-up steps" + regime if run.ion else ""),

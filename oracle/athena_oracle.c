@@ -240,11 +240,11 @@ static void flux_roe(const C1 *Ul, const C1 *Ur, const P1 *Wl, const P1 *Wr, Rea
 
 static void lr_states_x(const P1 *W, Real dt, Real dx, int il, int iu, P1 *Wl, P1 *Wr,
                         Real Gamma, int nscal, int trace);
-static void lr_states_ppm(const P1 *W, Real dt, Real dx, int il, int iu, P1 *Wl, P1 *Wr, Real Gamma, int nscal);
+static void lr_states_ppm(const P1 *W, Real dt, Real dx, int il, int iu, P1 *Wl, P1 *Wr, Real Gamma, int nscal, int trace);
 static void lr_states(const P1 *W, Real dt, Real dx, int il, int iu, P1 *Wl, P1 *Wr,
                       Real Gamma, int nscal, int order)
 {
-  if (order == 3) lr_states_ppm(W, dt, dx, il, iu, Wl, Wr, Gamma, nscal);
+  if (order == 3) lr_states_ppm(W, dt, dx, il, iu, Wl, Wr, Gamma, nscal, 1);
   else lr_states_x(W, dt, dx, il, iu, Wl, Wr, Gamma, nscal, 1);
 }
 
@@ -394,7 +394,7 @@ static void limited_slopes(const P1 *W, int i, Real Gamma, int nscal, Real dWm[6
   dWm[5] = nscal ? da[5] : 0.0;
 }
 
-static void lr_states_ppm(const P1 *W, Real dt, Real dx, int il, int iu, P1 *Wl, P1 *Wr, Real Gamma, int nscal)
+static void lr_states_ppm(const P1 *W, Real dt, Real dx, int il, int iu, P1 *Wl, P1 *Wr, Real Gamma, int nscal, int trace)
 {
   const Real dtodx = dt/dx;
   const int nv = NW + nscal;
@@ -433,6 +433,11 @@ static void lr_states_ppm(const P1 *W, Real dt, Real dx, int il, int iu, P1 *Wl,
     for (n = 0; n < nv; n++) {                                          /* Step 17 :451-455 */
       dW[n] = Wrv[n] - Wlv[n];
       W6[n] = 6.0*(w[n] - 0.5*(Wlv[n]*(1.0-gamma_curv) + Wrv[n]*(1.0+gamma_curv)));
+    }
+    if (!trace) {                                                       /* integrators other than CTU (VL), :502-507 */
+      for (n = 0; n < nv; n++) { pWl[n] = Wrv[n]; pWr[n] = Wlv[n]; }
+      if (!nscal) { pWl[5] = 0.0; pWr[5] = 0.0; }
+      continue;
     }
     qx1 = 0.5*MAXR(ev4,0.0)*dtodx;                                      /* Step 18 :461-500 */
     for (n = 0; n < nv; n++)
@@ -852,7 +857,8 @@ static void integrate_vl(OrcSim *s)
         C1 u1 = to_sweep(&Uh[base + c*str[d]], d);
         W[c] = cons_to_prim(&u1, Gamma_1, nscal);
       }
-      lr_states_x(W, dt, s->dx[d], lo[d], hi[d], Wl, Wr, Gamma, nscal, 0);
+      if (s->p.order == 3) lr_states_ppm(W, dt, s->dx[d], lo[d], hi[d], Wl, Wr, Gamma, nscal, 0);   /* --with-order=3 */
+      else lr_states_x(W, dt, s->dx[d], lo[d], hi[d], Wl, Wr, Gamma, nscal, 0);
       for (c = lo[d]; c <= hi[d]+1; c++) {
         C1 ul = prim_to_cons(&Wl[c], Gamma_1, nscal), ur = prim_to_cons(&Wr[c], Gamma_1, nscal), f;
         flux_roe(&ul, &ur, &Wl[c], &Wr[c], 0.0, Gamma, Gamma_1, nscal, &f);

@@ -326,6 +326,33 @@ def test_vl_golden_fixtures(aa, lib, vl_predict):
     g.close()
 
 
+@pytest.mark.parametrize("strict", [True, False])
+def test_vl_with_third_order_reconstruction_golden_fixtures(aa, lib, vl_predict, strict):
+    """--with-integrator=vl --with-order=3: the van Leer corrector on piecewise parabolic states of U^{n+1/2} without tracing
+    (lr_states_ppm.c:502-507), against whole runs of the reference built that way."""
+    for name, prob in (("vl_ppm_blast_16x12x20_n4", "blast"), ("vl_ppm_ioniz_sphere_20x16x12_n2", "ioniz_sphere")):
+        gz = np.load(os.path.join(GOLD, name + ".npz"))
+        nx = tuple(int(x) for x in gz["nx"])
+        ov = [f"domain1/Nx{d + 1}={nx[d]}" for d in range(3)]
+        run = aa.config.load(os.path.join(orc.DECKS, "athinput." + prob), ov, prob, "vl")
+        run.order = 3
+        g = lib.setup_problem(aa.config.slab(run), 0, strict)
+        nv = 5 + run.nscal
+        g.start()
+        niter = [g.step() for _ in range(int(gz["nstep"]))]
+        out = g.download()[4:-4, 4:-4, 4:-4, :nv]
+        if prob == "blast":
+            if strict:
+                assert g.time == float(gz["time"]) and g.dt == float(gz["dt"]) and np.array_equal(out, gz["U"][..., :nv])
+            else:
+                assert max(relerr(out, gz["U"][..., :nv])) < 1e-11
+        else:
+            assert niter == [int(x) for x in gz["niter"]]
+            assert abs(g.time / float(gz["time"]) - 1) < 1e-9
+            assert max(relerr(out, gz["U"][..., :nv])) < 1e-8, relerr(out, gz["U"][..., :nv])     # north_star: 1e-6
+        g.close()
+
+
 @pytest.mark.parametrize("problem,nx,nsteps", [("ifront", (16, 8, 8), 3), ("ioniz_sphere", (32, 32, 32), 2)])
 def test_vl_ion_problems_vs_oracle(aa, lib, problem, nx, nsteps, vl_predict):
     o, g, nv, trace = run_pair(aa, lib, problem, nx, nsteps, False, "vl")
