@@ -119,7 +119,7 @@ def from_par(par: ParTable, problem: Optional[str] = None) -> RunConfig:
 
 def load(path: str, overrides=None, problem: Optional[str] = None, integrator: str = "ctu") -> RunConfig:
     run = from_par(ParTable.from_file(path).cmdline(overrides), problem)
-    if integrator not in ("ctu", "vl"):
+    if integrator not in ("ctu", "vl", "ctu-noh"):      # ctu-noh: CTU without --enable-h-correction (the reference's configure default)
         raise ParError(f"[integrate_init]: unknown integrator {integrator}")
     run.integrator = integrator
     return run

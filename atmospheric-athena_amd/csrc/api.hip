@@ -340,7 +340,7 @@ int aa_set_static_grav_pot(aa_grid *g, aa_gravpot_fn fn)
 int aa_set_cooling(aa_grid *g, int kind)
 {
   if (kind != AA_COOL_NONE && kind != AA_COOL_KOYINUT) return fail(-1, "[aa_set_cooling]: kind=%d: only AA_COOL_NONE and AA_COOL_KOYINUT", kind);
-  if (kind && g->p.integrator != 0) return fail(-1, "[aa_set_cooling]: the van Leer integrator has no cooling terms in the reference (integrate_3d_vl.c)");
+  if (kind && g->p.integrator == 1) return fail(-1, "[aa_set_cooling]: the van Leer integrator has no cooling terms in the reference (integrate_3d_vl.c)");
   if (!g->slab.empty() || g->link) return slabs_set_cooling(g, kind);
   g->inner_swept = false;
   if (kind && !g->d.phalf) {
@@ -521,6 +521,17 @@ int aa_integrate_begin(aa_grid *g)
   return 0;
 }
 
+// aa_params.integrator 2: the CTU integrator of a reference built WITHOUT --enable-h-correction (its configure default).  Such a
+// build has no eta arrays and roe.c uses |ev| where the H_CORRECTION build uses MAX(|ev|, etah) (roe.c:282-290): the numbers of
+// etah = 0.  The correct kernels have just filled the etas; zero them before the second-pass fluxes read them (three fields:
+// ~1 ms at 512^3 in this mode only; the kernels of the default mode carry no flag for it).
+static void no_h_correction(aa_grid *g)
+{
+  if (g->p.integrator != 2) return;
+  Scope s(g, "no_h_correction");
+  (void)hipMemsetAsync(g->d.eta, 0, (size_t)3*g->d.nc*sizeof(Real), g->st);
+}
+
 int aa_integrate_3d_ctu(aa_grid *g)
 {
   if (!g->slab.empty()) return slabs_integrate(g, 0);
@@ -534,6 +545,7 @@ int aa_integrate_3d_ctu(aa_grid *g)
     { Scope s(g, "sweep_x1"); HL(launch_sweep)(d, ns, 0, dt, g->grav, g->st, 0, 2); HL(launch_sweep)(d, ns, 0, dt, g->grav, g->st, 2 + nk, 2); }
     if (!x3_fused(g)) { Scope s(g, "sweep_x3"); HL(launch_sweep)(d, ns, 2, dt, g->grav, g->st, 0, -1); }
     { Scope s(g, "correct_all"); HL(launch_correct_all)(d, ns, dt, g->grav, x3_fused(g), g->st); }
+    no_h_correction(g);
     Scope s(g, "flux2_update");
     cfl_arm(g);
     HL(launch_flux2_update)(d, ns, dt, g->grav, g->keep_flux ? &g->keep : nullptr, g->st, g->cfl_ready ? g->sc : nullptr, g->pin_mask);
@@ -552,6 +564,7 @@ int aa_integrate_3d_ctu(aa_grid *g)
     { Scope s(g, "correct_x2"); HL(launch_correct)(d, ns, 1, dt, g->grav, g->st); }
     { Scope s(g, "correct_x3"); HL(launch_correct)(d, ns, 2, dt, g->grav, g->st); }
   }
+  no_h_correction(g);
   if (g->fused_update) {
     Scope s(g, "flux2_update");
     cfl_arm(g);

@@ -114,6 +114,17 @@ static int use_vl(void)
 #endif
 }
 
+/* configure without --enable-h-correction (its default)  <->  -DAA_NO_H_CORRECTION at compile time, or AA_H_CORRECTION=0 */
+static int no_h_correction(void)
+{
+#ifdef AA_NO_H_CORRECTION
+  return 1;
+#else
+  const char *e = getenv("AA_H_CORRECTION");
+  return (e && atoi(e) == 0);
+#endif
+}
+
 /* configure --with-order=3  <->  -DAA_THIRD_ORDER at compile time, or AA_ORDER=3 */
 static int recon_order(void)
 {
@@ -237,7 +248,7 @@ static void ensure_grid(MeshS *pM)
 #ifdef AA_MPI
     if (!env) { const int nd = aa_device_count(); p.device = nd > 0 ? myID_Comm_world % nd : 0; }
 #endif
-    p.integrator = use_vl();
+    p.integrator = use_vl() ? 1 : (no_h_correction() ? 2 : 0);
     p.order = recon_order();
     CHK(aa_create(&p, &G[l]));
     ncell[l] = (size_t)(PG[l]->Nx[0] + 2*AA_NGHOST)*(PG[l]->Nx[1] + 2*AA_NGHOST)*(PG[l]->Nx[2] + 2*AA_NGHOST);

@@ -165,7 +165,7 @@ def params_from_grid(g: GridConfig, device: int = 0, ion_path: int = 0, nslab: i
         setattr(p, k, v)
     p.maxiter = r.maxiter
     p.device = device
-    p.integrator = 1 if r.integrator == "vl" else 0
+    p.integrator = {"ctu": 0, "vl": 1, "ctu-noh": 2}[r.integrator]
     p.level = g.level
     p.order = getattr(r, "order", 2)
     p.ion_path = ion_path

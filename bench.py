@@ -95,10 +95,10 @@ KERNEL_BYTES = {
     "ion_pass_first": 8 * (4 + 1) + 4, "ion_pass_last": 8 * (7 + 2) + 2,
     "ion_pass_begin": 8 * (6 + 4 + 1) + 2,      # the entry of the ion step on the first pass: U in; ke, max|v|, e_init, x_init, incoming flux, sign word out
     "ion_begin": 8 * (6 + 6), "ion_finish": 8 * 2,
-    "bvals_mhd": 0, "new_dt": 8 * 5, "pinned_cells": 0, "ppm_slopes": 3 * 8 * (6 + 6),
+    "bvals_mhd": 0, "new_dt": 8 * 5, "pinned_cells": 0, "ppm_slopes": 3 * 8 * (6 + 6), "no_h_correction": 8 * 3,
 }
 CORRECT_ALL_X3_BYTES = 8 * (6 + 12 + 4 + 36 + 3 + 1)   # k_correct_all with the x3 first pass inside (no x3 first-pass fluxes in HBM)
-HYDRO_KERNELS = ("sweep_", "sweep_correct_x1", "correct_", "flux2_", "update", "vl_", "ppm_slopes")
+HYDRO_KERNELS = ("sweep_", "sweep_correct_x1", "correct_", "flux2_", "update", "vl_", "ppm_slopes", "no_h_correction")
 SUBCYCLE_KERNELS = ("ray_sweep", "ray_sweep_rates", "ion_rates", "ion_update", "ion_pass", "ion_pass_first", "ion_pass_last", "ion_pass_begin",
                     "ion_pick")
 

@@ -40,7 +40,8 @@ typedef struct aa_params {
   int    maxiter;
   int    device;           /* HIP device ordinal                                                */
   int    integrator;       /* 0: CTU + H-correction (configure default + --enable-h-correction);
-                              1: van Leer, no H-correction (--with-integrator=vl)              */
+                              1: van Leer, no H-correction (--with-integrator=vl);
+                              2: CTU without H-correction (configure default, NO_H_CORRECTION)  */
   int    level;            /* DomainS.Level (static mesh refinement): dx = root dx / 2^level
                               (init_mesh.c:245); 0 for a single-level run                      */
   int    order;            /* configure --with-order: 2 (or 0) piecewise linear, lr_states_plm.c;

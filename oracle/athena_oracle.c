@@ -708,6 +708,12 @@ void orc_integrate(OrcSim *s)
   }
 
   /* === Step 9a: eta for the H-correction (:2300-2343) === */
+  /* (a build without --enable-h-correction, the configure default, has neither the eta arrays nor the etah argument: roe.c
+   *  :282-290 then uses |ev| where the H_CORRECTION build uses MAX(|ev|, etah) -- the same numbers as etah = 0) */
+  if (s->p.integrator == 2) {
+    const size_t nc0 = (size_t)s->N[0]*s->N[1]*s->N[2];
+    for (d = 0; d < 3; d++) memset(s->eta[d], 0, nc0*sizeof(Real));
+  } else
   for (d = 0; d < 3; d++) {
     int rl[3], ru[3];
     for (e = 0; e < 3; e++) { rl[e] = lo[e]-1; ru[e] = hi[e] + ((e == d) ? 2 : 1); }

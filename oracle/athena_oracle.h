@@ -37,7 +37,8 @@ typedef struct OrcParams {
   int    userwork;     /* 0: none, 1: ioniz_sphere Userwork_in_loop                   */
   double uw_K, uw_Cp, uw_rho0, uw_rreset2;
   int    integrator;   /* 0: CTU + H-correction (README.rst:25); 1: VL, no H-correction (the
-                          only VL combination the reference compiles)                  */
+                          only VL combination the reference compiles); 2: CTU without H-correction
+                          (the reference's configure default)                           */
   int    order;        /* 2 (0 = default): PLM, configure --with-order=2; 3: PPM, --with-order=3
                           (reconstruction/lr_states_ppm.c), CTU integrator only          */
 } OrcParams;

@@ -10,7 +10,7 @@ through oracle/_ref/libref_<cfg>.so to produce function-level known-answer vecto
 
 Fixtures are DATA (arrays + the scalar trace of each run); no reference text is stored.
 
-usage: python tests/golden/make_golden.py [whole] [shk] [dev] [kernels] [ppm] [smr] [hst] [ray] [cool] [vlppm]
+usage: python tests/golden/make_golden.py [whole] [shk] [dev] [kernels] [ppm] [smr] [hst] [ray] [cool] [vlppm] [noh]
 """
 import ctypes as C
 import os
@@ -151,6 +151,18 @@ def vl_ppm_runs():
     f, l, it = run_reference("ioniz_sphere_vl_ppm", sphere, (20, 16, 12), 2,
                              ["job/num_domains=1", "job/maxout=1", "output1/dt=1e300"], "ioniz_sphere", 1, True)
     save("vl_ppm_ioniz_sphere_20x16x12_n2", f, l, it, (20, 16, 12), [])
+
+
+def no_h_correction_runs():
+    """CTU without --enable-h-correction (the reference's configure default: no eta arrays, roe.c without etah)."""
+    sphere = os.path.join(REF, "tst/massloss/athinput.ioniz_sphere_hires")
+    blast = os.path.join(REF, "tst/3D-hydro/athinput.blast")
+    f, l, it = run_reference("blast_noh", blast, (16, 12, 20), 4,
+                             ["job/num_domains=1", "job/maxout=1", "output1/out_fmt=rst", "output1/dt=1e300"], "Blast", 0, False)
+    save("noh_blast_16x12x20_n4", f, l, it, (16, 12, 20), [])
+    f, l, it = run_reference("ioniz_sphere_noh", sphere, (20, 16, 12), 2,
+                             ["job/num_domains=1", "job/maxout=1", "output1/dt=1e300"], "ioniz_sphere", 1, True)
+    save("noh_ioniz_sphere_20x16x12_n2", f, l, it, (20, 16, 12), [])
 
 
 def cooling_runs():
@@ -436,11 +448,13 @@ def kernel_vectors():
 if __name__ == "__main__":
     if not os.path.isdir(REF) or not os.path.isdir(REFBIN):
         sys.exit("needs /root/reference and oracle/_ref (make -C oracle ref)")
-    which = sys.argv[1:] or ["whole", "shk", "dev", "kernels", "ppm", "smr", "hst", "ray", "cool", "vlppm"]
+    which = sys.argv[1:] or ["whole", "shk", "dev", "kernels", "ppm", "smr", "hst", "ray", "cool", "vlppm", "noh"]
     if "cool" in which:
         cooling_runs()
     if "vlppm" in which:
         vl_ppm_runs()
+    if "noh" in which:
+        no_h_correction_runs()
     if "ray" in which:
         rayplane_runs()
     if "hst" in which:

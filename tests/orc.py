@@ -114,7 +114,7 @@ def params_from_grid(g) -> OrcParams:
         p.bc[b] = g.bc[b]
     p.nscal = r.nscal; p.ion = 1 if r.ion else 0
     p.gamma = r.gamma; p.cour_no = r.cour_no; p.tlim = r.tlim
-    p.integrator = 1 if getattr(r, "integrator", "ctu") == "vl" else 0
+    p.integrator = {"ctu": 0, "vl": 1, "ctu-noh": 2}[getattr(r, "integrator", "ctu")]
     p.order = getattr(r, "order", 2)
     if r.ionp:
         for k, v in r.ionp.items():

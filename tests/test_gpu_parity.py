@@ -326,6 +326,39 @@ def test_vl_golden_fixtures(aa, lib, vl_predict):
     g.close()
 
 
+@pytest.mark.parametrize("chain", ["tiles", "correct_all", "unfused"])
+@pytest.mark.parametrize("strict", [True, False])
+def test_ctu_without_h_correction_golden_fixtures(aa, lib, strict, chain, monkeypatch):
+    """A reference built WITHOUT --enable-h-correction (its configure default): aa_params.integrator = 2, the CTU chain with the
+    etas zeroed in front of the second-pass fluxes (roe.c:282-290 without etah = with etah 0), against whole runs of the
+    reference built that way, through the three forms of the kernel chain."""
+    if chain == "correct_all": monkeypatch.setenv("AA_CORRECT_ALL", "1")
+    if chain == "unfused": monkeypatch.setenv("AA_FUSED_UPDATE", "0")
+    for name, prob in (("noh_blast_16x12x20_n4", "blast"), ("noh_ioniz_sphere_20x16x12_n2", "ioniz_sphere")):
+        gz = np.load(os.path.join(GOLD, name + ".npz"))
+        nx = tuple(int(x) for x in gz["nx"])
+        ov = [f"domain1/Nx{d + 1}={nx[d]}" for d in range(3)]
+        run = aa.config.load(os.path.join(orc.DECKS, "athinput." + prob), ov, prob, "ctu-noh")
+        g = lib.setup_problem(aa.config.slab(run), 0, strict)
+        nv = 5 + run.nscal
+        g.start()
+        niter = [g.step() for _ in range(int(gz["nstep"]))]
+        out = g.download()[4:-4, 4:-4, 4:-4, :nv]
+        if prob == "blast":
+            if strict:
+                assert g.time == float(gz["time"]) and g.dt == float(gz["dt"]) and np.array_equal(out, gz["U"][..., :nv])
+            else:
+                assert max(relerr(out, gz["U"][..., :nv])) < 1e-11
+        else:
+            assert niter == [int(x) for x in gz["niter"]]
+            assert abs(g.time / float(gz["time"]) - 1) < 1e-9
+            # 20x16x12 puts the planet (radius 2 zones) beside a 1e5 density jump; without the H-correction's dissipation the
+            # default build's last-bit differences (fused multiply-adds, reciprocal forms) grow to 1.3e-7 in the x1 momentum in
+            # two steps (every other field 4e-9; the strict build holds 1e-8 everywhere).  north_star: 1e-6
+            assert max(relerr(out, gz["U"][..., :nv])) < (1e-8 if strict else 1e-6), relerr(out, gz["U"][..., :nv])
+        g.close()
+
+
 @pytest.mark.parametrize("strict", [True, False])
 def test_vl_with_third_order_reconstruction_golden_fixtures(aa, lib, vl_predict, strict):
     """--with-integrator=vl --with-order=3: the van Leer corrector on piecewise parabolic states of U^{n+1/2} without tracing

@@ -93,6 +93,8 @@ def test_whole_run_bitwise(name):
     order = 2
     if prob.startswith("vl_"):
         prob, integrator = prob[3:], "vl"
+    if prob.startswith("noh_"):
+        prob, integrator = prob[4:], "ctu-noh"             # CTU without --enable-h-correction
     if prob.startswith("ppm_"):
         prob, order = prob[4:], 3
     if prob.startswith("shkset1d"):
