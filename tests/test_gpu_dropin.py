@@ -20,7 +20,7 @@ REFBIN = os.path.join(ROOT, "oracle", "_ref")
 
 
 def run(exe, problem, nx, nlim, env_extra=None):
-    problem = problem.replace("_vl", "").replace("_ppm", "")
+    problem = problem.replace("_vl", "").replace("_ppm", "").replace("_noh", "")
     from make_golden import read_rst
     tmp = tempfile.mkdtemp(prefix="dropin_")
     deck = os.path.join(tmp, "athinput")
@@ -48,6 +48,10 @@ def run(exe, problem, nx, nlim, env_extra=None):
     ("ioniz_sphere_vl", (32, 32, 32), 3, {}),
     ("blast_ppm", (24, 16, 20), 4, {}),                 # --with-order=3 builds of the reference
     ("ioniz_sphere_ppm", (32, 32, 32), 3, {}),
+    ("blast_noh", (24, 16, 20), 4, {}),                 # builds WITHOUT --enable-h-correction (the configure default)
+    ("ioniz_sphere_noh", (32, 32, 32), 3, {}),
+    ("blast_vl_ppm", (24, 16, 20), 4, {}),              # --with-integrator=vl --with-order=3
+    ("ioniz_sphere_vl_ppm", (32, 32, 32), 3, {}),
 ])
 def test_reference_driver_on_gpu_library(problem, nx, nlim, env):
     if not os.path.exists(os.path.join(REFBIN, f"athena_{problem}_amd")):
