@@ -646,6 +646,25 @@ def test_cooling_beside_gravity_scalar_and_radiation_vs_oracle(aa, lib, strict, 
     g.close()
 
 
+def test_cooling_on_a_grid_cut_into_slabs(aa, lib):
+    """aa_set_cooling on a composite handle (aa_params.nslab = 2, the drop-in's AA_NGPU): every slab runs the cooling kernels and
+    keeps its own P^{n+1/2}; 12 x 8 x 20 in two slabs of 10 planes against the reference run of the undivided Grid."""
+    gz = np.load(os.path.join(GOLD, "coolpat_c1_12x8x20_n3.npz"))
+    ov, n0, T0, v0, cool = orc.coolpat_setup(gz)
+    run = aa.config.load(os.path.join(orc.DECKS, "athinput.blast"), ov, "blast")
+    g = lib.Grid(aa.config.slab(run), 0, True, 0, 2)
+    U = g.new_host_block()
+    U[4:-4, 4:-4, 4:-4, :] = orc.cool_pattern(gz["nx"], n0, T0, v0, run.gamma)[..., :U.shape[-1]]
+    g.upload(U)
+    g.set_cooling(cool)
+    g.start()
+    for _ in range(int(gz["nstep"])): g.step()
+    out = g.download()[4:-4, 4:-4, 4:-4, :5]
+    assert abs(g.time / float(gz["time"]) - 1) < 1e-11 and abs(g.dt / float(gz["dt"]) - 1) < 1e-11
+    assert max(relerr(out, gz["U"][..., :5])) < 1e-10
+    g.close()
+
+
 def test_cooling_is_refused_where_the_reference_has_none(aa, lib):
     run = aa.config.load(os.path.join(orc.DECKS, "athinput.blast"), ["domain1/Nx1=8", "domain1/Nx2=8", "domain1/Nx3=8"], "blast")
     run.integrator = "vl"
