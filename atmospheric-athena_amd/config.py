@@ -196,23 +196,20 @@ def pencil(run: RunConfig, rank: int, p2: int, p3: int) -> GridConfig:
 
 
 def levels(par: ParTable, run: RunConfig) -> List[GridConfig]:
-    """The nested Domains of a static-mesh-refinement deck, one per level, root first
-    (init_mesh.c:170-295).  Level l has dx = root dx / 2^l; ``disp`` is <domainN> iDisp/jDisp/kDisp
-    in zones of that level; its lower edge is ``root_xmin + Disp*dx_l`` (:281-286); sides that are
-    not on the root boundary get bc = 0 (bvals_mhd.c:193-361, ProlongateLater)."""
+    """The Domains of a static-mesh-refinement deck in the order of the reference's loops -- level by level from the root,
+    Domains of a level in deck order (MeshS.Domain[nl][nd], init_mesh.c:170-295).  Level l has dx = root dx / 2^l; ``disp``
+    is <domainN> iDisp/jDisp/kDisp in zones of that level; its lower edge is ``root_xmin + Disp*dx_l`` (:281-286); sides that
+    are not on the root boundary get bc = 0 (bvals_mhd.c:193-361, ProlongateLater).  Domains of one level neither overlap nor
+    touch (:398-418), so every Domain lies in ONE Domain of the level below."""
     nd = par.geti_def("job", "num_domains", 1)
-    doms = {}
-    for n in range(1, nd + 1):
-        blk = f"domain{n}"
-        lev = par.geti(blk, "level")
-        if lev in doms:
-            raise ParError(f"[config]: more than one Domain on level {lev} is not supported")
-        doms[lev] = blk
-    if sorted(doms) != list(range(len(doms))):
-        raise ParError("[init_mesh]: levels must be contiguous from 0")
+    doms = sorted((par.geti(f"domain{n}", "level"), n) for n in range(1, nd + 1))
+    levs = sorted({lev for lev, _ in doms})
+    if levs != list(range(len(levs))) or sum(1 for lev, _ in doms if lev == 0) != 1:
+        raise ParError("[init_mesh]: levels must be contiguous from 0, with one root Domain")
     out = [slab(run, 0, 1)]
-    for lev in range(1, len(doms)):
-        blk = doms[lev]
+    ext = [((0, 0, 0), tuple(run.rootNx))]                # (origin, size) of every Domain in zones of its level
+    for lev, n in doms[1:]:
+        blk = f"domain{n}"
         irefine = 2 ** lev
         Nx = tuple(par.geti(blk, f"Nx{d}") for d in (1, 2, 3))
         disp = tuple(par.geti(blk, k) for k in ("iDisp", "jDisp", "kDisp"))
@@ -221,12 +218,20 @@ def levels(par: ParTable, run: RunConfig) -> List[GridConfig]:
                 raise ParError(f"[init_mesh]: {blk}/Nx{d + 1} = {Nx[d]} must be divisible by {irefine}")
             if disp[d] % irefine:
                 raise ParError(f"[init_mesh]: {blk}/Disp{d + 1} = {disp[d]} must be divisible by {irefine}")
-        # init_mesh.c:320-360: a child may touch its parent's edge only where that is the root boundary
-        pNx, pdisp = out[-1].Nx, (out[-1].disp if lev > 1 else (0, 0, 0))
+        # init_mesh.c:398-418: Domains on the same level may neither overlap nor touch
+        for g, (o, sz) in zip(out, ext):
+            if g.level == lev and all(disp[d] <= o[d] + sz[d] and o[d] <= disp[d] + Nx[d] for d in range(3)):
+                raise ParError(f"[init_mesh]: Domains at level {lev} overlap or touch ({blk})")
+        # init_mesh.c:320-360, :448-470: inside ONE Domain of the level below; it may touch its edge only where that is the root boundary
+        parent = None
+        for g, (o, sz) in zip(out, ext):
+            if g.level == lev - 1 and all(disp[d] // 2 >= o[d] and (disp[d] + Nx[d]) // 2 <= o[d] + sz[d] for d in range(3)):
+                parent = (o, sz)
+        if parent is None:
+            raise ParError(f"[init_mesh]: {blk} is not inside the Domain of level {lev - 1}")
+        pdisp, pNx = parent
         for d in range(3):
             lo, hi = disp[d] // 2, (disp[d] + Nx[d]) // 2
-            if lo < pdisp[d] or hi > pdisp[d] + pNx[d]:
-                raise ParError(f"[init_mesh]: {blk} is not inside the Domain of level {lev - 1}")
             if (lo == pdisp[d] and disp[d] != 0) or \
                (hi == pdisp[d] + pNx[d] and (disp[d] + Nx[d]) // irefine != run.rootNx[d]):
                 raise ParError(f"[init_mesh]: child Domain {blk} touches its parent in x{d + 1}")
@@ -240,17 +245,19 @@ def levels(par: ParTable, run: RunConfig) -> List[GridConfig]:
                 bc[2 * d + 1] = 0
         out.append(GridConfig(run=run, rank=0, nranks=1, Nx=Nx, disp=disp, MinX=MinX, bc=tuple(bc),
                               lx3=-1, rx3=-1, level=lev))
+        ext.append((disp, Nx))
     # ionrad_smr.c:97-98: the coarse->fine radiation hand-off is only defined while the parent is not
     # displaced across the rays (2 levels); AA_SMR_DEEP_RADIATION=fixed opts into the corrected index
     if run.ion and os.environ.get("AA_SMR_DEEP_RADIATION") != "fixed":
-        for g in out[1:-1]:
-            if g.disp[1] or g.disp[2]:
+        for g, (o, sz) in zip(out, ext):
+            has_child = any(c.level == g.level + 1 and all(c.disp[d] // 2 >= o[d] and (c.disp[d] + c.Nx[d]) // 2 <= o[d] + sz[d]
+                                                           for d in range(3)) for c in out)
+            if g.level and has_child and (g.disp[1] or g.disp[2]):
                 raise ParError(f"[config]: radiation across a displaced parent (level {g.level}) is undefined in the "
                                "reference; set AA_SMR_DEEP_RADIATION=fixed for the corrected hand-off")
     return out
 
 
-# ---- static mesh refinement across several GPUs ---------------------------------------------------
 # Every level is cut at the SAME planes as the root (x3 slabs, SURVEY.md 8e "co-partitioned"): rank r
 # owns root planes [K_r, K_r+1) and, of level l, the zones lying over them.  Restriction, the
 # radiation hand-off and prolongation then stay inside a rank (prolongation reads the parent's
@@ -305,6 +312,8 @@ def balanced_cuts(levs: List[GridConfig], nranks: int) -> Tuple[int, ...]:
 def mesh_slabs(par: ParTable, run: RunConfig, rank: int, nranks: int,
                cuts: Optional[Sequence[int]] = None) -> MeshSlabConfig:
     levs = levels(par, run)
+    if len({g.level for g in levs}) != len(levs):
+        raise ParError("[config]: several Domains on a level are not cut across GPUs (one process: Mesh / the drop-in shim)")
     n3 = run.rootNx[2]
     cuts = tuple(cuts) if cuts is not None else balanced_cuts(levs, nranks)
     if len(cuts) != nranks + 1 or cuts[0] != 0 or cuts[-1] != n3 or any(b - a < NGHOST for a, b in zip(cuts, cuts[1:])):

@@ -1344,10 +1344,15 @@ int orc_step(OrcSim *s)
  * reference adds between the levels.  No send/receive buffers: values are taken from the
  * other level directly, in the reference's summation order.                                */
 
-#define ORC_MAXLEV 8
+#define ORC_MAXLEV 16
+/* Grids in the order of the reference's loops: level by level from the root, Domains of a level in deck order
+ * (MeshS.Domain[nl][nd]).  Link L joins grid L+1 (the child) to grid par[L] (its parent): with one Domain per level
+ * par[L] = L.  Domains of a level neither overlap nor touch (init_mesh.c:398-418), so a child has ONE parent. */
 struct OrcMesh {
-  int nl;
+  int nl;                    /* number of Grids */
   OrcSim *lev[ORC_MAXLEV];
+  int par[ORC_MAXLEV];       /* par[L]: parent grid of grid L+1 */
+  int f2c[ORC_MAXLEV];       /* the links finest level first, deck order inside a level (RestrictCorrect, smr.c:1224) */
   /* overlap of level l+1 on level l in level-l indices (init_grid.c: CGrid.ijks/ijke) */
   int cs[ORC_MAXLEV][3], ce[ORC_MAXLEV][3];
   int prol[ORC_MAXLEV][6];   /* level l+1 has a fine/coarse boundary on this side (myFlx != NULL): its ghost
@@ -1366,8 +1371,19 @@ struct OrcMesh {
 
 static Cons *cz(size_t n) { return (Cons*)calloc(n ? n : 1, sizeof(Cons)); }
 
+/* order of the links for the fine-to-coarse passes */
+static void mesh_order(OrcMesh *m)
+{
+  int L, n = 0, lev, maxlev = 0;
+  for (L = 0; L + 1 < m->nl; L++) if (m->lev[L+1]->level > maxlev) maxlev = m->lev[L+1]->level;
+  for (lev = maxlev; lev >= 1; lev--) for (L = 0; L + 1 < m->nl; L++) if (m->lev[L+1]->level == lev) m->f2c[n++] = L;
+}
+
 /* links[21*l ..]: cs[3] (local parent index incl. ghosts), n[3], prol[6], corr[6], cdisp[3] of level l+1 on level l */
+static OrcMesh *mesh_create_links(int nlevels, const OrcParams *p, const int *links, const int *level, const int *par);
 OrcMesh *orc_mesh_create_local(int nlevels, const OrcParams *p, const int *links)
+{ return mesh_create_links(nlevels, p, links, NULL, NULL); }
+static OrcMesh *mesh_create_links(int nlevels, const OrcParams *p, const int *links, const int *level, const int *par)
 {
   OrcMesh *m; int l, d;
   if (nlevels < 1 || nlevels > ORC_MAXLEV) return NULL;
@@ -1375,10 +1391,12 @@ OrcMesh *orc_mesh_create_local(int nlevels, const OrcParams *p, const int *links
   m->nl = nlevels;
   for (l = 0; l < nlevels; l++) {
     OrcSim *s = orc_create(&p[l]);
-    s->level = l;
-    for (d = 0; d < 3; d++) s->dx[d] = s->rootdx[d]/(Real)(1 << l);                       /* init_mesh.c:245 */
+    s->level = level ? level[l] : l;
+    for (d = 0; d < 3; d++) s->dx[d] = s->rootdx[d]/(Real)(1 << s->level);               /* init_mesh.c:245 */
     m->lev[l] = s;
   }
+  for (l = 0; l + 1 < nlevels; l++) m->par[l] = par ? par[l] : l;
+  mesh_order(m);
   for (l = 0; l + 1 < nlevels; l++) {
     const int *L = links + 21*l; int n[3];
     for (d = 0; d < 3; d++) { m->cs[l][d] = L[d]; n[d] = L[3+d]; m->ce[l][d] = L[d] + n[d] - 1; m->cdisp[l][d] = L[18+d]; }
@@ -1394,38 +1412,62 @@ OrcMesh *orc_mesh_create_local(int nlevels, const OrcParams *p, const int *links
   return m;
 }
 
-OrcMesh *orc_mesh_create(int nlevels, const OrcParams *p, const int *disp)
+/* level[g]: DomainS.Level of grid g (grids level by level from the root, deck order inside a level); disp[3g..]: its
+ * iDisp/jDisp/kDisp in zones of its level.  The parent of a grid is the Domain of the level below that contains it. */
+OrcMesh *orc_mesh_create_tree(int ngrids, const OrcParams *p, const int *level, const int *disp)
 {
-  int links[21*ORC_MAXLEV], l, d;
-  if (nlevels < 1 || nlevels > ORC_MAXLEV) return NULL;
-  for (l = 0; l + 1 < nlevels; l++) {
-    int *L = links + 21*l, irefine = 1 << (l+1);
-    const int *dp = disp + 3*l, *dc = disp + 3*(l+1);
+  int links[21*ORC_MAXLEV], par[ORC_MAXLEV], l, d, c;
+  if (ngrids < 1 || ngrids > ORC_MAXLEV || level[0] != 0) return NULL;
+  for (c = 1; c < ngrids; c++) {
+    int *L = links + 21*(c-1), irefine = 1 << level[c], P = -1, q;
+    const int *dc = disp + 3*c, *dp;
+    if (level[c] < level[c-1] || level[c] < 1) return NULL;
+    for (q = 0; q < c && P < 0; q++) {
+      int inside = (level[q] == level[c] - 1);
+      for (d = 0; d < 3 && inside; d++) {
+        const int dq = (level[q] ? disp[3*q + d] : 0);
+        if (dc[d]/2 < dq || (dc[d] + p[c].Nx[d])/2 > dq + p[q].Nx[d]) inside = 0;
+      }
+      if (inside) P = q;
+    }
+    if (P < 0) { fprintf(stderr, "[orc_mesh_create]: grid %d (level %d) is not nested in a Domain of level %d\n", c, level[c], level[c]-1); return NULL; }
+    par[c-1] = P; l = P;
+    dp = disp + 3*P;
     for (d = 0; d < 3; d++) {
       /* init_grid.c: G3 = child extent/2 clipped to this Grid; the child must be nested */
-      int a = dc[d]/2 - dp[d], b = (dc[d] + p[l+1].Nx[d])/2 - dp[d];
-      if ((dc[d] & 1) || (p[l+1].Nx[d] & 1) || a < 0 || b > p[l].Nx[d]) {
-        fprintf(stderr, "[orc_mesh_create]: level %d is not nested in level %d along x%d\n", l+1, l, d+1);
+      const int dpd = level[P] ? dp[d] : 0;
+      int a = dc[d]/2 - dpd, b = (dc[d] + p[c].Nx[d])/2 - dpd;
+      if ((dc[d] & 1) || (p[c].Nx[d] & 1) || a < 0 || b > p[l].Nx[d]) {
+        fprintf(stderr, "[orc_mesh_create]: grid %d is not nested in grid %d along x%d\n", c, l, d+1);
         return NULL;
       }
       L[d] = a + NGHOST; L[3+d] = b - a; L[18+d] = dc[d];
       L[6+2*d]   = L[12+2*d]   = (dc[d] != 0);
-      L[6+2*d+1] = L[12+2*d+1] = ((dc[d] + p[l+1].Nx[d])/irefine != p[l+1].rootNx[d]);
+      L[6+2*d+1] = L[12+2*d+1] = ((dc[d] + p[c].Nx[d])/irefine != p[c].rootNx[d]);
     }
     /* ionrad_smr.c:97-98 mixes an index local to the parent Grid with the child's root-relative Disp:
      * only meaningful while the parent is not displaced across the rays.  ORC_SMR_DEEP_RADIATION=fixed
      * selects what the formula evidently means (child origin minus twice the parent's); that mode has
      * no reference behaviour behind it and only serves to check the product's same-named mode. */
-    if (p[0].ion && (dp[1] || dp[2])) {
+    if (p[0].ion && level[P] && (dp[1] || dp[2])) {
       const char *e = getenv("ORC_SMR_DEEP_RADIATION");
       if (!(e && strcmp(e, "fixed") == 0)) {
-        fprintf(stderr, "[orc_mesh_create]: radiation across a displaced parent (level %d) is undefined in the reference\n", l);
+        fprintf(stderr, "[orc_mesh_create]: radiation across a displaced parent (grid %d) is undefined in the reference\n", l);
         return NULL;
       }
       for (d = 0; d < 3; d++) L[18+d] = dc[d] - 2*dp[d];
     }
   }
-  return orc_mesh_create_local(nlevels, p, links);
+  return mesh_create_links(ngrids, p, links, level, par);
+}
+
+/* one Domain per level: level l = grid l */
+OrcMesh *orc_mesh_create(int nlevels, const OrcParams *p, const int *disp)
+{
+  int level[ORC_MAXLEV], l;
+  if (nlevels < 1 || nlevels > ORC_MAXLEV) return NULL;
+  for (l = 0; l < nlevels; l++) level[l] = l;
+  return orc_mesh_create_tree(nlevels, p, level, disp);
 }
 
 void orc_mesh_destroy(OrcMesh *m)
@@ -1487,7 +1529,7 @@ static Cons restrict_flux(const OrcSim *F, int dir, int nidx, int slow, int fast
  * zones just outside, :1277-1340).  RestrictCorrect is this for l = nl-2 ... 0. */
 static void restrict_correct_pair(OrcMesh *m, int l)
 {
-  OrcSim *G = m->lev[l]; const OrcSim *F = m->lev[l+1];
+  OrcSim *G = m->lev[m->par[l]]; const OrcSim *F = m->lev[l+1];      /* link l: grid l+1 on its parent */
   const int *cs = m->cs[l], *ce = m->ce[l];
   const int nn[3] = {ce[0]-cs[0]+1, ce[1]-cs[1]+1, ce[2]-cs[2]+1};
   int i, j, k, n, dim;
@@ -1539,25 +1581,28 @@ static void restrict_correct(OrcMesh *m, int first)
 {
   int l;
   (void)first;
-  for (l = m->nl - 2; l >= 0; l--) restrict_correct_pair(m, l);
+  for (l = 0; l + 1 < m->nl; l++) restrict_correct_pair(m, m->f2c[l]);      /* finest level first, deck order inside a level */
 }
 
-/* smr.c:85 ionradRestrictCorrect: E and s[0] only, after the radiation step */
+/* smr.c:85 ionradRestrictCorrect: E and s[0] only, after the radiation step.  Finest level first; a Grid takes what its
+ * children restricted (in their order), then restricts itself for its parent. */
 static void ion_restrict_correct(OrcMesh *m)
 {
-  int l, i, j, k;
-  for (l = m->nl - 1; l >= 0; l--) {
-    OrcSim *G = m->lev[l];
-    if (l + 1 < m->nl) {
-      const int *cs = m->cs[l], *ce = m->ce[l];
-      const Cons *r = m->rU[l];
+  int g, L, i, j, k, lev, maxlev = 0;
+  for (g = 0; g < m->nl; g++) if (m->lev[g]->level > maxlev) maxlev = m->lev[g]->level;
+  for (lev = maxlev; lev >= 0; lev--) for (g = 0; g < m->nl; g++) {
+    OrcSim *G = m->lev[g];
+    if (G->level != lev) continue;
+    for (L = 0; L + 1 < m->nl; L++) if (m->par[L] == g) {
+      const int *cs = m->cs[L], *ce = m->ce[L];
+      const Cons *r = m->rU[L];
       for (k = cs[2]; k <= ce[2]; k++) for (j = cs[1]; j <= ce[1]; j++) for (i = cs[0]; i <= ce[0]; i++, r++) {
         Cons *u = &G->U[IDX(G,k,j,i)];
         u->E = r->E; u->s = r->s;
       }
     }
-    if (l > 0) {
-      Cons *r = m->rU[l-1];
+    if (g > 0) {
+      Cons *r = m->rU[g-1];
       for (k = G->ks; k <= G->ke; k += 2) for (j = G->js; j <= G->je; j += 2) for (i = G->is; i <= G->ie; i += 2)
         *r++ = restrict_zone(G, i, j, k);
     }
@@ -1616,10 +1661,10 @@ static void prolongate(OrcMesh *m)
 {
   int l, i, j, k, dim;
   for (l = 0; l < m->nl; l++) {
-    OrcSim *G = m->lev[l];
-    if (l + 1 < m->nl) {                                           /* Step 1 :2397-2470 */
-      const int *cs = m->cs[l], *ce = m->ce[l];
-      Cons *b = m->box[l];
+    OrcSim *G = m->lev[l]; int L;
+    for (L = 0; L + 1 < m->nl; L++) if (m->par[L] == l) {          /* Step 1 :2397-2470, for every child */
+      const int *cs = m->cs[L], *ce = m->ce[L];
+      Cons *b = m->box[L];
       for (k = cs[2]-3; k <= ce[2]+3; k++) for (j = cs[1]-3; j <= ce[1]+3; j++) for (i = cs[0]-3; i <= ce[0]+3; i++)
         *b++ = G->U[IDX(G,k,j,i)];
     }
@@ -1652,15 +1697,17 @@ static void prolongate(OrcMesh *m)
 
 /* ionrad_smr.c:345 ionrad_prolong_snd (dim 0: rays along +x1): the flux this level left at the
  * upstream face of its child, one value per coarse ray plus one extra row and column */
-static void ionrad_prolong_snd(OrcMesh *m, int l)
+static void ionrad_prolong_snd(OrcMesh *m, int g)
 {
-  const OrcSim *G; const int *cs, *ce; int j, k, n0, n1, fixed, w;
-  if (l + 1 >= m->nl || !m->prol[l][0]) return;
-  G = m->lev[l]; cs = m->cs[l]; ce = m->ce[l];
-  n0 = G->p.Nx[0]+1; n1 = G->p.Nx[1]+1;
-  fixed = cs[0] - NGHOST; w = ce[1] - cs[1] + 2;
-  for (k = cs[2] - NGHOST; k <= ce[2]+1 - NGHOST; k++) for (j = cs[1] - NGHOST; j <= ce[1]+1 - NGHOST; j++)
-    m->ionflx[l][(size_t)(k-(cs[2]-NGHOST))*w + j-(cs[1]-NGHOST)] = G->EdgeFlux[((size_t)k*n1 + j)*n0 + fixed];
+  const OrcSim *G = m->lev[g]; const int *cs, *ce; int j, k, n0, n1, fixed, w, l;
+  for (l = 0; l + 1 < m->nl; l++) {                               /* every child of grid g */
+    if (m->par[l] != g || !m->prol[l][0]) continue;
+    cs = m->cs[l]; ce = m->ce[l];
+    n0 = G->p.Nx[0]+1; n1 = G->p.Nx[1]+1;
+    fixed = cs[0] - NGHOST; w = ce[1] - cs[1] + 2;
+    for (k = cs[2] - NGHOST; k <= ce[2]+1 - NGHOST; k++) for (j = cs[1] - NGHOST; j <= ce[1]+1 - NGHOST; j++)
+      m->ionflx[l][(size_t)(k-(cs[2]-NGHOST))*w + j-(cs[1]-NGHOST)] = G->EdgeFlux[((size_t)k*n1 + j)*n0 + fixed];
+  }
 }
 
 /* ionrad_smr.c:34 ionrad_prolong_rcv: piecewise-constant copy onto the 2x2 fine rays */
@@ -1692,7 +1739,7 @@ static void ionrad_prolong_rcv(OrcMesh *m, int l)
 static int ion_radtransfer_level(OrcMesh *m, int l)
 {
   OrcSim *s = m->lev[l];
-  const int finegrid = (l != 0);
+  const int finegrid = (s->level != 0);
   Real dt_chem, dt_therm, dt_hydro, dt, dt_done = 0.0;
   int niter = 0, hydro_done = 0, coarsetime_done = 0, nchem = 0, ntherm = 0;
   if (finegrid) ionrad_prolong_rcv(m, l); else m->tcoarse = 0;
@@ -1743,7 +1790,7 @@ void orc_mesh_restrict_correct(OrcMesh *m) { restrict_correct(m, 0); }
 void orc_mesh_restrict_correct_pair(OrcMesh *m, int l) { restrict_correct_pair(m, l); }
 void orc_mesh_ion_restrict_correct(OrcMesh *m) { ion_restrict_correct(m); }
 void orc_mesh_prolongate(OrcMesh *m) { prolongate(m); }
-void orc_mesh_ionflux_prolong(OrcMesh *m, int l) { ionrad_prolong_snd(m, l-1); ionrad_prolong_rcv(m, l); }
+void orc_mesh_ionflux_prolong(OrcMesh *m, int l) { ionrad_prolong_snd(m, m->par[l-1]); ionrad_prolong_rcv(m, l); }
 void orc_cfl_max_v(OrcSim *s, double v[3])
 { Real dti = 0.0; v[0] = v[1] = v[2] = 0.0; cfl_accumulate(s, v, &dti); }
 

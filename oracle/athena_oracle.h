@@ -93,6 +93,9 @@ double orc_ion_dt_hydro(OrcSim *s);                                /* :593-669  
  * before orc_mesh_start(). */
 typedef struct OrcMesh OrcMesh;
 OrcMesh *orc_mesh_create(int nlevels, const OrcParams *p, const int *disp);
+/* several Domains on a level (MeshS.Domain[nl][nd]): grids level by level from the root, deck order inside a level;
+ * level[g] = DomainS.Level, disp[3g..] = iDisp/jDisp/kDisp.  Domains of a level neither overlap nor touch (init_mesh.c:398-418). */
+OrcMesh *orc_mesh_create_tree(int ngrids, const OrcParams *p, const int *level, const int *disp);
 void     orc_mesh_destroy(OrcMesh *m);
 OrcSim  *orc_mesh_level(OrcMesh *m, int l);
 void     orc_mesh_start(OrcMesh *m);               /* main.c:395-447 */

@@ -315,11 +315,23 @@ def smr_runs():
          + ["domain1/bc_ix1=2", "domain1/bc_ox1=2", "domain1/bc_ix2=2", "domain1/bc_ox2=2", "domain1/bc_ix3=1",
             "domain1/bc_ox3=1", "domain1/x2min=-0.5", "domain1/x2max=0.5", "problem/radius=0.3"]),
     ]
+    # several Domains on a level (MeshS.Domain[nl][nd]): two level-1 patches one root zone apart in x1 with overlapping x2 / x3
+    # ranges -- the root zones between them are flux-corrected from both -- and two patches that both take the radiation
+    # from the root
+    cases += [
+        ("smr_blast_2dom_s6", "blast_smr", blast, ["job/maxout=1", "output1/out_fmt=rst", "output1/dt=1e300"], 6, 0, False,
+         ["job/num_domains=3"] + dom(1, (16, 24, 16)) + dom(2, (12, 16, 20), (8, 20, 6)) + ["domain3/level=1"] + dom(3, (6, 8, 8), (22, 24, 10))),
+        ("smr_ioniz_sphere_2dom_s3", "ioniz_sphere_smr", sphere, ["job/maxout=1", "output1/dt=1e300"], 3, 1, True,
+         ["job/num_domains=3"] + dom(1, (32, 32, 32)) + dom(2, (32, 28, 24), (16, 18, 20)) + ["domain3/level=1"] + dom(3, (16, 16, 12), (8, 20, 48))
+         + ["problem/rp=2.1e10"]),
+    ]
     # the same 2-level blast with the van Leer integrator and with third-order reconstruction
     two = ["job/num_domains=2"] + dom(1, (16, 24, 16)) + dom(2, (12, 16, 20), (8, 20, 6))
     cases += [("smr_vl_blast_2lev_s5", "blast_smr_vl", blast, ["job/maxout=1", "output1/out_fmt=rst", "output1/dt=1e300"], 5, 0, False, two),
               ("smr_ppm_blast_2lev_s5", "blast_smr_ppm", blast, ["job/maxout=1", "output1/out_fmt=rst", "output1/dt=1e300"], 5, 0, False, two)]
     for name, cfg, deck, refextra, nlim, nscal, ion, over in cases:
+        if os.environ.get("GOLDEN_ONLY") and os.environ["GOLDEN_ONLY"] not in name:
+            continue                                   # (regenerate a subset: GOLDEN_ONLY=2dom python make_golden.py smr)
         nlev = int(over[0].split("=")[1])
         nxs = [tuple(int(next(o for o in over if o.startswith(f"domain{n}/Nx{d}=")).split("=")[1]) for d in (1, 2, 3))
                for n in range(1, nlev + 1)]

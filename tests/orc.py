@@ -82,6 +82,7 @@ def lib():
         L.orc_mesh_time.restype = D; L.orc_mesh_time.argtypes = [P]
         L.orc_mesh_dt.restype = D; L.orc_mesh_dt.argtypes = [P]
         L.orc_mesh_nstep.restype = C.c_int; L.orc_mesh_nstep.argtypes = [P]
+        L.orc_mesh_create_tree.restype = P; L.orc_mesh_create_tree.argtypes = [C.c_int, C.POINTER(OrcParams), C.POINTER(C.c_int), C.POINTER(C.c_int)]
         L.orc_mesh_create_local.restype = P; L.orc_mesh_create_local.argtypes = [C.c_int, C.POINTER(OrcParams), C.POINTER(C.c_int)]
         for f in ("orc_mesh_restrict_correct", "orc_mesh_ion_restrict_correct", "orc_mesh_prolongate"):
             getattr(L, f).argtypes = [P]; getattr(L, f).restype = None
@@ -284,7 +285,8 @@ class Mesh:
         pa = (OrcParams * n)(*[params_from_grid(g) for g in grids])
         if links is None:
             da = (C.c_int * (3 * n))(*[g.disp[d] if g.level else 0 for g in grids for d in range(3)])
-            self.h = self.L.orc_mesh_create(n, pa, da)
+            la = (C.c_int * n)(*[g.level for g in grids])
+            self.h = self.L.orc_mesh_create_tree(n, pa, la, da)       # grids: level by level, deck order inside a level
         else:
             flat = [v for L_ in links for v in (*L_.cs, *L_.n, *L_.prol, *L_.corr, *L_.cdisp)]
             self.h = self.L.orc_mesh_create_local(n, pa, (C.c_int * max(1, len(flat)))(*flat))
