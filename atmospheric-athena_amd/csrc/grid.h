@@ -93,7 +93,7 @@ struct IonPart { Real dt_chem, dt_therm, max_dti, cellcount, neg; };
 
 // face planes (index along the normal, incl. ghost offset) whose second-pass fluxes the fused kernel also
 // stores: the level boundaries static mesh refinement reads back (smr.hip)
-struct KeepPlanes { int n; int p[3][4]; };
+struct KeepPlanes { int n; int p[3][8]; };       // own two boundary planes + the outlines of up to three children (unused slots repeat the first)
 #include "hydro_launch.h"
 }  // namespace aa
 namespace aa_cool {       // hydro_kernels.hip compiled with -DAA_COOLING=1 (see hydro_launch.h)

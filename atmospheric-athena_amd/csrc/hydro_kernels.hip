@@ -1049,7 +1049,8 @@ AA_DEV void atomic_max_pos(unsigned long long *addr, Real v)
 
 AA_DEV bool on_plane(const KeepPlanes &kp, int d, int x)
 {
-  return x == kp.p[d][0] || x == kp.p[d][1] || x == kp.p[d][2] || x == kp.p[d][3];
+  return x == kp.p[d][0] || x == kp.p[d][1] || x == kp.p[d][2] || x == kp.p[d][3] ||
+         x == kp.p[d][4] || x == kp.p[d][5] || x == kp.p[d][6] || x == kp.p[d][7];
 }
 
 // CFL: the zone's contribution to new_dt's maxima is taken from the updated state while it is in registers (k_cfl would

@@ -24,7 +24,7 @@
 using namespace aa;
 
 #define NG AA_NGHOST
-#define AA_MAXLEV 8
+#define AA_MAXLEV 16     /* Grids of a Mesh (one per Domain) */
 
 namespace {
 
@@ -237,12 +237,17 @@ inline unsigned nblk(long n, int b) { return (unsigned)((n + b - 1)/b); }
 
 }  // namespace
 
+// Grids in the order of the reference's loops: level by level from the root, Domains of a level in deck order
+// (MeshS.Domain[nl][nd]).  Link L joins grid L+1 (the child) to grid par[L] (its parent); with one Domain per level par[L] = L.
+// Domains of a level neither overlap nor touch (init_mesh.c:398-418): a child has ONE parent.
 struct aa_mesh {
-  int nl = 0;
+  int nl = 0;                      // number of Grids
   aa_grid *lev[AA_MAXLEV];
   int disp[AA_MAXLEV][3];
-  Link link[AA_MAXLEV];            // link[l]: level l+1 on level l
-  Real *box[AA_MAXLEV];            // prolongation snapshot of level l around level l+1
+  int par[AA_MAXLEV];              // par[L]: parent grid of grid L+1
+  int f2c[AA_MAXLEV];              // the links finest level first, deck order inside a level (smr.c:1224)
+  Link link[AA_MAXLEV];            // link[L]: grid L+1 on grid par[L]
+  Real *box[AA_MAXLEV];            // prolongation snapshot of the parent's zones around grid L+1
   hipStream_t st = nullptr; bool own_stream = true;
   double tcoarse = 0;              // ionrad_3d.c:44
   double time = 0, dt = 0; int nstep = 0;   // MeshS
@@ -266,12 +271,20 @@ static int mesh_finish(aa_mesh *m, aa_grid **levels, aa_mesh **out)
   for (int l = 0; l < m->nl; l++) {
     aa_grid *g = m->lev[l];
     const int lo[3] = {g->d.is, g->d.js, g->d.ks}, hi[3] = {g->d.ie, g->d.je, g->d.ke};
-    g->keep.n = 4;
-    for (int d = 0; d < 3; d++) {
-      g->keep.p[d][0] = lo[d]; g->keep.p[d][1] = hi[d] + 1;
-      g->keep.p[d][2] = (l + 1 < m->nl) ? m->link[l].cs[d] : lo[d];
-      g->keep.p[d][3] = (l + 1 < m->nl) ? m->link[l].ce[d] + 1 : lo[d];
+    g->keep.n = 8;
+    int nch = 0;
+    for (int d = 0; d < 3; d++) { for (int q = 0; q < 8; q++) g->keep.p[d][q] = lo[d]; g->keep.p[d][1] = hi[d] + 1; }
+    for (int L = 0; L + 1 < m->nl; L++) {
+      if (m->par[L] != l) continue;
+      if (nch == 3) return aa_fail(-1, "[aa_mesh_create]: more than three child Domains on one Grid");
+      for (int d = 0; d < 3; d++) { g->keep.p[d][2 + 2*nch] = m->link[L].cs[d]; g->keep.p[d][3 + 2*nch] = m->link[L].ce[d] + 1; }
+      nch++;
     }
+  }
+  { // the links finest level first, deck order inside a level
+    int n = 0, maxlev = 0;
+    for (int L = 0; L + 1 < m->nl; L++) if (m->lev[L + 1]->level > maxlev) maxlev = m->lev[L + 1]->level;
+    for (int lev = maxlev; lev >= 1; lev--) for (int L = 0; L + 1 < m->nl; L++) if (m->lev[L + 1]->level == lev) m->f2c[n++] = L;
   }
   *out = m;
   return 0;
@@ -284,10 +297,11 @@ static aa_mesh *mesh_alloc(int nlevels, aa_grid **levels)
   m->nl = nlevels;
   for (int l = 0; l < nlevels; l++) {
     aa_grid *g = levels[l];
-    if (!g || g->level != l) { delete m; aa_fail(-1, "[aa_mesh_create]: levels[%d] was not created with level=%d", l, l); return nullptr; }
+    if (!g || (l == 0 ? g->level != 0 : (g->level < 1 || g->level < levels[l - 1]->level || g->level > levels[l - 1]->level + 1))) {
+      delete m; aa_fail(-1, "[aa_mesh_create]: grids must come level by level from the root (grid %d)", l); return nullptr; }
     if (!g->slab.empty()) { delete m; aa_fail(-1, "[aa_mesh_create]: levels[%d] is cut into slabs (aa_params.nslab / AA_NGPU): nested levels stay on one device", l); return nullptr; }
     if (g->p.device != levels[0]->p.device) { delete m; aa_fail(-1, "[aa_mesh_create]: all levels must live on one device"); return nullptr; }
-    m->lev[l] = g; m->box[l] = nullptr;
+    m->lev[l] = g; m->box[l] = nullptr; m->par[l] = l;
     g->keep_flux = true;
   }
   return m;
@@ -300,24 +314,48 @@ int aa_mesh_create(int nlevels, aa_grid **levels, const int *disp, aa_mesh **out
   if (!disp || !out) return aa_fail(-1, "[aa_mesh_create]: bad arguments");
   aa_mesh *m = mesh_alloc(nlevels, levels);
   if (!m) return -1;
-  for (int l = 0; l + 1 < nlevels; l++) {
-    const aa_grid *P = m->lev[l], *C = m->lev[l + 1];
+  for (int c = 1; c < nlevels; c++) {
+    const aa_grid *C = m->lev[c];
+    const int *dc = disp + 3*c;
+    // the Domain of the level below that contains this one
+    int pi = -1;
+    for (int q = 0; q < c && pi < 0; q++) {
+      const aa_grid *Q = m->lev[q];
+      bool inside = (Q->level == C->level - 1);
+      for (int d = 0; d < 3 && inside; d++) {
+        const int dq = Q->level ? disp[3*q + d] : 0;
+        if (dc[d]/2 < dq || (dc[d] + C->p.Nx[d])/2 > dq + Q->p.Nx[d]) inside = false;
+      }
+      if (inside) pi = q;
+    }
+    if (pi < 0) { delete m; return aa_fail(-1, "[aa_mesh_create]: grid %d (level %d) is not nested in a Domain of level %d", c, C->level, C->level - 1); }
+    const int l = c - 1;
+    m->par[l] = pi;
+    const aa_grid *P = m->lev[pi];
     Link &L = m->link[l];
     const int lo[3] = {P->d.is, P->d.js, P->d.ks};
-    const int irefine = 1 << (l + 1);
-    const int *dp = disp + 3*l, *dc = disp + 3*(l + 1);
+    const int irefine = 1 << C->level;
+    const int dp[3] = {P->level ? disp[3*pi] : 0, P->level ? disp[3*pi + 1] : 0, P->level ? disp[3*pi + 2] : 0};
     for (int d = 0; d < 3; d++) {
       const int a = dc[d]/2 - dp[d], b = (dc[d] + C->p.Nx[d])/2 - dp[d];
       if ((dc[d] & 1) || (C->p.Nx[d] & 1) || a < 0 || b > P->p.Nx[d]) {
-        delete m; return aa_fail(-1, "[aa_mesh_create]: level %d is not nested in level %d along x%d", l + 1, l, d + 1);
+        delete m; return aa_fail(-1, "[aa_mesh_create]: grid %d is not nested in grid %d along x%d", c, pi, d + 1);
       }
       L.cs[d] = a + lo[d]; L.ce[d] = b + lo[d] - 1; L.n[d] = b - a; L.cdisp[d] = dc[d];
       L.prol[2*d]     = L.corr[2*d]     = (dc[d] != 0);
       L.prol[2*d + 1] = L.corr[2*d + 1] = ((dc[d] + C->p.Nx[d])/irefine != C->p.rootNx[d]);
       // init_mesh.c:320-360: a child may touch its parent's edge only on the root boundary
       if ((a == 0 && L.prol[2*d]) || (b == P->p.Nx[d] && L.prol[2*d + 1])) {
-        delete m; return aa_fail(-1, "[init_mesh] child Domain of level %d touches its parent in x%d", l + 1, d + 1);
+        delete m; return aa_fail(-1, "[init_mesh] child Domain (grid %d) touches its parent in x%d", c, d + 1);
       }
+    }
+    // init_mesh.c:398-418: Domains on the same level neither overlap nor touch
+    for (int q = 1; q < c; q++) {
+      const aa_grid *Q = m->lev[q];
+      if (Q->level != C->level) continue;
+      bool sep = false;
+      for (int d = 0; d < 3; d++) if (dc[d] > disp[3*q + d] + Q->p.Nx[d] || disp[3*q + d] > dc[d] + C->p.Nx[d]) sep = true;
+      if (!sep) { delete m; return aa_fail(-1, "[init_mesh]: Domains at the same level overlap or touch (grids %d and %d)", q, c); }
     }
     // ionrad_smr.c:97-98 mixes a parent-local index with the child's root-relative Disp: with a displaced
     // parent (3+ levels) the reference writes out of bounds.  Refused by default; AA_SMR_DEEP_RADIATION=fixed
@@ -326,8 +364,8 @@ int aa_mesh_create(int nlevels, aa_grid **levels, const int *disp, aa_mesh **out
     if (P->p.ion && (dp[1] || dp[2])) {
       const char *e = getenv("AA_SMR_DEEP_RADIATION");
       if (!(e && strcmp(e, "fixed") == 0)) {
-        delete m; return aa_fail(-1, "[aa_mesh_create]: radiation across a displaced parent (level %d) is undefined in the reference "
-                                     "(set AA_SMR_DEEP_RADIATION=fixed for the corrected hand-off)", l);
+        delete m; return aa_fail(-1, "[aa_mesh_create]: radiation across a displaced parent (grid %d) is undefined in the reference "
+                                     "(set AA_SMR_DEEP_RADIATION=fixed for the corrected hand-off)", pi);
       }
       for (int d = 0; d < 3; d++) L.cdisp[d] = dc[d] - 2*dp[d];
     }
@@ -388,7 +426,7 @@ int aa_mesh_set_state(aa_mesh *m, double time, double dt, int nstep)
 int aa_mesh_restrict_correct_pair(aa_mesh *m, int l)      // level l+1 -> level l
 {
   if (l < 0 || l + 1 >= m->nl) return aa_fail(-1, "[aa_mesh_restrict_correct_pair]: pair %d", l);
-  aa_grid *P = m->lev[l], *C = m->lev[l + 1];
+  aa_grid *P = m->lev[m->par[l]], *C = m->lev[l + 1];       // link l: grid l+1 on its parent
   const Link &L = m->link[l];
   const int nvar = 5 + P->p.nscal;
   Scope s(P, "smr_restrict_correct");
@@ -408,15 +446,16 @@ int aa_mesh_restrict_correct(aa_mesh *m)
 {
   // finest pair first: a level is restricted for its parent after it received its own child's
   // solution and flux correction (the order of the loop over levels at smr.c:1224)
-  for (int l = m->nl - 2; l >= 0; l--) { int rc = aa_mesh_restrict_correct_pair(m, l); if (rc) return rc; }
+  for (int l = 0; l + 1 < m->nl; l++) { int rc = aa_mesh_restrict_correct_pair(m, m->f2c[l]); if (rc) return rc; }
   return 0;
 }
 
 // smr.c:85: E and s[0] only, after the radiation step
 int aa_mesh_ionrad_restrict_correct(aa_mesh *m)
 {
-  for (int l = m->nl - 2; l >= 0; l--) {
-    aa_grid *P = m->lev[l], *C = m->lev[l + 1];
+  for (int q = 0; q + 1 < m->nl; q++) {
+    const int l = m->f2c[q];
+    aa_grid *P = m->lev[m->par[l]], *C = m->lev[l + 1];
     const Link &L = m->link[l];
     Scope s(P, "smr_ion_restrict");
     hipLaunchKernelGGL(k_restrict, dim3(nblk((long)L.n[0]*L.n[1]*L.n[2], 256)), dim3(256), 0, m->st,
@@ -430,10 +469,11 @@ int aa_mesh_ionrad_restrict_correct(aa_mesh *m)
 int aa_mesh_prolongate(aa_mesh *m)
 {
   for (int l = 0; l < m->nl; l++) {
-    if (l + 1 < m->nl) {                       // Step 1: hand the zones around the child over
-      const Link &L = m->link[l];
+    for (int c = 0; c + 1 < m->nl; c++) {      // Step 1: hand the zones around every child over
+      if (m->par[c] != l) continue;
+      const Link &L = m->link[c];
       const long nb = (long)(L.n[0] + 6)*(L.n[1] + 6)*(L.n[2] + 6);
-      hipLaunchKernelGGL(k_box_copy, dim3(nblk(nb, 256)), dim3(256), 0, m->st, m->lev[l]->d, L, m->box[l]);
+      hipLaunchKernelGGL(k_box_copy, dim3(nblk(nb, 256)), dim3(256), 0, m->st, m->lev[l]->d, L, m->box[c]);
     }
     if (l > 0) {                               // Steps 2-3: own ghost zones from the parent's zones
       aa_grid *C = m->lev[l];
@@ -481,10 +521,11 @@ int aa_mesh_ionflux_prolong(aa_mesh *m, int l)
 {
   if (l < 1 || l >= m->nl) return aa_fail(-1, "[aa_mesh_ionflux_prolong]: level %d", l);
   const Link &L = m->link[l - 1];
-  { int rc = aa_edgeflux_ready(m->lev[l - 1]); if (rc) return rc; }       // the parent's EdgeFlux of its last sweep
+  aa_grid *P = m->lev[m->par[l - 1]];
+  { int rc = aa_edgeflux_ready(P); if (rc) return rc; }       // the parent's EdgeFlux of its last sweep
   if (L.prol[0])
     hipLaunchKernelGGL(k_ionflux_prolong, dim3(nblk((long)(L.n[1] + 1)*(L.n[2] + 1), 256)), dim3(256), 0, m->st,
-                       m->lev[l]->d, m->lev[l - 1]->d, L);
+                       m->lev[l]->d, P->d, L);
   HIPCHK(hipGetLastError());
   return 0;
 }
@@ -515,7 +556,7 @@ int aa_flux_x3_apply(aa_grid *parent, int side, int i0, int j0, int n1, int n2, 
 int aa_mesh_ion_radtransfer(aa_mesh *m, int l, int *niter_out)
 {
   aa_grid *g = m->lev[l];
-  const bool finegrid = (l != 0);
+  const bool finegrid = (g->level != 0);
   double dt_done = 0.0;
   int niter = 0, rc;
   if (finegrid) { if ((rc = aa_mesh_ionflux_prolong(m, l))) return rc; }

@@ -44,11 +44,13 @@ def relerr(a, b):
     return out
 
 
-@pytest.mark.parametrize("name", ["smr_blast_3lev_s6", "smr_blast_3lev_edge_s8", "smr_vl_blast_2lev_s5", "smr_ppm_blast_2lev_s5"])
+@pytest.mark.parametrize("name", ["smr_blast_3lev_s6", "smr_blast_3lev_edge_s8", "smr_vl_blast_2lev_s5", "smr_ppm_blast_2lev_s5",
+                                  "smr_blast_2dom_s6"])
 @pytest.mark.parametrize("strict", [True, False])
 def test_blast_three_levels_vs_reference(aa, lib, name, strict):
     """(also 2 levels with the van Leer integrator and with third-order reconstruction: the reference's
-    --enable-smr --with-integrator=vl and --with-order=3 builds)"""
+    --enable-smr --with-integrator=vl and --with-order=3 builds; and TWO Domains on level 1 a root zone apart, whose
+    flux corrections meet in the root zones between them: MeshS.Domain[nl][nd], athena.h:355-361)"""
     g = np.load(os.path.join(GOLD, name + ".npz"))
     m = make_gpu_mesh(aa, lib, "blast", [str(o) for o in g["overrides"]], strict,
                       "vl" if name.startswith("smr_vl_") else "ctu", 3 if name.startswith("smr_ppm_") else 2)
@@ -82,6 +84,31 @@ def test_ghost_zones_after_prolongation_bitwise(aa, lib):
         m.start()
         for l, lev in enumerate(m.lev):
             assert np.array_equal(lev.download()[..., :5], o.lev[l].U[..., :5]), f"level {l}"
+    finally:
+        m.close()
+
+
+@pytest.mark.parametrize("strict", [True, False])
+def test_sphere_two_domains_on_a_level_vs_reference(aa, lib, strict):
+    """Two level-1 Domains that both take the radiation from the root (ionrad_prolong_snd to every child), gravity, the
+    pinned core inside one of them: sub-cycle counts of all three Grids and the state against the reference."""
+    g = np.load(os.path.join(GOLD, "smr_ioniz_sphere_2dom_s3.npz"))
+    m = make_gpu_mesh(aa, lib, "ioniz_sphere", [str(o) for o in g["overrides"]], strict)
+    try:
+        assert len(m.lev) == 3 and [lev.cfg.level for lev in m.lev] == [0, 1, 1]
+        m.start()
+        assert abs(m.dt / float(g["dt0"]) - 1) < 1e-13
+        niter = []
+        for _ in range(int(g["nstep"])):
+            niter += m.step()
+        assert niter == [int(x) for x in g["niter"]]
+        assert abs(m.time / float(g["time"]) - 1) < 1e-9 and abs(m.dt / float(g["dt"]) - 1) < 1e-9
+        for l, lev in enumerate(m.lev):
+            U = lev.download()[4:-4, 4:-4, 4:-4, :]
+            err = relerr(U, g[f"U{l}"])
+            assert max(err) < 1e-8, f"grid {l}: {err}"            # north_star: 1e-6
+            ef = lev.download_edgeflux(); ref = g[f"edgeflux{l}"]
+            assert np.nanmax(np.abs(ef - ref)) <= 1e-9 * np.nanmax(np.abs(ref)), f"EdgeFlux grid {l}"
     finally:
         m.close()
 
