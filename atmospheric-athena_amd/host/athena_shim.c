@@ -69,8 +69,10 @@ static double *hbuf[2][2][2];               /* [dir - 1][side][send, recv] host 
 static int nranks_dom = 1;
 #endif
 
-#define MAXLEV 8
-static int NL = 0;                          /* levels (1 without SMR) */
+#define MAXLEV 16
+static int NL = 0;                          /* Grids: one per Domain, level by level (1 without SMR) */
+static int LBASE[MAXLEV + 1];               /* index of the first Domain of a level in that order */
+#define GI(pD) (LBASE[(pD)->Level] + (pD)->DomNumber)
 static aa_grid *G[MAXLEV];
 static GridS *PG[MAXLEV];
 static MeshS *M = NULL, *M0 = NULL;
@@ -142,12 +144,14 @@ static void ensure_grid(MeshS *pM)
   int disp[3*MAXLEV];
   if (NL) return;
 #ifdef AA_SMR
-  if (pM->NLevels > MAXLEV) ath_error("[athena_amd]: more than %d levels\n", MAXLEV);
+  { int nl_, ng = 0; for (nl_ = 0; nl_ < pM->NLevels; nl_++) ng += pM->DomainsPerLevel[nl_];
+    if (pM->NLevels > MAXLEV || ng > MAXLEV) ath_error("[athena_amd]: more than %d Domains\n", MAXLEV); }
 #else
   if (pM->NLevels != 1) ath_error("[athena_amd]: this shim was compiled without -DAA_SMR: single level only\n");
 #endif
-  for (l = 0; l < pM->NLevels; l++)
-    if (pM->DomainsPerLevel[l] != 1) ath_error("[athena_amd]: one Domain per level only (level %d has %d)\n", l, pM->DomainsPerLevel[l]);
+  /* several Domains on a level (athena.h:355-361, init_mesh.c:131-235): one device Grid each, in the order of the
+   * reference's loops over (nl, nd) */
+  { int nl_; LBASE[0] = 0; for (nl_ = 0; nl_ < pM->NLevels; nl_++) LBASE[nl_ + 1] = LBASE[nl_] + pM->DomainsPerLevel[nl_]; }
   /* globals.h:25: the device integrator carries the cooling function the reference ships (microphysics/cool.c:48); any other
    * host function cannot run inside a kernel */
   if (CoolingFunc != NULL && (KoyInut == NULL || CoolingFunc != KoyInut))
@@ -175,8 +179,9 @@ static void ensure_grid(MeshS *pM)
     tlim_ = par_getd("time", "tlim"); nlim_ = par_geti_def("time", "nlim", -1);
   }
   env = getenv("AA_SYNC_EVERY"); sync_every = env ? atoi(env) : 1; if (sync_every < 1) sync_every = 1;
-  for (l = 0, irefine = 1; l < pM->NLevels; l++, irefine *= 2) {
-    pD = &pM->Domain[l][0]; PG[l] = pD->Grid;
+  for (l = 0; l < LBASE[pM->NLevels]; l++) {
+    { int nl_ = 0; while (LBASE[nl_ + 1] <= l) nl_++; pD = &pM->Domain[nl_][l - LBASE[nl_]]; irefine = 1 << nl_; }
+    PG[l] = pD->Grid;
 #ifdef AA_MPI
     if (pD->NGrid[0] != 1) ath_error("[athena_amd]: NGrid_x1 = %d: x1 is never cut (the rays travel along it)\n", pD->NGrid[0]);
     comm_dom = pD->Comm_Domain;
@@ -219,7 +224,7 @@ static void ensure_grid(MeshS *pM)
     p.nslab = 1;                                   /* the reference's ranks ARE the decomposition */
     if (nranks_dom > 1) p.ion_path = 2;            /* the two-kernel sub-cycle: its reductions sit where the reference's are */
 #endif
-    p.level = l;
+    p.level = pD->Level;
 #ifdef AA_SMR
     p.nslab = 1;                                   /* nested levels stay on one GPU */
 #endif
@@ -266,7 +271,7 @@ static void ensure_grid(MeshS *pM)
     fprintf(stderr, "[athena_amd] Grid %dx%dx%d (level %d) on HIP device %d, %.2f GB resident, coherence=%s\n",
             p.Nx[0], p.Nx[1], p.Nx[2], l, p.device, aa_device_bytes(G[l])/1e9, automode ? "auto" : (learn ? "learn" : "step"));
   }
-  NL = pM->NLevels;
+  NL = LBASE[pM->NLevels];
 #ifdef AA_SMR
   CHK(aa_mesh_create(NL, G, disp, &MM));
 #else
@@ -318,7 +323,7 @@ void lr_states_destruct(void) {}
 
 static void integrate_3d_amd(DomainS *pD)
 {
-  const int l = pD->Level;
+  const int l = GI(pD);
   to_device(l);
   active_same[l] = 0;
   if (use_vl()) CHK(aa_integrate_3d_vl(G[l])); else CHK(aa_integrate_3d_ctu(G[l]));
@@ -420,7 +425,7 @@ static void halo_exchange(int dir)
 
 void bvals_mhd(DomainS *pD)
 {
-  VGFun_t usr[6]; int d, side, any = 0; const int l = pD->Level;
+  VGFun_t usr[6]; int d, side, any = 0; const int l = GI(pD);
   ensure_grid(M0);
   to_device(l);
   usr[0] = pD->ix1_BCFun; usr[1] = pD->ox1_BCFun; usr[2] = pD->ix2_BCFun;
@@ -597,7 +602,7 @@ void ion_radtransfer_init_domain(MeshS *pM) { (void)pM; }
 #if AA_ION_RADPLANE
 static void ion_radtransfer_3d_amd(DomainS *pD)
 {
-  GridS *pG = pD->Grid; MeshS *pM = pD->Mesh; int niter = 0; double t, dt; int n; const int l = pD->Level;
+  GridS *pG = pD->Grid; MeshS *pM = pD->Mesh; int niter = 0; double t, dt; int n; const int l = GI(pD);
   to_device(l);
   active_same[l] = 0;
 #ifdef AA_SMR
@@ -644,7 +649,7 @@ VDFun_t ion_radtransfer_init(MeshS *pM, int ires)
 }
 
 void bvals_ionrad_init(MeshS *pM) { (void)pM; }
-void bvals_ionrad(DomainS *pD) { ensure_grid(pD->Mesh); CHK(aa_bvals_ionrad(G[pD->Level])); }
+void bvals_ionrad(DomainS *pD) { ensure_grid(pD->Mesh); CHK(aa_bvals_ionrad(G[GI(pD)])); }
 void set_coarse_time(void) {}
 void clear_coarse_time(void) {}
 

@@ -144,6 +144,8 @@ def test_cooling_function_enrolled_by_problem():
     ("smr_blast_3lev_edge_s8", "blast_smr", {}),
     ("smr_ioniz_sphere_2lev_s4", "ioniz_sphere_smr", {}),
     ("smr_ioniz_sphere_2lev_s4", "ioniz_sphere_smr", {"AA_COHERENCE": "learn"}),
+    ("smr_blast_2dom_s6", "blast_smr", {}),                  # two Domains on level 1 (MeshS.Domain[nl][nd])
+    ("smr_ioniz_sphere_2dom_s3", "ioniz_sphere_smr", {}),
 ])
 def test_reference_smr_driver_on_gpu_library(fixture, cfg, env):
     """The reference's --enable-smr driver (main.o, init_mesh.o, init_grid.o with its overlap tables,
