@@ -394,7 +394,8 @@ def setup_problem(grid: GridConfig, device: int = 0, strict: bool | None = None,
 
 
 class Mesh:
-    """Nested static-mesh-refinement levels on one GPU (MeshS with one Domain per level).  Method
+    """Nested static-mesh-refinement levels on one GPU (MeshS; one or several Domains per level: grids level by level
+    from the root, deck order inside a level, as config.levels() returns them).  Method
     names follow the reference: RestrictCorrect, Prolongate (smr.c), new_dt, and the per-level
     ion_radtransfer_3d with its coarse -> fine EdgeFlux hand-off (ionrad_smr.c)."""
 

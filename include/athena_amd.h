@@ -180,11 +180,13 @@ int aa_halo_get(aa_grid *g, int dir, int side, double *host_buf);        /* pack
 int aa_halo_put(aa_grid *g, int dir, int side, const double *host_buf);  /* host_buf -> the ghost planes of that side      */
 int aa_device_count(void);                                               /* visible HIP devices (0: none)                  */
 
-/* ---- static mesh refinement (reference built with --enable-smr): nested levels, one Domain per
- *      level, all resident on one GPU.  levels[l] was created with aa_params.level = l, Nx = the
+/* ---- static mesh refinement (reference built with --enable-smr): nested levels, all resident on one GPU.
+ *      levels[] holds one Grid per Domain in the order of the reference's loops (MeshS.Domain[nl][nd], athena.h:355-361):
+ *      level by level from the root, Domains of a level in deck order (they neither overlap nor touch, init_mesh.c:398-418;
+ *      up to three children per Grid).  Each was created with aa_params.level = its level, Nx = the
  *      Domain's zones, MinX = its lower edge (init_mesh.c:281-286), bc = 0 on fine/coarse sides
- *      (bvals_mhd.c:193-361 ProlongateLater); disp[3*l+d] = <domainN> iDisp/jDisp/kDisp in zones
- *      of level l.  Fill every level (problem(), hooks) before aa_mesh_start().  The Mesh takes
+ *      (bvals_mhd.c:193-361 ProlongateLater); disp[3*g+d] = <domainN> iDisp/jDisp/kDisp in zones
+ *      of its level.  Fill every level (problem(), hooks) before aa_mesh_start().  The Mesh takes
  *      over the levels' streams; destroy it before the levels.                               */
 typedef struct aa_mesh aa_mesh;
 int  aa_mesh_create(int nlevels, aa_grid **levels, const int *disp, aa_mesh **out); /* init_grid.c overlap
