@@ -235,6 +235,9 @@ def levels(par: ParTable, run: RunConfig) -> List[GridConfig]:
             if (lo == pdisp[d] and disp[d] != 0) or \
                (hi == pdisp[d] + pNx[d] and (disp[d] + Nx[d]) // irefine != run.rootNx[d]):
                 raise ParError(f"[init_mesh]: child Domain {blk} touches its parent in x{d + 1}")
+            # init_mesh.c:484-499: ... or lies closer than nghost/2 parent zones to its edge (the prolongation stencil)
+            if 0 < 2 * (lo - pdisp[d]) < NGHOST or 0 < 2 * (pdisp[d] + pNx[d] - hi) < NGHOST:
+                raise ParError(f"[init_mesh]: child Domain {blk} closer than nghost/2 to its parent in x{d + 1}")
         dxl = tuple(run.dx[d] / float(irefine) for d in range(3))
         MinX = tuple(run.xmin[d] if disp[d] == 0 else run.xmin[d] + float(disp[d]) * dxl[d] for d in range(3))
         bc = list(run.bc)
