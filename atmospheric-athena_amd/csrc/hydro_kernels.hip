@@ -992,7 +992,7 @@ k_update(DevGrid g, const Real *dhalf, Real dt, Order ord)
 // operands of one second-pass Riemann problem: the corrected face states (sweep frame) and the 9 etas
 struct FaceIn { Real ul[6], ur[6], eta[9]; };
 #ifndef FU_ABL
-#define FU_ABL 0          // timing experiments only (wrong results): 1 = update operands not loaded, 2 = only the face's own eta
+#define FU_ABL 0          // timing experiments only (profiles/r03_ab_experiments.txt; wrong results): 1 = the update's operands not loaded and U not stored, 2 = only the face's own eta loaded
 #endif
 template <int NS, int D>
 AA_DEV void face_load(const DevGrid &g, long m, FaceIn &in)
@@ -1206,9 +1206,11 @@ k_flux2_update(DevGrid g, const Real *dhalf, Real dt, int kchunk, KeepPlanes kp,
       for (int n = 0; n < NV; n++) u[gv<1>(n)] -= dtodx[1]*d2[n];
 #pragma unroll
       for (int n = 0; n < NV; n++) u[gv<2>(n)] -= dtodx[2]*d3[n];
+      if (!(FU_ABL & 1) || kchunk < 0) {        // (FU_ABL 1: U neither loaded nor stored -- the state stands still, the arithmetic stays; run with AA_CFL_FUSED=0)
 #pragma unroll
       for (int v = 0; v < NV; v++) Uf(g, v)[m] = u[v];
-      if (CFL) {
+      }
+      if (CFL && !(FU_ABL & 1)) {
         if (!pinned) {
           Real cmx[3] = {s_cmx[0][row][lane], s_cmx[1][row][lane], s_cmx[2][row][lane]};
           cfl_zone(u[0], u[1], u[2], u[3], u[4], g.Gamma, g.Gamma_1, cmx);
