@@ -43,6 +43,41 @@ def test_config_rejects_what_the_reference_rejects(aa):
         aa.config.load(deck, ["domain1/Nx3=1"], "blast")
 
 
+def test_mesh_of_several_domains_per_level_follows_init_mesh(aa):
+    """config.levels: Domains level by level in deck order (MeshS.Domain[nl][nd]); what init_mesh.c refuses is refused: Domains
+    of a level that overlap or touch (:398-418), a child that touches its parent's edge away from the root boundary or lies
+    closer than nghost/2 parent zones to it (:448-499), a Domain outside every Domain of the level below."""
+    deck = os.path.join(PKGDIR, "decks", "athinput.blast")
+    base = ["job/num_domains=3", "domain1/Nx1=16", "domain1/Nx2=24", "domain1/Nx3=16",
+            "domain2/Nx1=12", "domain2/Nx2=16", "domain2/Nx3=20", "domain2/iDisp=8", "domain2/jDisp=20", "domain2/kDisp=6", "domain3/level=1"]
+
+    def lev(third):
+        par = aa.athinput.ParTable.from_file(deck).cmdline(base + third)
+        return aa.config.levels(par, aa.config.from_par(par, "blast"))
+
+    def dom3(nx, disp):
+        return [f"domain3/Nx{d + 1}={nx[d]}" for d in range(3)] + [f"domain3/{k}Disp={disp[d]}" for d, k in enumerate("ijk")]
+
+    g = lev(dom3((6, 8, 8), (22, 24, 10)))
+    assert [x.level for x in g] == [0, 1, 1] and g[1].Nx == (12, 16, 20) and g[2].disp == (22, 24, 10)
+    assert g[2].bc == (0, 0, 0, 0, 0, 0)                                   # fine / coarse sides all round
+    with pytest.raises(aa.athinput.ParError, match="overlap or touch"):
+        lev(dom3((6, 8, 8), (20, 24, 10)))                                 # starts where domain2 ends in x1
+    with pytest.raises(aa.athinput.ParError, match="overlap or touch"):
+        lev(dom3((8, 8, 8), (14, 24, 10)))                                 # inside domain2
+    with pytest.raises(aa.athinput.ParError, match="nghost/2"):
+        lev(dom3((8, 8, 8), (22, 24, 10)))                                 # one root zone from the root Domain's upper x1 edge
+    with pytest.raises(aa.athinput.ParError, match="not inside"):
+        lev(dom3((8, 8, 8), (28, 24, 10)))                                 # sticks out of the root
+    # a level-2 Domain under the SECOND level-1 Domain finds that one as its parent
+    par = aa.athinput.ParTable.from_file(deck).cmdline(
+        ["job/num_domains=3", "domain1/Nx1=32", "domain1/Nx2=32", "domain1/Nx3=32",
+         "domain2/Nx1=16", "domain2/Nx2=16", "domain2/Nx3=16", "domain2/iDisp=8", "domain2/jDisp=8", "domain2/kDisp=8",
+         "domain3/Nx1=16", "domain3/Nx2=16", "domain3/Nx3=16", "domain3/iDisp=24", "domain3/jDisp=24", "domain3/kDisp=24"])
+    g = aa.config.levels(par, aa.config.from_par(par, "blast"))
+    assert [x.level for x in g] == [0, 1, 2]
+
+
 @pytest.mark.parametrize("so", ["libathena_amd.so", "libathena_amd_strict.so"])
 def test_cabi_exports_every_declared_symbol(so):
     hdr = open(os.path.join(ROOT, "include", "athena_amd.h")).read()
