@@ -325,6 +325,14 @@ def smr_runs():
          ["job/num_domains=3"] + dom(1, (32, 32, 32)) + dom(2, (32, 28, 24), (16, 18, 20)) + ["domain3/level=1"] + dom(3, (16, 16, 12), (8, 20, 48))
          + ["problem/rp=2.1e10"]),
     ]
+    # a tree: two level-1 Domains and a level-2 Domain under the SECOND of them (the decks stop at <domain3>: the fourth block
+    # travels with the fixture as text to append)
+    extra4 = "\n<domain4>\nlevel = 2\nNx1 = 12\nNx2 = 12\nNx3 = 12\niDisp = 48\njDisp = 44\nkDisp = 40\n"
+    cases += [
+        ("smr_blast_tree_s5", "blast_smr", blast, ["job/maxout=1", "output1/out_fmt=rst", "output1/dt=1e300"], 5, 0, False,
+         ["job/num_domains=4"] + dom(1, (20, 20, 20)) + dom(2, (12, 12, 12), (4, 4, 4)) + ["domain3/level=1"] + dom(3, (12, 12, 12), (20, 18, 16))
+         + dom(4, (12, 12, 12), (48, 44, 40)) + ["problem/radius=0.25"]),
+    ]
     # the same 2-level blast with the van Leer integrator and with third-order reconstruction
     two = ["job/num_domains=2"] + dom(1, (16, 24, 16)) + dom(2, (12, 16, 20), (8, 20, 6))
     cases += [("smr_vl_blast_2lev_s5", "blast_smr_vl", blast, ["job/maxout=1", "output1/out_fmt=rst", "output1/dt=1e300"], 5, 0, False, two),
@@ -337,6 +345,10 @@ def smr_runs():
                for n in range(1, nlev + 1)]
         tmp = tempfile.mkdtemp(prefix="golden_")
         rundir = os.path.join(tmp, "run")
+        extra = extra4 if "tree" in name else ""
+        if extra:                                                  # a deck with the extra <domainN> block
+            open(os.path.join(tmp, "deck"), "w").write(open(deck).read() + extra)
+            deck = os.path.join(tmp, "deck")
         pr = subprocess.run([os.path.join(REFBIN, "athena_" + cfg), "-i", deck, "-d", rundir, f"time/nlim={nlim}"] + refextra + over,
                             stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, cwd=tmp)
         if pr.returncode != 0:
@@ -346,7 +358,7 @@ def smr_runs():
         first = read_rst_levels(os.path.join(rundir, rsts[0]), nxs, nscal, ion)
         last = read_rst_levels(os.path.join(rundir, rsts[-1]), nxs, nscal, ion)
         shutil.rmtree(tmp)
-        d = dict(overrides=np.array(over), nlevels=nlev, nstep=last["nstep"], time=last["time"], dt=last["dt"],
+        d = dict(overrides=np.array(over), extra_deck=np.array(extra), nlevels=nlev, nstep=last["nstep"], time=last["time"], dt=last["dt"],
                  dt0=first["dt"], niter=np.array(niter, dtype=np.int64))
         for l, (U, ef) in enumerate(last["levels"]):
             d[f"U{l}"] = U

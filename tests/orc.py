@@ -324,6 +324,18 @@ class Mesh:
     nstep = property(lambda s: s.L.orc_mesh_nstep(s.h))
 
 
+def deck_for(problem, g):
+    """The deck of a golden SMR fixture: ours, with the <domainN> block the fixture carries appended (decks stop at <domain3>)."""
+    import tempfile
+    base = os.path.join(DECKS, "athinput." + problem)
+    extra = str(g["extra_deck"]) if "extra_deck" in g.files else ""
+    if not extra:
+        return base
+    f = tempfile.NamedTemporaryFile("w", prefix="athinput_", suffix="." + problem, delete=False)
+    f.write(open(base).read() + extra); f.close()
+    return f.name
+
+
 def make_mesh(problem, deck_path=None, overrides=None, integrator="ctu", order=2):
     aa = importlib.import_module("atmospheric-athena_amd")
     par = aa.athinput.ParTable.from_file(deck_path or os.path.join(DECKS, "athinput." + problem)).cmdline(overrides)

@@ -159,7 +159,7 @@ def test_smr_runs_bitwise(name):
     STATIC_MESH_REFINEMENT, bit for bit on every level."""
     g = np.load(os.path.join(GOLD, name + ".npz"))
     prob = "ioniz_sphere" if "ioniz_sphere" in name else "blast"
-    m = orc.make_mesh(prob, None, [str(o) for o in g["overrides"]], integrator="vl" if name.startswith("smr_vl_") else "ctu",
+    m = orc.make_mesh(prob, orc.deck_for(prob, g), [str(o) for o in g["overrides"]], integrator="vl" if name.startswith("smr_vl_") else "ctu",
                       order=3 if name.startswith("smr_ppm_") else 2)
     assert len(m.lev) == int(g["nlevels"])
     nv = 5 + m.lev[0].grid.run.nscal
