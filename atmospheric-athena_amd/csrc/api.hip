@@ -177,6 +177,11 @@ int aa_create(const aa_params *p, aa_grid **out)
       hipFree(g->pool); hipFree(g->sc); hipHostFree(g->sc_host); delete g; return fail(-2, "[aa_create]: ion reduction buffers");
     }
   }
+  // (every word of these is written before it is read; zeroed all the same, so that no run ever depends on what a freed
+  //  allocation of an earlier Grid left behind)
+  (void)hipMemset(g->sc, 0, sizeof(DevScalars)); memset(g->sc_host, 0, sizeof(DevScalars));
+  if (g->ion_part) (void)hipMemset(g->ion_part, 0, (size_t)ion_pass_blocks(d)*sizeof(IonPart));
+  if (g->ion_words) (void)hipMemset(g->ion_words, 0, AA_ION_WORDS*sizeof(Real));
   hipStreamCreate(&g->st); g->own_stream = true;
   *out = g;
   return 0;

@@ -265,6 +265,7 @@ static int mesh_finish(aa_mesh *m, aa_grid **levels, aa_mesh **out)
     const Link &L = m->link[l];
     const size_t nb = (size_t)(L.n[0] + 6)*(L.n[1] + 6)*(L.n[2] + 6)*6;
     if (hipMalloc(&m->box[l], nb*sizeof(Real)) != hipSuccess) return aa_fail(-2, "[aa_mesh_create]: hipMalloc box");
+    (void)hipMemset(m->box[l], 0, nb*sizeof(Real));
   }
   // the face planes whose second-pass fluxes k_flux_correct / k_flux_x3_export / k_flux_x3_apply read:
   // a level's own boundary faces and the outline of its child
