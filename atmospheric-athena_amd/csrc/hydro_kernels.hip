@@ -1777,7 +1777,10 @@ static void correct_all_impl(const DevGrid &g, Real dt, bool x3f, hipStream_t st
   static int kc_env = -1;
   if (kc_env < 0) { const char *e = getenv("AA_CA_KC"); kc_env = e ? atoi(e) : 0; }
   int kc = kc_env > 0 ? kc_env : (x3f ? 64 : 32);
-  while (kc > 4 && (long)nblk(ni - 1, 63)*nblk(nj - 1, CA_TJ - 1)*((nk + kc - 1)/kc) < 1024) kc >>= 1;
+  // ... on Grids with fewer columns shorter chunks pay more than their start-up planes cost: the launch should hold about
+  // eight rounds of the 512 blocks that are resident at a time (measured, profiles/microbench/kc_small.sh: 128^3 and 192^3 best
+  // with 8 planes, 1.30 against 1.65 ms at 192^3; 256^3 with 16, 2.80 against 3.09; 320^3 with 32; from 384^3 on with 64)
+  if (kc_env <= 0) while (kc > 8 && (long)nblk(ni + 15, 64)*nblk(nj, CA_TJ)*((nk + kc - 1)/kc) < 4096) kc >>= 1;
   dim3 grid(nblk(ni + 15, 64), nblk(nj, CA_TJ), (nk + kc - 1)/kc), blk(64, CA_TJ);
   if (x3f) {
     if (g.slope) hipLaunchKernelGGL((k_correct_all<NS, GRAV, 3, true>), grid, blk, 0, st, g, dt, kc);
