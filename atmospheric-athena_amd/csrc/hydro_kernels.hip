@@ -1890,8 +1890,10 @@ void launch_pin_mask(const DevGrid &g, long long n, const long long *idx, unsign
 void launch_flux2_update(const DevGrid &g, int nscal, Real dt, bool grav, const KeepPlanes *keep, hipStream_t st, DevScalars *sc, const unsigned char *pinmask)
 {
   const int ni = g.ie - g.is + 1, nj = g.je - g.js + 1, nk = g.ke - g.ks + 1;
-  int kc = 32;
-  while (kc > 4 && (long)nblk(ni, 64)*nblk(nj, FU_TJ - 1)*((nk + kc - 1)/kc) < 1024) kc >>= 1;
+  static int kc_env = -1;
+  if (kc_env < 0) { const char *e = getenv("AA_FU_KC"); kc_env = e ? atoi(e) : 0; }
+  int kc = kc_env > 0 ? kc_env : 32;
+  if (kc_env <= 0) while (kc > 4 && (long)nblk(ni, 64)*nblk(nj, FU_TJ - 1)*((nk + kc - 1)/kc) < 1024) kc >>= 1;
   dim3 grid(nblk(ni, 64), nblk(nj, FU_TJ - 1), (nk + kc - 1)/kc), blk(64, FU_TJ);
   if (nscal) { if (grav) launch_fu<1, true>(g, dt, kc, grid, blk, keep, sc, pinmask, st); else launch_fu<1, false>(g, dt, kc, grid, blk, keep, sc, pinmask, st); }
   else       { if (grav) launch_fu<0, true>(g, dt, kc, grid, blk, keep, sc, pinmask, st); else launch_fu<0, false>(g, dt, kc, grid, blk, keep, sc, pinmask, st); }
