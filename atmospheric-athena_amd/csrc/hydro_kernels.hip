@@ -1053,6 +1053,22 @@ AA_DEV bool on_plane(const KeepPlanes &kp, int d, int x)
          x == kp.p[d][4] || x == kp.p[d][5] || x == kp.p[d][6] || x == kp.p[d][7];
 }
 
+// ---- experiment FU_DMA (off): the update's operands by LDS-DMA -------------------------------------------------------
+// VERDICT r02's proposal taken literally for the one place in k_flux2_update where a load is consumed at once: the zone's own
+// U, the potential values and d^{n+1/2} of the update.  One global_load_lds_dwordx4 moves 64 x 16 bytes = two 512-byte rows
+// (lanes 0..31 the first field, 32..63 the second) into the wavefront's own LDS rows without a register; issued right behind
+// the wait for the x1 face's operands, they land during the x1 solve and are covered by the compiler's own wait for the x2
+// face's operands (loads retire in order), so no s_waitcnt of ours is needed and none of the compiler's is lengthened.
+#ifndef FU_DMA
+#define FU_DMA 0
+#endif
+AA_DEV void dma16(const void *gsrc, unsigned lds_dst)      // lds_dst: wave-uniform byte address; lane L's 16 bytes land at lds_dst + 16 L
+{
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+
 // CFL: the zone's contribution to new_dt's maxima is taken from the updated state while it is in registers (k_cfl would
 // read the five fields again: 0.9 ms at 512^3); zones marked in `pinmask` are left out, the caller adds them after it
 // has overwritten them (k_pinned_cfl).
@@ -1064,6 +1080,8 @@ k_flux2_update(DevGrid g, const Real *dhalf, Real dt, int kchunk, KeepPlanes kp,
   //  next plane's writers off this plane's readers -- 8 wavefronts, a whole CU, wait at every barrier of this block)
   __shared__ Real s_f2[2][FU_TJ][6][64];
   __shared__ Real s_f1e[2][FU_TJ - 1][6], s_f1s[2][FU_TJ - 1][6];
+  constexpr bool DMA = (FU_DMA != 0) && NS && GRAV;
+  __shared__ Real s_dma[DMA ? FU_TJ - 1 : 1][DMA ? 14 : 1][64];      // rows: U0..U5, phi_c, d^{n+1/2}, phi_1, phi_2, phi_3, phi_2(j+1), phi_3(k+1), -
   const int lane = threadIdx.x, row = threadIdx.y;
   // Tiles of 64 x (FU_TJ - 1) zones; the rows start on a 128-byte line (zone is) and do not overlap in x1: with a stride
   // of 63 zones every 512-byte row request touched a fifth line and 512 zones took 9 tiles (rocprofv3: 559 B/zone fetched
@@ -1086,6 +1104,10 @@ k_flux2_update(DevGrid g, const Real *dhalf, Real dt, int kchunk, KeepPlanes kp,
   const long mcol = (long)jc*g.sJ + ic;
   // where this thread's x1 face is, relative to its zone: 0, or for the edge wavefront the hop to (i0 + 64, j0 + lane)
   const long m1off = edge ? ((long)(j0 + lane)*g.sJ + (i0 + 64)) - mcol : 0L;
+  // DMA: whole 64-zone rows, so only tiles that lie inside the row of the Grid (block-uniform), and only the wavefronts that own zones
+  const int wave = __builtin_amdgcn_readfirstlane(row);
+  const bool dma_go = DMA && (i0 + 63 <= g.ie + 1) && (wave < FU_TJ - 1);
+  const unsigned dma_base = DMA ? (unsigned)(size_t)&s_dma[DMA ? wave : 0][0][0] : 0u;
   Real dtodx[3];
 #pragma unroll
   for (int d = 0; d < 3; d++) dtodx[d] = dt/g.dx[d];
@@ -1118,11 +1140,37 @@ k_flux2_update(DevGrid g, const Real *dhalf, Real dt, int kchunk, KeepPlanes kp,
     asm volatile("" : "+v"(m));
     const int pb = k & 1;
     if (need2) face_load<NS, 1>(g, m, in2);
+    // DMA: what is left of the update's loads travels with the x2 face's operands (lane 63's upper x1-face potential: the
+    // next tile's first value, outside the wavefront's row; the pin-mask byte)
+    Real p1e = 0.0; unsigned char pin_early = 0;
+    if (DMA && cell) { if (lane == 63) p1e = Pf(g, 1)[m + 1]; if (CFL && pinmask) pin_early = pinmask[m]; }
     __builtin_amdgcn_sched_barrier(0);
     {
       Real f[6];
 #pragma unroll
       for (int n = 0; n < 6; n++) f[n] = 0.0;
+      if (DMA) {
+        // the x1 face's operands named as inputs of an empty statement: the compiler's wait for them sits HERE, in front of the
+        // DMA requests, and counts exactly what it issued itself (a statement of ours in front of that wait would make it drain
+        // the stores of the previous plane: loads and stores retire through one in-order counter)
+        if (need1) {
+          asm volatile("" :: "v"(in1.ul[0]), "v"(in1.ul[1]), "v"(in1.ul[2]), "v"(in1.ul[3]), "v"(in1.ul[4]), "v"(in1.ul[5]),
+                             "v"(in1.ur[0]), "v"(in1.ur[1]), "v"(in1.ur[2]), "v"(in1.ur[3]), "v"(in1.ur[4]), "v"(in1.ur[5]));
+          asm volatile("" :: "v"(in1.eta[0]), "v"(in1.eta[1]), "v"(in1.eta[2]), "v"(in1.eta[3]), "v"(in1.eta[4]), "v"(in1.eta[5]),
+                             "v"(in1.eta[6]), "v"(in1.eta[7]), "v"(in1.eta[8]));
+        }
+        if (dma_go) {
+          const long mr = m - lane + 2*(lane & 31);  // this lane's pair of zones in the wavefront's row
+          const bool hi = lane >= 32;
+          dma16((hi ? Uf(g, 1) : Uf(g, 0)) + mr, dma_base);
+          dma16((hi ? Uf(g, 3) : Uf(g, 2)) + mr, dma_base + 1024u);
+          dma16((hi ? Uf(g, 5) : Uf(g, 4)) + mr, dma_base + 2048u);
+          dma16((hi ? dhalf : Pf(g, 0)) + mr, dma_base + 3072u);
+          dma16((hi ? Pf(g, 2) : Pf(g, 1)) + mr, dma_base + 4096u);
+          dma16((hi ? Pf(g, 2) + g.sJ : Pf(g, 3)) + mr, dma_base + 5120u);
+          dma16((hi ? Pf(g, 1) : Pf(g, 3) + g.sK) + mr, dma_base + 6144u);
+        }
+      }
       if (need1) face_solve<NS>(g, in1, f);
       if (keep1) store_sweep<0, NS>(Ff(g, 0, 0), g.nc, m + m1off, f);
 #pragma unroll
@@ -1178,12 +1226,32 @@ k_flux2_update(DevGrid g, const Real *dhalf, Real dt, int kchunk, KeepPlanes kp,
 #pragma unroll
       for (int n = 0; n < NV; n++) f3lo[n] = f3[n];
       Real u[6];
+      constexpr bool from_lds = DMA;       // (the experiment build takes Grids whose rows are whole tiles only: Nx1 a multiple of 64)
+      if (from_lds) {
+#pragma unroll
+        for (int v = 0; v < NV; v++) u[v] = s_dma[DMA ? row : 0][DMA ? v : 0][lane];
+      } else {
 #pragma unroll
       for (int v = 0; v < NV; v++) u[v] = (FU_ABL & 1) ? f3lo[v] : Uf(g, v)[m];
+      }
       // (the mask byte with the zone's other operands, not behind the stores of U: a load that is consumed at once waits
       //  for everything issued before it, i.e. the wave sat out the six stores' round trip in every plane)
       unsigned char pinned = 0;
-      if (CFL && pinmask && !(FU_ABL & 1)) pinned = pinmask[m];
+      if (from_lds) pinned = pin_early;
+      else if (CFL && pinmask && !(FU_ABL & 1)) pinned = pinmask[m];
+      if (GRAV && from_lds) {        // the same expressions on the operands the DMA brought
+        const int rw = DMA ? row : 0;
+        const Real phic = s_dma[rw][DMA ? 6 : 0][lane], dh = s_dma[rw][DMA ? 7 : 0][lane];
+        { const Real phil = s_dma[rw][DMA ? 8 : 0][lane], phir = (lane < 63) ? s_dma[rw][DMA ? 8 : 0][(lane + 1) & 63] : p1e;
+          u[1] -= dtodx[0]*(phir - phil)*dh;
+          u[4] -= dtodx[0]*(m1lo*(phic - phil) + m1hi*(phir - phic)); }
+        { const Real phir = s_dma[rw][DMA ? 11 : 0][lane], phil = s_dma[rw][DMA ? 9 : 0][lane];
+          u[2] -= dtodx[1]*(phir - phil)*dh;
+          u[4] -= dtodx[1]*(m2lo*(phic - phil) + m2hi*(phir - phic)); }
+        { const Real phir = s_dma[rw][DMA ? 12 : 0][lane], phil = s_dma[rw][DMA ? 10 : 0][lane];
+          u[3] -= dtodx[2]*(phir - phil)*dh;
+          u[4] -= dtodx[2]*(m3lo*(phic - phil) + m3hi*(phir - phic)); }
+      } else
       if (GRAV && !(FU_ABL & 1)) {   // :2741-2782, with the mass fluxes (sweep component 0) of the faces just solved
         const Real phic = Pf(g, 0)[m], dh = dhalf[m];
         { const Real phir = Pf(g, 1)[m + 1], phil = Pf(g, 1)[m];
