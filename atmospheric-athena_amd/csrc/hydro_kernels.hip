@@ -1062,11 +1062,15 @@ AA_DEV bool on_plane(const KeepPlanes &kp, int d, int x)
 #ifndef FU_DMA
 #define FU_DMA 0
 #endif
-AA_DEV void dma16(const void *gsrc, unsigned lds_dst)      // lds_dst: wave-uniform byte address; lane L's 16 bytes land at lds_dst + 16 L
+// lds_dst: wave-uniform byte address; lane L's 16 bytes come from base + off (its own 32-bit byte offset) and land at lds_dst + 16 L.
+// Scalar base + one offset register for all requests of an iteration: per-lane 64-bit addresses (seven pairs at the kernel's register
+// peak) cost 18 spilled registers in the first form of this experiment (18.95 ms).
+AA_DEV void dma16(const Real *base, unsigned off, unsigned lds_dst)
 {
   unsigned keep;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-               : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+  const unsigned long long b = (unsigned long long)base;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(off), "s"(b), "s"(lds_dst) : "memory");
 }
 
 // CFL: the zone's contribution to new_dt's maxima is taken from the updated state while it is in registers (k_cfl would
@@ -1081,7 +1085,7 @@ k_flux2_update(DevGrid g, const Real *dhalf, Real dt, int kchunk, KeepPlanes kp,
   __shared__ Real s_f2[2][FU_TJ][6][64];
   __shared__ Real s_f1e[2][FU_TJ - 1][6], s_f1s[2][FU_TJ - 1][6];
   constexpr bool DMA = (FU_DMA != 0) && NS && GRAV;
-  __shared__ Real s_dma[DMA ? FU_TJ - 1 : 1][DMA ? 14 : 1][64];      // rows: U0..U5, phi_c, d^{n+1/2}, phi_1, phi_2, phi_3, phi_2(j+1), phi_3(k+1), -
+  __shared__ Real s_dma[DMA ? FU_TJ - 1 : 1][DMA ? 14 : 1][64];      // rows: U0..U5, phi_c, phi_1, phi_2, phi_3, phi_2(j+1), phi_3(k+1), d^{n+1/2} (twice)
   const int lane = threadIdx.x, row = threadIdx.y;
   // Tiles of 64 x (FU_TJ - 1) zones; the rows start on a 128-byte line (zone is) and do not overlap in x1: with a stride
   // of 63 zones every 512-byte row request touched a fifth line and 512 zones took 9 tiles (rocprofv3: 559 B/zone fetched
@@ -1160,15 +1164,19 @@ k_flux2_update(DevGrid g, const Real *dhalf, Real dt, int kchunk, KeepPlanes kp,
                              "v"(in1.eta[6]), "v"(in1.eta[7]), "v"(in1.eta[8]));
         }
         if (dma_go) {
-          const long mr = m - lane + 2*(lane & 31);  // this lane's pair of zones in the wavefront's row
+          // rows in LDS: U0..U5, phi_c, phi_1, phi_2, phi_3, phi_2(j+1), phi_3(k+1), d^{n+1/2} (twice); the fields of a pair are
+          // nc doubles apart, so the upper half of the lanes adds that to the one offset
           const bool hi = lane >= 32;
-          dma16((hi ? Uf(g, 1) : Uf(g, 0)) + mr, dma_base);
-          dma16((hi ? Uf(g, 3) : Uf(g, 2)) + mr, dma_base + 1024u);
-          dma16((hi ? Uf(g, 5) : Uf(g, 4)) + mr, dma_base + 2048u);
-          dma16((hi ? dhalf : Pf(g, 0)) + mr, dma_base + 3072u);
-          dma16((hi ? Pf(g, 2) : Pf(g, 1)) + mr, dma_base + 4096u);
-          dma16((hi ? Pf(g, 2) + g.sJ : Pf(g, 3)) + mr, dma_base + 5120u);
-          dma16((hi ? Pf(g, 1) : Pf(g, 3) + g.sK) + mr, dma_base + 6144u);
+          const unsigned mr8 = (unsigned)((m - lane + 2*(lane & 31))*8);
+          const unsigned nc8 = (unsigned)(g.nc*8);
+          const unsigned off = mr8 + (hi ? nc8 : 0u);
+          dma16(Uf(g, 0), off, dma_base);
+          dma16(Uf(g, 2), off, dma_base + 1024u);
+          dma16(Uf(g, 4), off, dma_base + 2048u);
+          dma16(Pf(g, 0), off, dma_base + 3072u);
+          dma16(Pf(g, 2), off, dma_base + 4096u);
+          dma16(Pf(g, 2), mr8 + (hi ? nc8 + (unsigned)(g.sK*8) : (unsigned)(g.sJ*8)), dma_base + 5120u);
+          dma16(dhalf, mr8, dma_base + 6144u);
         }
       }
       if (need1) face_solve<NS>(g, in1, f);
@@ -1241,14 +1249,14 @@ k_flux2_update(DevGrid g, const Real *dhalf, Real dt, int kchunk, KeepPlanes kp,
       else if (CFL && pinmask && !(FU_ABL & 1)) pinned = pinmask[m];
       if (GRAV && from_lds) {        // the same expressions on the operands the DMA brought
         const int rw = DMA ? row : 0;
-        const Real phic = s_dma[rw][DMA ? 6 : 0][lane], dh = s_dma[rw][DMA ? 7 : 0][lane];
-        { const Real phil = s_dma[rw][DMA ? 8 : 0][lane], phir = (lane < 63) ? s_dma[rw][DMA ? 8 : 0][(lane + 1) & 63] : p1e;
+        const Real phic = s_dma[rw][DMA ? 6 : 0][lane], dh = s_dma[rw][DMA ? 12 : 0][lane];
+        { const Real phil = s_dma[rw][DMA ? 7 : 0][lane], phir = (lane < 63) ? s_dma[rw][DMA ? 7 : 0][(lane + 1) & 63] : p1e;
           u[1] -= dtodx[0]*(phir - phil)*dh;
           u[4] -= dtodx[0]*(m1lo*(phic - phil) + m1hi*(phir - phic)); }
-        { const Real phir = s_dma[rw][DMA ? 11 : 0][lane], phil = s_dma[rw][DMA ? 9 : 0][lane];
+        { const Real phir = s_dma[rw][DMA ? 10 : 0][lane], phil = s_dma[rw][DMA ? 8 : 0][lane];
           u[2] -= dtodx[1]*(phir - phil)*dh;
           u[4] -= dtodx[1]*(m2lo*(phic - phil) + m2hi*(phir - phic)); }
-        { const Real phir = s_dma[rw][DMA ? 12 : 0][lane], phil = s_dma[rw][DMA ? 10 : 0][lane];
+        { const Real phir = s_dma[rw][DMA ? 11 : 0][lane], phil = s_dma[rw][DMA ? 9 : 0][lane];
           u[3] -= dtodx[2]*(phir - phil)*dh;
           u[4] -= dtodx[2]*(m3lo*(phic - phil) + m3hi*(phir - phic)); }
       } else
