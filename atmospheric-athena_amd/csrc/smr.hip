@@ -255,6 +255,7 @@ struct aa_mesh {
 
 extern "C" {
 
+void aa_mesh_destroy(aa_mesh *m);
 static int mesh_finish(aa_mesh *m, aa_grid **levels, aa_mesh **out)
 {
   hipError_t e = hipSetDevice(levels[0]->p.device);
@@ -264,7 +265,7 @@ static int mesh_finish(aa_mesh *m, aa_grid **levels, aa_mesh **out)
   for (int l = 0; l + 1 < m->nl; l++) {
     const Link &L = m->link[l];
     const size_t nb = (size_t)(L.n[0] + 6)*(L.n[1] + 6)*(L.n[2] + 6)*6;
-    if (hipMalloc(&m->box[l], nb*sizeof(Real)) != hipSuccess) return aa_fail(-2, "[aa_mesh_create]: hipMalloc box");
+    if (hipMalloc(&m->box[l], nb*sizeof(Real)) != hipSuccess) { aa_mesh_destroy(m); return aa_fail(-2, "[aa_mesh_create]: hipMalloc box"); }
     (void)hipMemset(m->box[l], 0, nb*sizeof(Real));
   }
   // the face planes whose second-pass fluxes k_flux_correct / k_flux_x3_export / k_flux_x3_apply read:
@@ -277,7 +278,7 @@ static int mesh_finish(aa_mesh *m, aa_grid **levels, aa_mesh **out)
     for (int d = 0; d < 3; d++) { for (int q = 0; q < 8; q++) g->keep.p[d][q] = lo[d]; g->keep.p[d][1] = hi[d] + 1; }
     for (int L = 0; L + 1 < m->nl; L++) {
       if (m->par[L] != l) continue;
-      if (nch == 3) return aa_fail(-1, "[aa_mesh_create]: more than three child Domains on one Grid");
+      if (nch == 3) { aa_mesh_destroy(m); return aa_fail(-1, "[aa_mesh_create]: more than three child Domains on one Grid"); }
       for (int d = 0; d < 3; d++) { g->keep.p[d][2 + 2*nch] = m->link[L].cs[d]; g->keep.p[d][3 + 2*nch] = m->link[L].ce[d] + 1; }
       nch++;
     }
