@@ -659,8 +659,13 @@ def main():
     if world == 1 and not multi and w["run"].ion and (a.spinup == "auto" or a.burst_window) and not a.no_burst:
         # second window: the regime in which the radiation sub-cycle dominates the step (dozens of sub-cycles), so that the
         # sub-cycle kernel's roofline fraction is a driver-timed number as well
-        wb = run_window(c, False, "burst", min(6, a.steps), 0)
-        if rank == 0:
+        try:
+            wb = run_window(c, False, "burst", min(6, a.steps), 0)
+        except Exception as e:           # the headline window above stands on its own: say so and go on
+            wb = None
+            if rank == 0:
+                out["regimes"] = {"burst": {"error": f"{type(e).__name__}: {e}"[:300]}}
+        if rank == 0 and wb is not None:
             b = analyse(c, wb)
             sub = b.get("phases", {}).get("subcycle", {})
             out["regimes"] = {"stationary": {"nsub": out["config"]["radiation_subcycles_per_step"], "ms_per_step": out["ms_per_step"]},
@@ -674,7 +679,10 @@ def main():
                                         "roofline": b.get("roofline")}}
     if rank == 0:
         if not a.no_cpu_baseline and world == 1:
-            cb = cpu_baseline()
+            try:
+                cb = cpu_baseline()
+            except Exception as e:
+                cb = {"value": None, "unit": "cell-updates/s", "cores": 0, "kind": "none", "sample": f"failed: {type(e).__name__}: {e}"[:300]}
             out["cpu_baseline"] = cb
             if "phases" in out and "per_hydro_step_ns_per_zone" in cb:
                 ph = out["phases"]
