@@ -633,6 +633,13 @@ k_correct_all(DevGrid g, Real dt, int kchunk)
   // X3F: the x3 states of zone k+1 wait here while zone k is corrected (each thread its own slots, no barrier): 24
   // registers that the 6-variable gravity kernel does not have at 2 waves per SIMD (it spilled 16 to scratch)
   __shared__ Real s_park[(X3F && CA_PARK) ? 12 : 1][CA_TJ][64];
+  // ... and in the 6-variable gravity kernel, which spilled three registers, the x1 / x2 frame pressures of planes k+1 and k+2 wait
+  // there too (each thread its own slots): no scratch, 18.53 -> 18.18 ms at 512^3 (same-box ABAB x 3; CA_PARK2=0: in registers)
+#ifndef CA_PARK2
+#define CA_PARK2 1
+#endif
+  constexpr bool PARK2 = (CA_PARK2 != 0) && X3F && NS && GRAV;
+  __shared__ Real s_pp[PARK2 ? 4 : 1][CA_TJ][64];
   // The zones a tile needs from its neighbours (lane 0's lower / lane 63's upper x1 neighbour, row 0's lower / row CA_TJ-1's
   // upper x2 neighbour) are requested at the head of the iteration with everything else and wait here for their block: a load
   // issued inside a block would have to wait for the face-state stores of the block before it (loads and stores retire
@@ -678,6 +685,7 @@ k_correct_all(DevGrid g, Real dt, int kchunk)
   if (X3F) {
     load_prim3<NS>(g, (long)kbeg*g.sK + mcol, wn, pn0, pn1);
     load_prim3<NS>(g, (long)(kbeg + 1)*g.sK + mcol, wn2, pn20, pn21);
+    if (PARK2) { s_pp[0][row][lane] = pn0; s_pp[PARK2 ? 1 : 0][row][lane] = pn1; s_pp[PARK2 ? 2 : 0][row][lane] = pn20; s_pp[PARK2 ? 3 : 0][row][lane] = pn21; }
 #pragma unroll
     for (int v = 0; v < 6; v++) { f3[v] = 0.0; wl3[v] = 1.0; wr3[v] = 1.0; wc[v] = 1.0; }
   } else {
@@ -703,8 +711,10 @@ k_correct_all(DevGrid g, Real dt, int kchunk)
     if (X3F) {
 #pragma unroll
       for (int n = 0; n < 6; n++) { wc[n] = wn[n]; wn[n] = wn2[n]; }
-      pc0 = pn0; pc1 = pn1; pn0 = pn20; pn1 = pn21;
+      if (PARK2) { pc0 = s_pp[0][row][lane]; pc1 = s_pp[1][row][lane]; s_pp[0][row][lane] = s_pp[PARK2 ? 2 : 0][row][lane]; s_pp[PARK2 ? 1 : 0][row][lane] = s_pp[PARK2 ? 3 : 0][row][lane]; }
+      else { pc0 = pn0; pc1 = pn1; pn0 = pn20; pn1 = pn21; }
       load_prim3<NS>(g, m + 2*g.sK, wn2, pn20, pn21);
+      if (PARK2) { s_pp[PARK2 ? 2 : 0][row][lane] = pn20; s_pp[PARK2 ? 3 : 0][row][lane] = pn21; }
       if (do3) {
         {   // (A) zone k+1 along x3
           Real wm[6], ws[6], wp[6];
