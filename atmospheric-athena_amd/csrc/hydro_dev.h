@@ -234,8 +234,9 @@ AA_DEV void flux_hlle(const Real ul[6], const Real ur[6], const Real wl[6], cons
 // rsolvers/roe.c:59 fluxes() with the H-correction etah and the HLLE fallback;
 // eigensystem rsolvers/esystem_roe.c:132
 // FAST: the reciprocal forms (AA_FD_ROE, off: see above; k_flux2_update, at its register limit, was also slower with them)
-// XD: the scaling-free quotients / square roots (AA_XDIV) -- everywhere but in k_flux2_update, which is not bound by its
-// instruction count and lost 4 % with them (13.9 -> 14.4 ms at 512^3, same-box ABAB: three more registers spilled)
+// XD: the scaling-free quotients / square roots (AA_XDIV).  k_flux2_update, which is not bound by its instruction count, lost 4 %
+// with them while it was at its register limit (13.9 -> 14.4 ms at 512^3, three more registers spilled) and gains 2 % since its
+// carried x3 flux waits in LDS (FU_PARK, hydro_kernels.hip)
 template <int NS, bool FAST = (AA_FD_ROE != 0), bool XD = true>
 AA_DEV void flux_roe(const Real ul[6], const Real ur[6], const Real wl[6], const Real wr[6],
                      Real etah, Real Gamma, Real Gamma_1, Real f[6])

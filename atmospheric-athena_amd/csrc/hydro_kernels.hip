@@ -1031,7 +1031,10 @@ AA_DEV void face_solve(const DevGrid &g, const FaceIn &in, Real f[6])
   Real wl[6], wr[6];
   cons_to_prim<NS>(in.ul, wl, g.Gamma_1);
   cons_to_prim<NS>(in.ur, wr, g.Gamma_1);
-  flux_roe<NS, false, false>(in.ul, in.ur, wl, wr, etah, g.Gamma, g.Gamma_1, f);      // (see flux_roe: faster without the AA_FAST_DIV and AA_XDIV forms here)
+#ifndef FU_XD
+#define FU_XD 1
+#endif
+  flux_roe<NS, false, (FU_XD != 0)>(in.ul, in.ur, wl, wr, etah, g.Gamma, g.Gamma_1, f);      // (faster without the AA_FAST_DIV forms here; the AA_XDIV forms since the x3 flux is parked in LDS)
 }
 template <int NS, int D>
 AA_DEV void face_flux2(const DevGrid &g, long m, Real f[6])
@@ -1095,6 +1098,15 @@ k_flux2_update(DevGrid g, const Real *dhalf, Real dt, int kchunk, KeepPlanes kp,
   __shared__ Real s_f2[2][FU_TJ][6][64];
   __shared__ Real s_f1e[2][FU_TJ - 1][6], s_f1s[2][FU_TJ - 1][6];
   constexpr bool DMA = (FU_DMA != 0) && NS && GRAV;
+#ifndef FU_PARK
+#define FU_PARK 1
+#endif
+  // The lower x3 flux of the zone -- live across the whole iteration in 12 registers -- waits in the thread's own LDS slots: the
+  // 6-variable gravity kernel then holds 246 registers without scratch, and the scaling-free quotients / square roots of the
+  // solver (FU_XD), which cost it three spilled registers and 4 % before, pay: 13.77 -> 13.45 ms at 512^3 (same-box ABAB x 3;
+  // parked alone 13.70).  FU_PARK=0 / FU_XD=0: the round's earlier form.
+  constexpr bool FPARK = (FU_PARK != 0);
+  __shared__ Real s_f3[FPARK ? 6 : 1][FPARK ? FU_TJ : 1][64];
   __shared__ Real s_dma[DMA ? FU_TJ - 1 : 1][DMA ? 14 : 1][64];      // rows: U0..U5, phi_c, phi_1, phi_2, phi_3, phi_2(j+1), phi_3(k+1), d^{n+1/2} (twice)
   const int lane = threadIdx.x, row = threadIdx.y;
   // Tiles of 64 x (FU_TJ - 1) zones; the rows start on a 128-byte line (zone is) and do not overlap in x1: with a stride
@@ -1137,6 +1149,10 @@ k_flux2_update(DevGrid g, const Real *dhalf, Real dt, int kchunk, KeepPlanes kp,
   if (cell) {                                                                   // face k0
     face_flux2<NS, 2>(g, (long)k0*g.sK + mcol, f3lo);
     if (KEEP && on_plane(kp, 2, k0)) store_sweep<2, NS>(Ff(g, 2, 0), g.nc, (long)k0*g.sK + mcol, f3lo);
+  }
+  if (FPARK) {
+#pragma unroll
+    for (int n = 0; n < NV; n++) s_f3[FPARK ? n : 0][FPARK ? row : 0][lane] = f3lo[n];
   }
   // Software pipeline: the operands of the NEXT Riemann problem are requested before the current one is
   // solved (x2's during the x1 solve, x3's during x2's, the next zone's x1's during x3's), so that with two
@@ -1238,11 +1254,11 @@ k_flux2_update(DevGrid g, const Real *dhalf, Real dt, int kchunk, KeepPlanes kp,
     if (cell) {
       if (KEEP && on_plane(kp, 2, k + 1)) store_sweep<2, NS>(Ff(g, 2, 0), g.nc, m + g.sK, f3);
 #pragma unroll
-      for (int n = 0; n < NV; n++) d3[n] = f3[n] - f3lo[n];
+      for (int n = 0; n < NV; n++) { if (FPARK) f3lo[n] = s_f3[FPARK ? n : 0][FPARK ? row : 0][lane]; d3[n] = f3[n] - f3lo[n]; }
       m3hi = f3[0];
       const Real m3lo = f3lo[0];
 #pragma unroll
-      for (int n = 0; n < NV; n++) f3lo[n] = f3[n];
+      for (int n = 0; n < NV; n++) { if (FPARK) s_f3[FPARK ? n : 0][FPARK ? row : 0][lane] = f3[n]; else f3lo[n] = f3[n]; }
       Real u[6];
       constexpr bool from_lds = DMA;       // (the experiment build takes Grids whose rows are whole tiles only: Nx1 a multiple of 64)
       if (from_lds) {
