@@ -295,8 +295,14 @@ AA_DEV bool decode_zone(const Order o, int ni, int nj, int nk, int &i, int &j, i
 // ---- steps 2,3: x2 / x3 sweeps, register sliding window along the sweep direction ---------
 // One thread owns one (i, transverse) column and a chunk of `chunk` interfaces; lanes are
 // consecutive in i.  Cells reconstructed: l..u = s-2..e+2; interfaces l+1..u (:179-184).
+#ifndef SW_PARK
+#define SW_PARK 0          /* experiment: 1 = the carried left state, 2 = also the window's two upper cells, parked in LDS over the face's work */
+#endif
+#ifndef SW_OCC
+#define SW_OCC 3
+#endif
 template <int NS, int D, bool GRAV, int MODE, int ORD>
-__global__ void __launch_bounds__(256, 3)      // 3 waves per SIMD (168 VGPRs): the kernel is VALU-bound and sits right at that edge
+__global__ void __launch_bounds__(SW_PARK ? 64 : 256, SW_OCC)      // 3 waves per SIMD (168 VGPRs): the kernel is VALU-bound and sits right at that edge
 k_sweep_march(DevGrid g, const Real *src, Real dt, int chunk, int toff, int tcnt)
 {
   static_assert(D == 1 || D == 2, "march kernel is for the strided directions");
@@ -322,6 +328,12 @@ k_sweep_march(DevGrid g, const Real *src, Real dt, int chunk, int toff, int tcnt
   // instances may round differently, and the result must not depend on where the chunks start (the
   // chunk size follows the Grid size, hence the decomposition).
   Real wm[6], w[6], wp[6], wl_cur[6], wl_next[6], wr[6], u[6];
+#if SW_PARK
+  __shared__ Real s_pk[SW_PARK == 2 ? 18 : 6][64];
+  const int ln = threadIdx.x;
+#pragma unroll
+  for (int n = 0; n < 6; n++) s_pk[n][ln] = 0.0;
+#endif
   load_sweep<D, NS>(src, g.nc, base + (long)(f0 - 2)*s, u); cons_to_prim<NS>(u, w,  g.Gamma_1);
   load_sweep<D, NS>(src, g.nc, base + (long)(f0 - 1)*s, u); cons_to_prim<NS>(u, wp, g.Gamma_1);
 #pragma unroll
@@ -334,9 +346,25 @@ k_sweep_march(DevGrid g, const Real *src, Real dt, int chunk, int toff, int tcnt
     for (int n = 0; n < 6; n++) { wm[n] = w[n]; w[n] = wp[n]; }
     load_sweep<D, NS>(src, g.nc, mf + s, u); cons_to_prim<NS>(u, wp, g.Gamma_1);
     recon_cell<NS, MODE != MODE_VL, ORD, D>(g, mf, wm, w, wp, dtodx, wl_next, wr);  // cell f -> Wl[f+1], Wr[f]
+#if SW_PARK
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int n = 0; n < 6; n++) { wl_cur[n] = s_pk[n][ln]; s_pk[n][ln] = wl_next[n]; }
+#if SW_PARK == 2
+#pragma unroll
+    for (int n = 0; n < 6; n++) { s_pk[6 + n][ln] = w[n]; s_pk[12 + n][ln] = wp[n]; }
+#endif
+    asm volatile("" ::: "memory");
+#endif
     if (f >= f0) face_work<NS, D, GRAV, MODE>(g, mf, i, D == 1 ? f : t, D == 1 ? t : f, dt, wl_cur, wr);
+#if SW_PARK == 2
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int n = 0; n < 6; n++) { w[n] = s_pk[6 + n][ln]; wp[n] = s_pk[12 + n][ln]; }
+#elif !SW_PARK
 #pragma unroll
     for (int n = 0; n < 6; n++) wl_cur[n] = wl_next[n];
+#endif
   }
 }
 
