@@ -443,6 +443,68 @@ k_sweep_tile(DevGrid g, const Real *src, Real dt)
 // ---- step 1: x1 sweep, neighbours through LDS ------------------------------------------
 // A block of B threads reconstructs B consecutive cells of one (j,k) row and solves the B-1
 // interfaces between them; blocks overlap by one cell.
+#ifndef SW_X1_FLAT
+#define SW_X1_FLAT 1
+#endif
+// The x1 sweep with the rows of a k-plane laid end to end (SW_X1_FLAT, the default): a plane's (je-js+5) rows of nc = ie-is+5
+// cells l..u are ONE line of slots, cut into blocks of B-1 faces wherever they fall, so that only the plane's last block has
+// idle lanes (a block per row piece left 576 lanes for 516 cells at 512^3, 128 for 68 at 64^3).  A row's first cell has no
+// face to solve and its lower neighbour is not the slot before it: the lanes at a row's (or the block's) ends fetch and convert
+// that one neighbour themselves, everybody else finds it in LDS.  slot -> (row, cell) by a multiply-shift with the host's
+// reciprocal (exact below 2^30 slots per plane: launch_sweep checks).
+template <int NS, bool GRAV, int MODE, int ORD>
+__global__ void __launch_bounds__(256, 4)
+k_sweep_x1_flat(DevGrid g, const Real *src, Real dt, int koff, unsigned nslots, unsigned rmul, int rsh)
+{
+  extern __shared__ Real sm[];
+  const int B = blockDim.x, t = threadIdx.x;
+  const int nc = g.ie - g.is + 5;                      // cells l..u of a row
+  const unsigned s = blockIdx.x*(unsigned)(B - 1) + t;
+  const bool have = (s < nslots);
+  const unsigned r = have ? (unsigned)(((unsigned long long)s*rmul) >> rsh) : 0u;
+  const int ci = have ? (int)(s - r*(unsigned)nc) : 1;
+  const int j = g.js - 2 + (int)r, k = g.ks - 2 + koff + blockIdx.y;
+  const int c = g.is - 2 + ci;
+  const long row = (long)k*g.sK + (long)j*g.sJ;
+  const Real dtodx = dt/g.dx[0];
+  const bool lo_own = have && (t == 0 || ci == 0);          // the lower / upper neighbour is not in this block's LDS line
+  const bool hi_own = have && (t == B - 1 || ci == nc - 1 || s + 1 == nslots);
+  Real u[6], w[6], wm[6], wp[6], ulo[6], uhi[6];
+  if (have) load_sweep<0, NS>(src, g.nc, row + c, u);
+  if (lo_own) load_sweep<0, NS>(src, g.nc, row + c - 1, ulo);
+  if (hi_own) load_sweep<0, NS>(src, g.nc, row + c + 1, uhi);
+  if (have) cons_to_prim<NS>(u, w, g.Gamma_1);
+  else {
+#pragma unroll
+    for (int n = 0; n < 6; n++) w[n] = 1.0;
+  }
+#pragma unroll
+  for (int n = 0; n < 5 + NS; n++) sm[n*B + t] = w[n];
+  __syncthreads();
+#pragma unroll
+  for (int n = 0; n < 5 + NS; n++) { wm[n] = sm[n*B + (t > 0 ? t - 1 : 0)]; wp[n] = sm[n*B + (t < B - 1 ? t + 1 : t)]; }
+  if (!NS) { wm[5] = 0.0; wp[5] = 0.0; }
+  if (lo_own) cons_to_prim<NS>(ulo, wm, g.Gamma_1);
+  if (hi_own) cons_to_prim<NS>(uhi, wp, g.Gamma_1);
+  Real wl_next[6], wr[6];
+  if (have) recon_cell<NS, MODE != MODE_VL, ORD, 0>(g, row + c, wm, w, wp, dtodx, wl_next, wr);
+  else {
+#pragma unroll
+    for (int n = 0; n < 6; n++) { wl_next[n] = 1.0; wr[n] = 1.0; }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int n = 0; n < 5 + NS; n++) sm[n*B + t] = wl_next[n];
+  __syncthreads();
+  if (t >= 1 && ci >= 1 && have) {                     // interface c, between cells c-1 and c
+    Real wl[6];
+#pragma unroll
+    for (int n = 0; n < 5 + NS; n++) wl[n] = sm[n*B + t - 1];
+    if (!NS) wl[5] = 0.0;
+    face_work<NS, 0, GRAV, MODE>(g, row + c, c, j, k, dt, wl, wr);
+  }
+}
+
 template <int NS, bool GRAV, int MODE, int ORD>
 __global__ void __launch_bounds__(256, 4)
 k_sweep_x1(DevGrid g, const Real *src, Real dt, int koff)
@@ -1844,6 +1906,20 @@ static void sweep_impl_o(const DevGrid &g, const Real *src, int dir, Real dt, hi
   if (kcnt < 0) kcnt = nk_all - koff;
   if (kcnt <= 0) return;
   if (dir == 0) {
+#if SW_X1_FLAT
+    static const int flat = getenv("AA_X1_FLAT") ? atoi(getenv("AA_X1_FLAT")) : 1;
+    const long nc = g.ie - g.is + 5, nslots = nc*(g.je - g.js + 5);
+    if (flat && nslots < (1L << 30)) {
+      int rsh = 31; while ((2L << (rsh - 31)) <= nc) rsh++;            // 31 + floor(log2 nc)
+      const unsigned long long rmul = ((1ULL << rsh) + nc - 1)/nc;      // <= 2^31; exact quotients for slots < 2^30
+      int Bf = (int)((nslots + 63)/64)*64; if (Bf > 256 || nslots > 256) Bf = 256;
+      dim3 gridf((unsigned)((nslots - 1 + Bf - 2)/(Bf - 1)), kcnt);
+      if (gridf.x < 1) gridf.x = 1;
+      hipLaunchKernelGGL((k_sweep_x1_flat<NS, GRAV, MODE, ORD>), gridf, dim3(Bf), (size_t)(5 + NS)*Bf*sizeof(Real), st, g, src, dt,
+                         koff, (unsigned)nslots, (unsigned)rmul, rsh);
+      return;
+    }
+#endif
     const int nfaces = (g.ie - g.is + 1) + 3;          // interfaces l+1..u
     int nb = (nfaces + 254)/255;
     int B = (nfaces + nb - 1)/nb + 1;                  // B-1 interfaces per block
