@@ -26,7 +26,7 @@ ALIAS = [(r"k_ion_pass<true, true, false>", "ion_pass"), (r"k_ion_pass<true, fal
          (r"k_ion_update", "ion_update"), (r"k_ion_rates", "ion_rates"), (r"k_ray_sweep<true>", "ray_sweep_rates"),
          (r"k_ray_sweep<false>", "ray_sweep"), (r"k_ion_begin", "ion_begin"), (r"k_cfl", "new_dt"), (r"k_update<", "update"),
          (r"k_flux2_update<", "flux2_update"), (r"k_correct_all<", "correct_all"), (r"k_eta_edges<", "correct_all"),
-         (r"k_sweep_x1<1, true, 0", "sweep_x1"), (r"k_sweep_march<1, 1, true, 0", "sweep_x2"), (r"k_sweep_march<1, 2, true, 0", "sweep_x3"),
+         (r"k_sweep_x1<1, true, 0", "sweep_x1"), (r"k_sweep_x1_flat<1, true, 0", "sweep_x1"), (r"k_sweep_march<1, 1, true, 0", "sweep_x2"), (r"k_sweep_march<1, 2, true, 0", "sweep_x3"),
          (r"k_bc", "bvals_mhd"), (r"k_pinned", "pinned_cells")]
 
 
@@ -74,7 +74,7 @@ for n, rows in dur.items():
     rows.sort()
     # launches per step in the timed region: launches between the start of the steps-th last launch of k_correct_all ...
     table.append((n, key, rows))
-ref = sorted(dur[[n for n in dur if "k_correct_all<" in n or "k_sweep_x1<" in n][0]])
+ref = sorted(dur[[n for n in dur if "k_correct_all<" in n or "k_sweep_x1<" in n or "k_sweep_x1_flat<" in n][0]])
 t0 = ref[-steps][0]                       # start of the timed region's first hydro kernel of that name
 # the ion step precedes the hydro kernels of a step: open the window at the last ion-step entry before t0
 entries = sorted(s for n in dur if ("k_ion_pass<false, true" in n or "k_ion_begin" in n) for s, _ in dur[n] if s < t0)
