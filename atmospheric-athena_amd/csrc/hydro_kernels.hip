@@ -295,6 +295,13 @@ AA_DEV bool decode_zone(const Order o, int ni, int nj, int nk, int &i, int &j, i
 // ---- steps 2,3: x2 / x3 sweeps, register sliding window along the sweep direction ---------
 // One thread owns one (i, transverse) column and a chunk of `chunk` interfaces; lanes are
 // consecutive in i.  Cells reconstructed: l..u = s-2..e+2; interfaces l+1..u (:179-184).
+#ifndef SW_ALIGN
+#define SW_ALIGN 1
+#endif
+// (the pool puts zone i = 4 of every row on a 128-byte line when the pitch is a multiple of 16 doubles: api.hip)
+__host__ __device__ static inline int march_shift(const DevGrid &g) { return (g.sJ & 15) ? 0 : ((g.is - 2 + 12) & 15); }
+__host__ __device__ static inline int march_slots(const DevGrid &g)
+{ const int n = march_shift(g) + g.ie - g.is + 5; return (g.sJ & 15) ? n : ((n + 15) & ~15); }
 #ifndef SW_PARK
 #define SW_PARK 0          /* experiment: 1 = the carried left state, 2 = also the window's two upper cells, parked in LDS over the face's work */
 #endif
@@ -306,15 +313,26 @@ __global__ void __launch_bounds__(SW_PARK ? 64 : 256, SW_OCC)      // 3 waves pe
 k_sweep_march(DevGrid g, const Real *src, Real dt, int chunk, int toff, int tcnt)
 {
   static_assert(D == 1 || D == 2, "march kernel is for the strided directions");
-  const int ni = g.ie - g.is + 5;                              // i in [is-2, ie+2]
   // transverse lines toff .. toff+tcnt-1 of the (D == 1 ? ke - ks : je - js) + 5 (the launcher passes all of them, or
   // for x2 a range of k-planes: see launch_sweep)
   const int tlo = (D == 1 ? g.ks : g.js) - 2 + toff;
   const int nt  = tcnt;
   const long lin = (long)blockIdx.x*blockDim.x + threadIdx.x;
+#if SW_ALIGN
+  // lanes on whole 128-byte lines: a row of slots starts on the line that holds is-2 and is a whole number of lines long (a
+  // wavefront's 64 lanes are four whole lines of one or two rows; the lanes off the ends of [is-2, ie+2] leave)
+  const int sh = march_shift(g), nq = march_slots(g);
+  if (lin >= (long)nq*nt) return;
+  const int q = (int)(lin % nq);
+  const int i = g.is - 2 - sh + q;
+  const int t = tlo + (int)(lin / nq);
+  if (q < sh || i > g.ie + 2) return;
+#else
+  const int ni = g.ie - g.is + 5;                              // i in [is-2, ie+2]
   if (lin >= (long)ni*nt) return;
   const int i = g.is - 2 + (int)(lin % ni);
   const int t = tlo + (int)(lin / ni);
+#endif
   const int lo = (D == 1 ? g.js : g.ks), hi = (D == 1 ? g.je : g.ke);
   const int f0 = lo - 1 + blockIdx.y*chunk;                    // first interface of this chunk
   int f1 = f0 + chunk - 1; if (f1 > hi + 2) f1 = hi + 2;
@@ -1938,7 +1956,7 @@ static void sweep_impl_o(const DevGrid &g, const Real *src, int dir, Real dt, hi
     if (dir == 1) hipLaunchKernelGGL((k_sweep_tile<NS, 1, GRAV, MODE, BT, ORD>), grid, blk, lds, st, g, src, dt);
     else          hipLaunchKernelGGL((k_sweep_tile<NS, 2, GRAV, MODE, BT, ORD>), grid, blk, lds, st, g, src, dt);
   } else if constexpr (MODE == MODE_FLUX1 || MODE == MODE_VL) {
-    const long ni = g.ie - g.is + 5;
+    const long ni = SW_ALIGN ? march_slots(g) : g.ie - g.is + 5;
     const long nt = (dir == 1 ? kcnt : g.je - g.js + 5);
     const int toff = (dir == 1 ? koff : 0);
     const int nfaces = (dir == 1 ? g.je - g.js : g.ke - g.ks) + 1 + 3;
