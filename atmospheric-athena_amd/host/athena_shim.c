@@ -313,6 +313,7 @@ static void refresh_for_userwork(int l)
   host_newer[l] = 1;
   if (learn) {
     if (!snap[l]) snap[l] = (double*)malloc(ncell[l]*sizeof(ConsS));
+    if (!snap[l]) ath_error("[athena_amd]: out of host memory for the snapshot of the host block\n");
     memcpy(snap[l], host_block(l), ncell[l]*sizeof(ConsS));
   }
 }
@@ -412,7 +413,8 @@ static void halo_exchange(int dir)
   MPI_Request rq[4]; MPI_Status st[4]; int nrq = 0, side, w;
   if (lo < 0 && hi < 0) return;
   for (side = 0; side < 2; side++) for (w = 0; w < 2; w++)
-    if (!hbuf[dir - 1][side][w]) hbuf[dir - 1][side][w] = (double*)malloc((size_t)n*sizeof(double));
+    if (!hbuf[dir - 1][side][w] && !(hbuf[dir - 1][side][w] = (double*)malloc((size_t)n*sizeof(double))))
+      ath_error("[athena_amd]: out of host memory for the MPI halo buffers\n");
   if (lo >= 0) MPI_Irecv(hbuf[dir - 1][0][1], (int)n, MPI_DOUBLE, lo, 100 + 2*dir + 1, comm_dom, &rq[nrq++]);   /* travelled up   */
   if (hi >= 0) MPI_Irecv(hbuf[dir - 1][1][1], (int)n, MPI_DOUBLE, hi, 100 + 2*dir,     comm_dom, &rq[nrq++]);   /* travelled down */
   if (lo >= 0) { CHK(aa_halo_get(G[0], dir, 0, hbuf[dir - 1][0][0])); MPI_Isend(hbuf[dir - 1][0][0], (int)n, MPI_DOUBLE, lo, 100 + 2*dir, comm_dom, &rq[nrq++]); }
@@ -497,6 +499,7 @@ void new_dt(MeshS *pM)
       const double *h = host_block(l); long long cnt = 0, c; size_t i; int v;
       for (i = 0; i < ncell[l]; i++) if (memcmp(h + i*nv, snap[l] + i*nv, nv*sizeof(double)) != 0) cnt++;
       idx_l[l] = (long long*)malloc((size_t)(cnt + 1)*sizeof(long long)); val_l[l] = (double*)malloc((size_t)(cnt + 1)*nv*sizeof(double));
+      if (idx_l[l] == NULL || val_l[l] == NULL) ath_error("[athena_amd]: out of host memory for the %lld zones Userwork_in_loop wrote\n", cnt);
       for (i = 0, c = 0; i < ncell[l]; i++) if (memcmp(h + i*nv, snap[l] + i*nv, nv*sizeof(double)) != 0) {
         idx_l[l][c] = (long long)i; for (v = 0; v < nv; v++) val_l[l][c*nv + v] = h[i*nv + v]; c++;
       }
