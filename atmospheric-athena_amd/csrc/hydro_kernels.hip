@@ -302,6 +302,51 @@ AA_DEV bool decode_zone(const Order o, int ni, int nj, int nk, int &i, int &j, i
 __host__ __device__ static inline int march_shift(const DevGrid &g) { return (g.sJ & 15) ? 0 : ((g.is - 2 + 12) & 15); }
 __host__ __device__ static inline int march_slots(const DevGrid &g)
 { const int n = march_shift(g) + g.ie - g.is + 5; return (g.sJ & 15) ? n : ((n + 15) & ~15); }
+// The limited slopes along x2 / x3 as a march (SLOPES_MARCH, the default): k_slopes reads and converts three cells per zone, two of them
+// in other rows, which at 512^3 come back from HBM for blocks on other XCDs; here a thread owns an (i, transverse) column and a
+// chunk of cells along D with the three-cell window in registers (every cell read and converted once, lanes on whole 128-byte
+// lines as in k_sweep_march).  ONE inlined instance of the conversion serves every cell, so the values do not depend on where
+// the chunks start.  Cells [s-3, e+3] along D, [s-2, e+2] across, as k_slopes.
+#ifndef SLOPES_MARCH
+#define SLOPES_MARCH 1
+#endif
+template <int NS, int D>
+__global__ void __launch_bounds__(64)
+k_slopes_march(DevGrid g, const Real *src, int chunk)
+{
+  static_assert(D == 1 || D == 2, "march kernel is for the strided directions");
+  const int sh = march_shift(g), nq = march_slots(g);
+  const int nt = (D == 1 ? g.ke - g.ks : g.je - g.js) + 5;
+  const long lin = (long)blockIdx.x*blockDim.x + threadIdx.x;
+  if (lin >= (long)nq*nt) return;
+  const int q = (int)(lin % nq);
+  const int i = g.is - 2 - sh + q;
+  const int t = (D == 1 ? g.ks : g.js) - 2 + (int)(lin / nq);
+  if (q < sh || i > g.ie + 2) return;
+  const int lo = (D == 1 ? g.js : g.ks) - 3, hi = (D == 1 ? g.je : g.ke) + 3;
+  const int c0 = lo + blockIdx.y*chunk;
+  int c1 = c0 + chunk - 1; if (c1 > hi) c1 = hi;
+  if (c0 > c1) return;
+  const long s = stride<D>(g);
+  const long base = (D == 1) ? ((long)t*g.sK + i) : ((long)t*g.sJ + i);
+  Real wm[6], w[6], wp[6], u[6], dW[6];
+#pragma unroll
+  for (int n = 0; n < 6; n++) { w[n] = 1.0; wp[n] = 1.0; }
+#pragma nounroll
+  for (int c = c0 - 2; c <= c1; c++) {
+    long mc = base + (long)c*s;
+    asm volatile("" : "+v"(mc));
+#pragma unroll
+    for (int n = 0; n < 6; n++) { wm[n] = w[n]; w[n] = wp[n]; }
+    load_sweep<D, NS>(src, g.nc, mc + s, u); cons_to_prim<NS>(u, wp, g.Gamma_1);
+    if (c >= c0) {
+      limited_slopes<NS>(wm, w, wp, g.Gamma, dW);
+#pragma unroll
+      for (int n = 0; n < 5 + NS; n++) Sf(g, D, n)[mc] = dW[n];
+    }
+  }
+}
+
 #ifndef SW_PARK
 #define SW_PARK 0          /* experiment: 1 = the carried left state, 2 = also the window's two upper cells, parked in LDS over the face's work */
 #endif
@@ -1987,6 +2032,19 @@ static void slopes_impl(const DevGrid &g, int dir, hipStream_t st, const Real *s
   const int lo[3] = {g.is, g.js, g.ks}, hi[3] = {g.ie, g.je, g.ke};
   for (int d = 0; d < 3; d++) n *= hi[d] - lo[d] + 1 + (d == dir ? 6 : 4);
   dim3 grid(nblk(n, 256)), blk(256);
+#if SLOPES_MARCH
+  static const int march = getenv("AA_SLOPES_MARCH") ? atoi(getenv("AA_SLOPES_MARCH")) : 1;
+  if (march && dir != 0) {
+    const long nq = march_slots(g), nt = (dir == 1 ? g.ke - g.ks : g.je - g.js) + 5;
+    const int ncell = (dir == 1 ? g.je - g.js : g.ke - g.ks) + 7;
+    int chunk = 32;
+    while (chunk > 4 && (long)nblk(nq*nt, 64)*((ncell + chunk - 1)/chunk) < 4096) chunk >>= 1;
+    dim3 gm(nblk(nq*nt, 64), (ncell + chunk - 1)/chunk);
+    if (dir == 1) hipLaunchKernelGGL((k_slopes_march<NS, 1>), gm, dim3(64), 0, st, g, src, chunk);
+    else          hipLaunchKernelGGL((k_slopes_march<NS, 2>), gm, dim3(64), 0, st, g, src, chunk);
+    return;
+  }
+#endif
   if (dir == 0) hipLaunchKernelGGL((k_slopes<NS, 0>), grid, blk, 0, st, g, src);
   else if (dir == 1) hipLaunchKernelGGL((k_slopes<NS, 1>), grid, blk, 0, st, g, src);
   else hipLaunchKernelGGL((k_slopes<NS, 2>), grid, blk, 0, st, g, src);
