@@ -1,0 +1,45 @@
+"""The layouts adopted in round 3 against the ones they replaced: the x1 first-pass sweep with a plane's rows laid end to end
+(AA_X1_FLAT=0: a block per row piece) and the PPM slope arrays along x2 / x3 by a march (AA_SLOPES_MARCH=0: one zone per thread).
+Strict build: the same bits.  Default build: the flat x1 sweep changes no bit either (the same inlined arithmetic per zone); the
+marching slope kernel converts a cell with ONE instance of cons_to_prim where k_slopes has three, which hipcc may contract
+differently: rounding level.  Odd sizes, so that rows, blocks and chunks end in the middle of wavefronts; the library reads the
+switches once per process, hence the child processes."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+TOOL = os.path.join(HERE, "tools", "layout_run.py")
+
+CASES = [("blast", 37, 19, 23, 2, "ctu", 3), ("ioniz_sphere", 70, 21, 18, 3, "ctu", 2), ("blast", 130, 18, 17, 3, "vl", 3),
+         ("ioniz_sphere", 128, 128, 128, 2, "ctu", 2)]        # the last one takes the big-Grid kernels (2^21 zones)
+
+
+def _run(case, env, out, strict):
+    e = dict(os.environ); e.update(env)
+    r = subprocess.run([sys.executable, TOOL] + [str(x) for x in case] + [out] + (["strict"] if strict else []), env=e,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    return np.load(out)
+
+
+@pytest.mark.parametrize("strict", [True, False], ids=["strict", "default"])
+@pytest.mark.parametrize("case", CASES, ids=lambda c: f"{c[0]}-{c[1]}x{c[2]}x{c[3]}-o{c[4]}-{c[5]}")
+def test_old_and_new_layouts(case, strict, tmp_path):
+    new = _run(case, {}, str(tmp_path / "new.npy"), strict)
+    assert np.isfinite(new).all()
+    old_x1 = _run(case, {"AA_X1_FLAT": "0"}, str(tmp_path / "old_x1.npy"), strict)
+    assert np.array_equal(new, old_x1)
+    if case[4] == 3:
+        old_sl = _run(case, {"AA_SLOPES_MARCH": "0"}, str(tmp_path / "old_sl.npy"), strict)
+        if strict:
+            assert np.array_equal(new, old_sl)
+        else:
+            scale = np.abs(old_sl).max(axis=tuple(range(old_sl.ndim - 1)), keepdims=True)
+            err = float(np.max(np.abs(new - old_sl)/scale))
+            print("default build, marching slopes against k_slopes: max error / field scale", err)
+            assert err < 1e-11
