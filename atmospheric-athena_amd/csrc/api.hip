@@ -199,6 +199,7 @@ void aa_destroy(aa_grid *g)
   if (g->pin_idx) hipFree(g->pin_idx);
   if (g->pin_val) hipFree(g->pin_val);
   if (g->pin_mask) hipFree(g->pin_mask);
+  if (g->cfl_part) hipFree(g->cfl_part);
   if (g->d.phalf) hipFree(g->d.phalf);
   if (g->own_stream) hipStreamDestroy(g->st);
   delete g;
@@ -578,7 +579,7 @@ int aa_integrate_3d_ctu(aa_grid *g)
     { Scope s(g, "flux2_x1"); HL(launch_flux2)(d, ns, 0, g->st); }
     { Scope s(g, "flux2_x2"); HL(launch_flux2)(d, ns, 1, g->st); }
     { Scope s(g, "flux2_x3"); HL(launch_flux2)(d, ns, 2, g->st); }
-    { Scope s(g, "update");   HL(launch_update)(d, ns, d.dhalf, dt, g->grav, g->st); }
+    { Scope s(g, "update");   HL(launch_update)(d, ns, d.dhalf, dt, g->grav, g->st, nullptr, nullptr, nullptr); }
   }
   HIPCHK(hipGetLastError());
   return 0;
@@ -603,7 +604,18 @@ int aa_integrate_3d_vl(aa_grid *g)
   { Scope s(g, "vl_flux2_x1"); launch_vl_flux2(d, ns, 0, dt, g->st); }
   { Scope s(g, "vl_flux2_x2"); launch_vl_flux2(d, ns, 1, dt, g->st); }
   { Scope s(g, "vl_flux2_x3"); launch_vl_flux2(d, ns, 2, dt, g->st); }
-  { Scope s(g, "update");   launch_update(d, ns, d.LR, dt, g->grav, g->st); }   // d^{n+1/2} = Uhalf.d
+  {
+    Scope s(g, "update");
+    cfl_arm(g);                      // aa_cfl_in_update: new_dt's maxima ride on the update, as in k_flux2_update
+    if (g->cfl_ready) {
+      const long nb = update_blocks(d);
+      if (g->cfl_part_n < 3*nb) {
+        if (g->cfl_part) { (void)hipFree(g->cfl_part); g->cfl_part = nullptr; g->cfl_part_n = 0; }
+        if (hipMalloc(&g->cfl_part, (size_t)3*nb*sizeof(Real)) == hipSuccess) g->cfl_part_n = 3*nb; else g->cfl_ready = false;
+      }
+    }
+    launch_update(d, ns, d.LR, dt, g->grav, g->st, g->cfl_ready ? g->sc : nullptr, g->cfl_part, g->pin_mask);   // d^{n+1/2} = Uhalf.d
+  }
   HIPCHK(hipGetLastError());
   return 0;
 }

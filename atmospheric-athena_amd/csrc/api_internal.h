@@ -24,6 +24,7 @@ struct aa_grid {
   aa::DevScalars *sc = nullptr;        // device
   aa::DevScalars *sc_host = nullptr;   // pinned
   long long *pin_idx = nullptr; aa::Real *pin_val = nullptr; long long npin = 0;
+  double *cfl_part = nullptr; long cfl_part_n = 0;   // the blocks' CFL maxima of k_update<CFL> (van Leer integrator), 3 x update_blocks
   unsigned char *pin_mask = nullptr;   // 1 where a zone is pinned (k_flux2_update<CFL> leaves those to k_pinned_cfl)
   bool cfl_in_update = false;          // aa_cfl_in_update: the integrator also leaves new_dt's maxima behind
   bool ion_spec_on = true;             // AA_ION_SPECULATE=0: the first pass of an ion step never applies an update

@@ -1098,13 +1098,22 @@ k_flux2(DevGrid g, Order ord)
 }
 
 // ---- steps 11a, 12: gravity source and conservative update ---------------------------------
-template <int NS, bool GRAV>
+AA_DEV void cfl_zone(Real d, Real m1, Real m2, Real m3, Real e, Real Gamma, Real Gamma_1, Real mx[3]);
+AA_DEV void atomic_max_pos(unsigned long long *addr, Real v);
+template <int NS, bool GRAV, bool CFL>
 __global__ void __launch_bounds__(256)
-k_update(DevGrid g, const Real *dhalf, Real dt, Order ord)
+k_update(DevGrid g, const Real *dhalf, Real dt, Order ord, Real *cfl_part, const unsigned char *pinmask)
 {
+  // CFL (the van Leer integrator's update; the CTU path has it in k_flux2_update): the zone's contribution to new_dt's maxima from the
+  // updated state while it is in registers; one zone per thread makes half a million blocks at 512^3, so a block leaves its three
+  // maxima in cfl_part[d][block] (k_cfl_fold turns them into the three words) instead of 1.5 M same-address atomics
+  __shared__ Real s_red[CFL ? 3 : 1][CFL ? 256 : 1];
+  Real cmx[3] = {0.0, 0.0, 0.0};
   const int ni = g.ie - g.is + 1, nj = g.je - g.js + 1, nk = g.ke - g.ks + 1;
   int i, j, k;
-  if (!decode_zone(ord, ni, nj, nk, i, j, k)) return;
+  const bool ok = decode_zone(ord, ni, nj, nk, i, j, k);
+  if (!CFL && !ok) return;
+  if (ok) {
   i += g.is; j += g.js; k += g.ks;
   const long m = (long)k*g.sK + (long)j*g.sJ + i;
   constexpr int NV = 5 + NS;
@@ -1136,6 +1145,45 @@ k_update(DevGrid g, const Real *dhalf, Real dt, Order ord)
   }
 #pragma unroll
   for (int v = 0; v < NV; v++) Uf(g, v)[m] = u[v];
+  if (CFL && !(pinmask && pinmask[m])) cfl_zone(u[0], u[1], u[2], u[3], u[4], g.Gamma, g.Gamma_1, cmx);
+  }
+  if (CFL) {
+    const int t = threadIdx.x;
+#pragma unroll
+    for (int d = 0; d < 3; d++) s_red[CFL ? d : 0][CFL ? t : 0] = cmx[d];
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+      if (t < w) {
+#pragma unroll
+        for (int d = 0; d < 3; d++) s_red[CFL ? d : 0][CFL ? t : 0] = rmax(s_red[CFL ? d : 0][CFL ? t : 0], s_red[CFL ? d : 0][CFL ? t + w : 0]);
+      }
+      __syncthreads();
+    }
+    if (t < 3) cfl_part[(size_t)t*gridDim.x + blockIdx.x] = s_red[CFL ? t : 0][0];
+  }
+}
+
+// the blocks' maxima of k_update<CFL> -> the three words of new_dt (MAX of non-negative doubles on their bit patterns: order-free)
+__global__ void __launch_bounds__(256)
+k_cfl_fold(const Real *part, int nb, DevScalars *sc)
+{
+  __shared__ Real red[3][256];
+  Real mx[3] = {0.0, 0.0, 0.0};
+  for (int b = blockIdx.x*256 + threadIdx.x; b < nb; b += gridDim.x*256) {
+#pragma unroll
+    for (int d = 0; d < 3; d++) mx[d] = rmax(mx[d], part[(size_t)d*nb + b]);
+  }
+#pragma unroll
+  for (int d = 0; d < 3; d++) red[d][threadIdx.x] = mx[d];
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if ((int)threadIdx.x < w) {
+#pragma unroll
+      for (int d = 0; d < 3; d++) red[d][threadIdx.x] = rmax(red[d][threadIdx.x], red[d][threadIdx.x + w]);
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x < 3) atomic_max_pos(&sc->max_v[threadIdx.x], red[threadIdx.x][0]);
 }
 
 // ---- steps 9b-d + 11a + 12 in one marching kernel --------------------------------------------
@@ -2183,14 +2231,27 @@ void launch_flux2_update(const DevGrid &g, int nscal, Real dt, bool grav, const 
   else       { if (grav) launch_fu<0, true>(g, dt, kc, grid, blk, keep, sc, pinmask, st); else launch_fu<0, false>(g, dt, kc, grid, blk, keep, sc, pinmask, st); }
 }
 
-void launch_update(const DevGrid &g, int nscal, const Real *dhalf, Real dt, bool grav, hipStream_t st)
+long update_blocks(const DevGrid &g)
+{ return (long)nblk8((long)(g.ie - g.is + 1)*(g.je - g.js + 1)*(g.ke - g.ks + 1), 256); }
+// sc != nullptr: new_dt's maxima ride on the update (cfl_part: 3 * update_blocks(g) doubles of scratch; pinmask: zones left out)
+void launch_update(const DevGrid &g, int nscal, const Real *dhalf, Real dt, bool grav, hipStream_t st, DevScalars *sc, Real *cfl_part,
+                   const unsigned char *pinmask)
 {
   const long n = (long)(g.ie - g.is + 1)*(g.je - g.js + 1)*(g.ke - g.ks + 1);
   dim3 grid(nblk8(n, 256)), blk(256);
-  if (nscal) { if (grav) hipLaunchKernelGGL((k_update<1, true>), grid, blk, 0, st, g, dhalf, dt, zone_order());
-               else      hipLaunchKernelGGL((k_update<1, false>), grid, blk, 0, st, g, dhalf, dt, zone_order()); }
-  else       { if (grav) hipLaunchKernelGGL((k_update<0, true>), grid, blk, 0, st, g, dhalf, dt, zone_order());
-               else      hipLaunchKernelGGL((k_update<0, false>), grid, blk, 0, st, g, dhalf, dt, zone_order()); }
+  if (sc && cfl_part) {
+    if (nscal) { if (grav) hipLaunchKernelGGL((k_update<1, true, true>), grid, blk, 0, st, g, dhalf, dt, zone_order(), cfl_part, pinmask);
+                 else      hipLaunchKernelGGL((k_update<1, false, true>), grid, blk, 0, st, g, dhalf, dt, zone_order(), cfl_part, pinmask); }
+    else       { if (grav) hipLaunchKernelGGL((k_update<0, true, true>), grid, blk, 0, st, g, dhalf, dt, zone_order(), cfl_part, pinmask);
+                 else      hipLaunchKernelGGL((k_update<0, false, true>), grid, blk, 0, st, g, dhalf, dt, zone_order(), cfl_part, pinmask); }
+    unsigned nf = nblk(grid.x, 256*8); if (nf > 256) nf = 256;
+    hipLaunchKernelGGL(k_cfl_fold, dim3(nf), dim3(256), 0, st, cfl_part, (int)grid.x, sc);
+    return;
+  }
+  if (nscal) { if (grav) hipLaunchKernelGGL((k_update<1, true, false>), grid, blk, 0, st, g, dhalf, dt, zone_order(), nullptr, nullptr);
+               else      hipLaunchKernelGGL((k_update<1, false, false>), grid, blk, 0, st, g, dhalf, dt, zone_order(), nullptr, nullptr); }
+  else       { if (grav) hipLaunchKernelGGL((k_update<0, true, false>), grid, blk, 0, st, g, dhalf, dt, zone_order(), nullptr, nullptr);
+               else      hipLaunchKernelGGL((k_update<0, false, false>), grid, blk, 0, st, g, dhalf, dt, zone_order(), nullptr, nullptr); }
 }
 
 void launch_bc(const DevGrid &g, int nscal, int dir, int side, int flag, hipStream_t st)

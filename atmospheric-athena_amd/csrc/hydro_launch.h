@@ -10,7 +10,9 @@ void launch_sweep_correct_x1(const DevGrid &g, int nscal, Real dt, bool grav, hi
 // the three correct passes in one kernel; x3f: and the x3 first pass (then launch_sweep(.., 2, ..) is not needed)
 void launch_correct_all(const DevGrid &g, int nscal, Real dt, bool grav, bool x3f, hipStream_t st);
 void launch_flux2(const DevGrid &g, int nscal, int dir, hipStream_t st);
-void launch_update(const DevGrid &g, int nscal, const Real *dhalf, Real dt, bool grav, hipStream_t st);
+void launch_update(const DevGrid &g, int nscal, const Real *dhalf, Real dt, bool grav, hipStream_t st, DevScalars *sc = nullptr,
+                   Real *cfl_part = nullptr, const unsigned char *pinmask = nullptr);
+long update_blocks(const DevGrid &g);
 void launch_flux2_update(const DevGrid &g, int nscal, Real dt, bool grav, const KeepPlanes *keep, hipStream_t st,
                          DevScalars *sc = nullptr, const unsigned char *pinmask = nullptr);   // sc: also new_dt's maxima (k_flux2_update<CFL>)
 void launch_pinned_cfl(const DevGrid &g, long long n, const long long *idx, DevScalars *sc, hipStream_t st);

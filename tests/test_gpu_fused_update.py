@@ -129,20 +129,22 @@ def test_integrate_begin_changes_no_bit(problem, ov, strict, x3, monkeypatch):
     assert np.array_equal(out[0][0], out[1][0], equal_nan=True)
 
 
+@pytest.mark.parametrize("integrator", ["ctu", "vl"])
 @pytest.mark.parametrize("strict", [True, False])
 @pytest.mark.parametrize("problem,ov,nstep", [(c[0], c[1], 4) for c in CASES])
-def test_new_dt_maxima_from_the_update_kernel(problem, ov, nstep, strict, monkeypatch):
+def test_new_dt_maxima_from_the_update_kernel(problem, ov, nstep, strict, integrator, monkeypatch):
     """AA_CFL_FUSED: k_flux2_update leaves max(|v_d| + a) of the zones it has just updated behind (pinned zones excepted,
     which k_pinned_cfl adds after Userwork has overwritten them: ioniz_sphere's core), new_dt reads that instead of sweeping
     the Grid with k_cfl.  MAX of the same non-negative doubles: the dt sequence and the state are the same, bit for bit, in
-    BOTH builds (cfl_zone is compiled without multiply-add contraction everywhere: ADVICE r02)."""
+    BOTH builds (cfl_zone is compiled without multiply-add contraction everywhere: ADVICE r02).  The van Leer integrator's
+    k_update does the same (block maxima to a scratch array, folded by k_cfl_fold)."""
     aa = importlib.import_module("atmospheric-athena_amd")
     lib = importlib.import_module("atmospheric-athena_amd.lib")
     monkeypatch.setenv("AA_FUSED_UPDATE", "1")
     out = []
     for on in ("0", "2"):                       # 2: also in the strict build (which keeps k_cfl by default)
         monkeypatch.setenv("AA_CFL_FUSED", on)
-        run = aa.config.load(os.path.join(DECKS, "athinput." + problem), ov, problem)
+        run = aa.config.load(os.path.join(DECKS, "athinput." + problem), ov, problem, integrator)
         g = lib.setup_problem(aa.config.slab(run), 0, strict)
         g.start()
         its, dts = [], []
