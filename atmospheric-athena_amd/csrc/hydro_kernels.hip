@@ -1606,7 +1606,9 @@ k_vl_flux1(DevGrid g)
 // variants.  The lower x1 face takes its left state from the previous lane (shuffle), the lower x2 face
 // from the row below (loaded), the lower x3 face from the previous step (registers); the upper fluxes come
 // from the next lane / row / step.  Lane 63 and row VP_TJ-1 only provide fluxes.
+#ifndef VP_TJ
 #define VP_TJ 8
+#endif
 struct VlState { Real w[6], p[3], e[3]; };       // w: d, V1, V2, V3, (unused), r;  p, e per sweep frame
 template <int NS>
 AA_DEV void vl_state(const DevGrid &g, long m, VlState &q)
