@@ -127,7 +127,7 @@ int aa_step(aa_grid *g, int *niter);                /* one pass of main.c:519-66
  * for it; aa_integrate_3d_ctu then does the rest.  Same bits with or without; a no-op where the split does not apply. */
 int aa_integrate_begin(aa_grid *g);      /* (aa_upload_cons, aa_download_cons and aa_history between the two calls are allowed:
                                            * they stage through the face-state area and make the integrator redo these sweeps) */
-/* new_dt.c:72-140 inside the integrator: with on != 0 the caller promises that between aa_integrate_3d_ctu and the
+/* new_dt.c:72-140 inside the integrator: with on != 0 the caller promises that between aa_integrate_3d_ctu / _vl and the
  * next aa_new_dt_local / aa_cfl_max_v nothing but aa_apply_pinned_cells changes the active zones (the order of main.c:572-629
  * when Userwork_in_loop only pins zones); the update kernel then leaves max(|v_d| + a) behind while the new state is in
  * registers and new_dt reads it instead of sweeping the Grid again.  aa_step does this by itself.                     */
