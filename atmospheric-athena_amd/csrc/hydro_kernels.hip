@@ -300,8 +300,29 @@ AA_DEV bool decode_zone(const Order o, int ni, int nj, int nk, int &i, int &j, i
 #endif
 // (the pool puts zone i = 4 of every row on a 128-byte line when the pitch is a multiple of 16 doubles: api.hip)
 __host__ __device__ static inline int march_shift(const DevGrid &g) { return (g.sJ & 15) ? 0 : ((g.is - 2 + 12) & 15); }
+// SW_FOLD (experiment): the row of slots begins on the line of zone `is` instead; the two zones below it, is-2 and is-1, ride in the
+// row's last line, which has room (528 slots for the 517 zones of a 512^3 row instead of 544)
+#ifndef SW_FOLD
+#define SW_FOLD 0
+#endif
+__host__ __device__ static inline bool march_folded(const DevGrid &g) { return SW_FOLD && !(g.sJ & 15) && !((g.is + 12) & 15); }
 __host__ __device__ static inline int march_slots(const DevGrid &g)
-{ const int n = march_shift(g) + g.ie - g.is + 5; return (g.sJ & 15) ? n : ((n + 15) & ~15); }
+{
+  if (march_folded(g)) return (g.ie - g.is + 5 + 15) & ~15;
+  const int n = march_shift(g) + g.ie - g.is + 5; return (g.sJ & 15) ? n : ((n + 15) & ~15);
+}
+__host__ __device__ static inline bool march_cell(const DevGrid &g, int q, int &i)      // slot q of a row -> zone i (false: idle lane)
+{
+  if (march_folded(g)) {
+    const int nmain = g.ie - g.is + 3;                 // is .. ie+2
+    if (q < nmain) { i = g.is + q; return true; }
+    if (q < nmain + 2) { i = g.is - 2 + (q - nmain); return true; }
+    i = g.is; return false;
+  }
+  const int sh = march_shift(g);
+  i = g.is - 2 - sh + q;
+  return q >= sh && i <= g.ie + 2;
+}
 // The limited slopes along x2 / x3 as a march (SLOPES_MARCH, the default): k_slopes reads and converts three cells per zone, two of them
 // in other rows, which at 512^3 come back from HBM for blocks on other XCDs; here a thread owns an (i, transverse) column and a
 // chunk of cells along D with the three-cell window in registers (every cell read and converted once, lanes on whole 128-byte
@@ -315,14 +336,14 @@ __global__ void __launch_bounds__(64)
 k_slopes_march(DevGrid g, const Real *src, int chunk)
 {
   static_assert(D == 1 || D == 2, "march kernel is for the strided directions");
-  const int sh = march_shift(g), nq = march_slots(g);
+  const int nq = march_slots(g);
   const int nt = (D == 1 ? g.ke - g.ks : g.je - g.js) + 5;
   const long lin = (long)blockIdx.x*blockDim.x + threadIdx.x;
   if (lin >= (long)nq*nt) return;
   const int q = (int)(lin % nq);
-  const int i = g.is - 2 - sh + q;
+  int i;
   const int t = (D == 1 ? g.ks : g.js) - 2 + (int)(lin / nq);
-  if (q < sh || i > g.ie + 2) return;
+  if (!march_cell(g, q, i)) return;
   const int lo = (D == 1 ? g.js : g.ks) - 3, hi = (D == 1 ? g.je : g.ke) + 3;
   const int c0 = lo + blockIdx.y*chunk;
   int c1 = c0 + chunk - 1; if (c1 > hi) c1 = hi;
@@ -366,12 +387,12 @@ k_sweep_march(DevGrid g, const Real *src, Real dt, int chunk, int toff, int tcnt
 #if SW_ALIGN
   // lanes on whole 128-byte lines: a row of slots starts on the line that holds is-2 and is a whole number of lines long (a
   // wavefront's 64 lanes are four whole lines of one or two rows; the lanes off the ends of [is-2, ie+2] leave)
-  const int sh = march_shift(g), nq = march_slots(g);
+  const int nq = march_slots(g);
   if (lin >= (long)nq*nt) return;
   const int q = (int)(lin % nq);
-  const int i = g.is - 2 - sh + q;
+  int i;
   const int t = tlo + (int)(lin / nq);
-  if (q < sh || i > g.ie + 2) return;
+  if (!march_cell(g, q, i)) return;
 #else
   const int ni = g.ie - g.is + 5;                              // i in [is-2, ie+2]
   if (lin >= (long)ni*nt) return;
