@@ -530,6 +530,12 @@ k_sweep_tile(DevGrid g, const Real *src, Real dt)
 #ifndef SW_X1_FLAT
 #define SW_X1_FLAT 1
 #endif
+#ifndef X1_ALIGNED
+#define X1_ALIGNED 0
+#endif
+#ifndef SW_X1_LINES
+#define SW_X1_LINES 0
+#endif
 // The x1 sweep with the rows of a k-plane laid end to end (SW_X1_FLAT, the default): a plane's (je-js+5) rows of nc = ie-is+5
 // cells l..u are ONE line of slots, cut into blocks of B-1 faces wherever they fall, so that only the plane's last block has
 // idle lanes (a block per row piece left 576 lanes for 516 cells at 512^3, 128 for 68 at 64^3).  A row's first cell has no
@@ -589,6 +595,90 @@ k_sweep_x1_flat(DevGrid g, const Real *src, Real dt, int koff, unsigned nslots, 
   }
 }
 
+// The x1 sweep on whole lines (SW_X1_LINES): as k_sweep_x1_flat, but a row is a whole number of 128-byte lines of slots beginning on
+// the line that holds is-2 (544 slots for the 517 cells of a 512^3 row, like the march kernels) and a block is 256 slots = 16 lines,
+// so that no line of first-pass flux is written in parts by two blocks (on two XCDs): k_correct_all behind it reads those lines
+// (same-box A/B with a block-per-row-piece kernel whose stores were aligned: -0.8 ms there).  Blocks do not overlap: the left state
+// of a block's first face comes from a second turn of the ONE reconstruction instance by lane 0 (cell i-1, from two halo cells).
+// EXPERIMENT, off: the second turn holds the whole block at the barrier (x1 4.25 -> 5.07 ms, k_correct_all 18.76 -> 17.96: a draw);
+// with the second turn behind the barrier in one uniform two-turn loop the kernel took 7.3 ms (profiles/r03_ab_experiments.txt).
+// Idle slots at the row ends lend their LDS places to the rows' outside neighbours.
+template <int NS, bool GRAV, int MODE, int ORD>
+__global__ void __launch_bounds__(256, 4)
+k_sweep_x1_lines(DevGrid g, const Real *src, Real dt, int koff, unsigned nslots, unsigned nq, unsigned rmul, int rsh)
+{
+  extern __shared__ Real sm[];
+  const int B = blockDim.x, t = threadIdx.x;
+  const int PW = B + 3, PL = B + 1;                    // pitches: cells (2 halo in front, 1 behind), left states (1 in front)
+  Real *sw = sm, *sl = sm + (5 + NS)*PW;
+  const unsigned s = blockIdx.x*(unsigned)B + t;
+  const bool slot = (s < nslots);
+  const unsigned r = slot ? (unsigned)(((unsigned long long)s*rmul) >> rsh) : 0u;
+  const int q = slot ? (int)(s - r*nq) : 0;
+  const int i = g.is - 16 + q;
+  const int j = g.js - 2 + (int)r, k = g.ks - 2 + koff + blockIdx.y;
+  const long row = (long)k*g.sK + (long)j*g.sJ;
+  const Real dtodx = dt/g.dx[0];
+  const bool have = slot && i >= g.is - 2 && i <= g.ie + 2;
+  const bool face = have && i >= g.is - 1;
+  const bool lo_own = have && (t == 0 || i == g.is - 2);
+  const bool hi_own = have && (t == B - 1 || i == g.ie + 2);
+  const bool extra = face && t == 0;
+  Real u[6], w[6], ulo[6], uhi[6], ull[6];
+  if (have) load_sweep<0, NS>(src, g.nc, row + i, u);
+  if (lo_own) load_sweep<0, NS>(src, g.nc, row + i - 1, ulo);
+  if (hi_own) load_sweep<0, NS>(src, g.nc, row + i + 1, uhi);
+  if (extra) load_sweep<0, NS>(src, g.nc, row + i - 2, ull);
+  if (have) {
+    cons_to_prim<NS>(u, w, g.Gamma_1);
+#pragma unroll
+    for (int n = 0; n < 5 + NS; n++) sw[n*PW + t + 2] = w[n];
+  }
+  if (lo_own) {
+    cons_to_prim<NS>(ulo, w, g.Gamma_1);
+#pragma unroll
+    for (int n = 0; n < 5 + NS; n++) sw[n*PW + t + 1] = w[n];
+  }
+  if (hi_own) {
+    cons_to_prim<NS>(uhi, w, g.Gamma_1);
+#pragma unroll
+    for (int n = 0; n < 5 + NS; n++) sw[n*PW + t + 3] = w[n];
+  }
+  if (extra) {
+    cons_to_prim<NS>(ull, w, g.Gamma_1);
+#pragma unroll
+    for (int n = 0; n < 5 + NS; n++) sw[n*PW + 0] = w[n];
+  }
+  __syncthreads();
+  Real wr[6];
+#pragma unroll
+  for (int n = 0; n < 6; n++) wr[n] = 1.0;
+  if (have) {
+#pragma nounroll
+    for (int it = extra ? 0 : 1; it < 2; it++) {       // it == 0: lane 0 reconstructs the cell before the block
+      Real a[6], b[6], c[6], ol[6], orr[6];
+#pragma unroll
+      for (int n = 0; n < 5 + NS; n++) { a[n] = sw[n*PW + t + it]; b[n] = sw[n*PW + t + it + 1]; c[n] = sw[n*PW + t + it + 2]; }
+      if (!NS) { a[5] = 0.0; b[5] = 0.0; c[5] = 0.0; }
+      recon_cell<NS, MODE != MODE_VL, ORD, 0>(g, row + i - 1 + it, a, b, c, dtodx, ol, orr);
+#pragma unroll
+      for (int n = 0; n < 5 + NS; n++) sl[n*PL + t + it] = ol[n];
+      if (it == 1) {
+#pragma unroll
+        for (int n = 0; n < 6; n++) wr[n] = orr[n];
+      }
+    }
+  }
+  __syncthreads();
+  if (face) {                                          // interface i, between cells i-1 and i
+    Real wl[6];
+#pragma unroll
+    for (int n = 0; n < 5 + NS; n++) wl[n] = sl[n*PL + t];
+    if (!NS) wl[5] = 0.0;
+    face_work<NS, 0, GRAV, MODE>(g, row + i, i, j, k, dt, wl, wr);
+  }
+}
+
 template <int NS, bool GRAV, int MODE, int ORD>
 __global__ void __launch_bounds__(256, 4)
 k_sweep_x1(DevGrid g, const Real *src, Real dt, int koff)
@@ -596,7 +686,15 @@ k_sweep_x1(DevGrid g, const Real *src, Real dt, int koff)
   extern __shared__ Real sm[];
   const int B = blockDim.x, t = threadIdx.x;
   const int j = g.js - 2 + blockIdx.y, k = g.ks - 2 + koff + blockIdx.z;
+#if X1_ALIGNED
+  // experiment: a block's stored faces begin and end on 128-byte lines (zone is is line-aligned): block 0 holds cells is-2 .. is+239
+  // (faces is-1 .. is+239), block b >= 1 cells is-1+240b .. (faces is+240b .. is+240b+239); B = 256, 14 - 15 lanes of the last wave idle
+  const int c0 = blockIdx.x ? g.is - 1 + 240*(int)blockIdx.x : g.is - 2;
+  const int cend = g.is + 240*(int)blockIdx.x + 239;   // last face this block stores
+#else
   const int c0 = g.is - 2 + blockIdx.x*(B - 1);
+  const int cend = c0 + B - 1;
+#endif
   const int c = c0 + t;
   const long row = (long)k*g.sK + (long)j*g.sJ;
   const Real dtodx = dt/g.dx[0];
@@ -641,7 +739,7 @@ k_sweep_x1(DevGrid g, const Real *src, Real dt, int koff)
 #pragma unroll
   for (int n = 0; n < 5 + NS; n++) sm[n*P + t] = wl_next[n];
   __syncthreads();
-  if (t >= 1 && recon) {                               // interface c, between cells c-1 and c
+  if (t >= 1 && recon && c <= cend) {                  // interface c, between cells c-1 and c
     Real wl[6];
 #pragma unroll
     for (int n = 0; n < 5 + NS; n++) wl[n] = sm[n*P + t - 1];
@@ -2040,6 +2138,21 @@ static void sweep_impl_o(const DevGrid &g, const Real *src, int dir, Real dt, hi
   if (kcnt < 0) kcnt = nk_all - koff;
   if (kcnt <= 0) return;
   if (dir == 0) {
+#if SW_X1_LINES
+    static const int lines = getenv("AA_X1_LINES") ? atoi(getenv("AA_X1_LINES")) : 1;
+    if (lines && !(g.sJ & 15) && g.is == 4) {
+      const long nq = ((long)(g.ie + 2 - (g.is - 16) + 1) + 15) & ~15L, nsl = nq*(g.je - g.js + 5);
+      if (nsl < (1L << 30)) {
+        int rsh = 31; while ((2L << (rsh - 31)) <= nq) rsh++;
+        const unsigned long long rmul = ((1ULL << rsh) + nq - 1)/nq;
+        dim3 gl((unsigned)((nsl + 255)/256), kcnt);
+        const size_t lds = (size_t)(5 + NS)*(256 + 3 + 256 + 1)*sizeof(Real);
+        hipLaunchKernelGGL((k_sweep_x1_lines<NS, GRAV, MODE, ORD>), gl, dim3(256), lds, st, g, src, dt, koff, (unsigned)nsl, (unsigned)nq,
+                           (unsigned)rmul, rsh);
+        return;
+      }
+    }
+#endif
 #if SW_X1_FLAT
     static const int flat = getenv("AA_X1_FLAT") ? atoi(getenv("AA_X1_FLAT")) : 1;
     const long nc = g.ie - g.is + 5, nslots = nc*(g.je - g.js + 5);
@@ -2059,6 +2172,9 @@ static void sweep_impl_o(const DevGrid &g, const Real *src, int dir, Real dt, hi
     int B = (nfaces + nb - 1)/nb + 1;                  // B-1 interfaces per block
     B = ((B + 63)/64)*64; if (B > 256) B = 256;
     nb = (nfaces + (B - 1) - 1)/(B - 1);
+#if X1_ALIGNED
+    B = 256; nb = (g.ie + 2 - g.is + 240)/240;        // faces is-1 .. ie+2, block b ends with face is + 240 b + 239
+#endif
     dim3 grid(nb, g.je - g.js + 5, kcnt);
     size_t lds = (size_t)(5 + NS)*(B + 2)*sizeof(Real);
     hipLaunchKernelGGL((k_sweep_x1<NS, GRAV, MODE, ORD>), grid, dim3(B), lds, st, g, src, dt, koff);
