@@ -84,8 +84,17 @@ int aa_create(const aa_params *p, aa_grid **out)
   HIPCHK(hipSetDevice(p->device));
   aa_grid *g = new aa_grid();
   g->p = *p;
-  DevGrid &d = g->d;
-  memset(&d, 0, sizeof d);
+  HostGrid &d = g->d;
+  d = HostGrid();
+  {   // the launch choices of this Grid (grid.h LaunchCfg): read here, once per Grid, never again
+    LaunchCfg &c = d.cfg;
+    auto env = [](const char *name, int dflt) { const char *e = getenv(name); return e ? atoi(e) : dflt; };
+    c.strip = env("AA_STRIP", 64); c.xcd = env("AA_XCD", 1);
+    c.x1_flat = env("AA_X1_FLAT", 1); c.slopes_march = env("AA_SLOPES_MARCH", 1);
+    c.ca_kc = env("AA_CA_KC", 0); c.fu_kc = env("AA_FU_KC", 0);
+    c.ion_pass_cap = env("AA_ION_PASS_BLOCKS", 4096); if (c.ion_pass_cap < 1) c.ion_pass_cap = 1;
+    c.pitch_align = env("AA_PITCH_ALIGN", 1);
+  }
   d.Nx1 = p->Nx[0]; d.Nx2 = p->Nx[1]; d.Nx3 = p->Nx[2];
   d.N1 = d.Nx1 + 2*AA_NGHOST; d.N2 = d.Nx2 + 2*AA_NGHOST; d.N3 = d.Nx3 + 2*AA_NGHOST;
   d.is = d.js = d.ks = AA_NGHOST;
@@ -93,8 +102,7 @@ int aa_create(const aa_params *p, aa_grid **out)
   // rows padded to a multiple of 16 doubles and every field shifted by 12 doubles: the first active zone of
   // every row (i = 4) then sits on a 128-byte line, and so does every wavefront of the kernels that walk the
   // active zones 64 at a time (-2.9 % of a 512^3 step; AA_PITCH_ALIGN=0: dense rows)
-  static int pitch_align = -1;
-  if (pitch_align < 0) { const char *e = getenv("AA_PITCH_ALIGN"); pitch_align = e ? atoi(e) : 1; }
+  const int pitch_align = d.cfg.pitch_align;
   d.sJ = pitch_align ? ((d.N1 + 15)/16)*16 : d.N1; d.sK = (long)d.sJ*d.N2; d.nc = d.sK*d.N3;
   if (p->level < 0 || p->level > 7) { delete g; return fail(-1, "[aa_create]: level %d out of range", p->level); }
   g->level = p->level;
@@ -517,7 +525,7 @@ static bool x3_fused(const aa_grid *g)      // default: always (round 3; until t
 int aa_integrate_begin(aa_grid *g)
 {
   if (!g->slab.empty() || g->p.integrator != 0 || g->d.slope || !g->correct_all || !g->fused_update || g->inner_swept) return 0;
-  const DevGrid &d = g->d; const int ns = g->p.nscal; const Real dt = g->dt;
+  const HostGrid &d = g->d; const int ns = g->p.nscal; const Real dt = g->dt;
   const int nk = d.ke - d.ks + 1;
   { Scope s(g, "sweep_x2"); HL(launch_sweep)(d, ns, 1, dt, g->grav, g->st, 2, nk); }
   { Scope s(g, "sweep_x1"); HL(launch_sweep)(d, ns, 0, dt, g->grav, g->st, 2, nk); }
@@ -542,7 +550,7 @@ int aa_integrate_3d_ctu(aa_grid *g)
 {
   if (!g->slab.empty()) return slabs_integrate(g, 0);
   g->cfl_ready = false;
-  const DevGrid &d = g->d; const int ns = g->p.nscal; const Real dt = g->dt;
+  const HostGrid &d = g->d; const int ns = g->p.nscal; const Real dt = g->dt;
   if (g->inner_swept) {      // aa_integrate_begin did the planes ks .. ke: the two ghost planes either side remain
     if (g->inner_dt != dt) return fail(-1, "[aa_integrate_3d_ctu]: dt changed after aa_integrate_begin");
     g->inner_swept = false;
@@ -591,7 +599,7 @@ int aa_integrate_3d_vl(aa_grid *g)
   if (!g->slab.empty()) return slabs_integrate(g, 1);
   g->cfl_ready = false;
   // integrate_3d_vl.c:96-: donor-cell fluxes -> U^{n+1/2} -> PLM or PPM (no tracing) + Roe -> update
-  const DevGrid &d = g->d; const int ns = g->p.nscal; const Real dt = g->dt;
+  const HostGrid &d = g->d; const int ns = g->p.nscal; const Real dt = g->dt;
   // donor-cell fluxes + U^{n+1/2} in one marching kernel from 2^18 zones (512^3: 16.8 -> 9.7 ms; same at 80^3;
   // 10 % slower at 32^3); AA_VL_PREDICT forces either, the results are the same bit for bit
   if (g->vl_predict) { Scope s(g, "vl_predict"); launch_vl_predict(d, ns, dt, g->grav, g->st); }

@@ -17,7 +17,7 @@ struct ProfEntry { std::string name; std::vector<hipEvent_t> ev; double total_ms
 
 struct aa_grid {
   aa_params p;
-  aa::DevGrid d;
+  aa::HostGrid d;
   aa::IonPar ion;
   hipStream_t st = nullptr; bool own_stream = false;
   aa::Real *pool = nullptr; size_t pool_doubles = 0;

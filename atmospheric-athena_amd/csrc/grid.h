@@ -91,6 +91,21 @@ struct IonPart { Real dt_chem, dt_therm, max_dti, cellcount, neg; };
 #define AA_ION_WORDS 8               /* doubles per rank in the sub-cycle's reduction (5 used) */
 #endif
 
+// Host-side launch choices of ONE Grid: read from the environment by aa_create and kept with the Grid, so that no later change of
+// the environment (a test's monkeypatch, a second Grid of another caller) can reach a Grid that already exists and no Grid depends
+// on what an earlier one found there.  Every choice changes the launch geometry only; the results are the same bit for bit in the
+// strict build (tests/test_gpu_layout_switches.py).
+struct LaunchCfg {
+  int strip = 64, xcd = 1;   // AA_STRIP / AA_XCD: zone order of the unfused stencil kernels (k_flux2, k_update)
+  int x1_flat = 1;           // AA_X1_FLAT=0: the x1 first-pass sweep with a block per piece of a row
+  int slopes_march = 1;      // AA_SLOPES_MARCH=0: the PPM slope arrays along x2 / x3 one zone per thread
+  int ca_kc = 0, fu_kc = 0;  // AA_CA_KC / AA_FU_KC: planes per block of k_correct_all / k_flux2_update (0: by size)
+  int ion_pass_cap = 4096;   // AA_ION_PASS_BLOCKS: most blocks of a k_ion_pass launch
+  int pitch_align = 1;       // AA_PITCH_ALIGN=0: dense device rows
+};
+// the descriptor as the host keeps it: what the kernels get (DevGrid, passed by value: the launch slices it off) + the launch choices
+struct HostGrid : DevGrid { LaunchCfg cfg; };
+
 // face planes (index along the normal, incl. ghost offset) whose second-pass fluxes the fused kernel also
 // stores: the level boundaries static mesh refinement reads back (smr.hip)
 struct KeepPlanes { int n; int p[3][8]; };       // own two boundary planes + the outlines of up to three children (unused slots repeat the first)
@@ -115,11 +130,11 @@ void launch_ray_sweep_x2(const DevGrid &g, const IonPar &p, Real flux_i, hipStre
 void launch_edgeflux_bc_x2(const DevGrid &g, Real flux_i, hipStream_t st);
 
 // ---- launch wrappers (ion_pass.hip): the one-kernel radiation sub-cycle ------------------
-int  ion_pass_blocks(const DevGrid &g);                       // launch size = number of IonPart records
+int  ion_pass_blocks(const HostGrid &g);                       // launch size = number of IonPart records
 void launch_ion_begin16(const DevGrid &g, const IonPar &p, hipStream_t st);
 // [entry of the ion step: floors, save_energy_and_x, if `begin`;] update(n-1) with sc->dt_sel, then sweep(n) + rates(n)
 // into buffer cur^1; folds the records into `words`
-void launch_ion_pass(const DevGrid &g, const IonPar &p, bool update, bool sweep, bool begin, Real flux0, bool from_edgeflux,
+void launch_ion_pass(const HostGrid &g, const IonPar &p, bool update, bool sweep, bool begin, Real flux0, bool from_edgeflux,
                      const DevScalars *sc, int cur, IonPart *part, Real *words, hipStream_t st, Real spec_dt = -1.0);
 void launch_ion_pick2(const Real *words, int nranks, DevScalars *sc, int first, Real dt_limit, hipStream_t st, int spec_armed = 0);
 void launch_ion_finish(const DevGrid &g, int cur, hipStream_t st);

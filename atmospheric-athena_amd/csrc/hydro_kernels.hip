@@ -300,25 +300,12 @@ AA_DEV bool decode_zone(const Order o, int ni, int nj, int nk, int &i, int &j, i
 #endif
 // (the pool puts zone i = 4 of every row on a 128-byte line when the pitch is a multiple of 16 doubles: api.hip)
 __host__ __device__ static inline int march_shift(const DevGrid &g) { return (g.sJ & 15) ? 0 : ((g.is - 2 + 12) & 15); }
-// SW_FOLD (experiment): the row of slots begins on the line of zone `is` instead; the two zones below it, is-2 and is-1, ride in the
-// row's last line, which has room (528 slots for the 517 zones of a 512^3 row instead of 544)
-#ifndef SW_FOLD
-#define SW_FOLD 0
-#endif
-__host__ __device__ static inline bool march_folded(const DevGrid &g) { return SW_FOLD && !(g.sJ & 15) && !((g.is + 12) & 15); }
 __host__ __device__ static inline int march_slots(const DevGrid &g)
 {
-  if (march_folded(g)) return (g.ie - g.is + 5 + 15) & ~15;
   const int n = march_shift(g) + g.ie - g.is + 5; return (g.sJ & 15) ? n : ((n + 15) & ~15);
 }
 __host__ __device__ static inline bool march_cell(const DevGrid &g, int q, int &i)      // slot q of a row -> zone i (false: idle lane)
 {
-  if (march_folded(g)) {
-    const int nmain = g.ie - g.is + 3;                 // is .. ie+2
-    if (q < nmain) { i = g.is + q; return true; }
-    if (q < nmain + 2) { i = g.is - 2 + (q - nmain); return true; }
-    i = g.is; return false;
-  }
   const int sh = march_shift(g);
   i = g.is - 2 - sh + q;
   return q >= sh && i <= g.ie + 2;
@@ -368,14 +355,11 @@ k_slopes_march(DevGrid g, const Real *src, int chunk)
   }
 }
 
-#ifndef SW_PARK
-#define SW_PARK 0          /* experiment: 1 = the carried left state, 2 = also the window's two upper cells, parked in LDS over the face's work */
-#endif
 #ifndef SW_OCC
 #define SW_OCC 3
 #endif
 template <int NS, int D, bool GRAV, int MODE, int ORD>
-__global__ void __launch_bounds__(SW_PARK ? 64 : 256, SW_OCC)      // 3 waves per SIMD (168 VGPRs): the kernel is VALU-bound and sits right at that edge
+__global__ void __launch_bounds__(256, SW_OCC)      // 3 waves per SIMD (168 VGPRs): the kernel is VALU-bound and sits right at that edge
 k_sweep_march(DevGrid g, const Real *src, Real dt, int chunk, int toff, int tcnt)
 {
   static_assert(D == 1 || D == 2, "march kernel is for the strided directions");
@@ -412,12 +396,6 @@ k_sweep_march(DevGrid g, const Real *src, Real dt, int chunk, int toff, int tcnt
   // instances may round differently, and the result must not depend on where the chunks start (the
   // chunk size follows the Grid size, hence the decomposition).
   Real wm[6], w[6], wp[6], wl_cur[6], wl_next[6], wr[6], u[6];
-#if SW_PARK
-  __shared__ Real s_pk[SW_PARK == 2 ? 18 : 6][64];
-  const int ln = threadIdx.x;
-#pragma unroll
-  for (int n = 0; n < 6; n++) s_pk[n][ln] = 0.0;
-#endif
   load_sweep<D, NS>(src, g.nc, base + (long)(f0 - 2)*s, u); cons_to_prim<NS>(u, w,  g.Gamma_1);
   load_sweep<D, NS>(src, g.nc, base + (long)(f0 - 1)*s, u); cons_to_prim<NS>(u, wp, g.Gamma_1);
 #pragma unroll
@@ -430,25 +408,9 @@ k_sweep_march(DevGrid g, const Real *src, Real dt, int chunk, int toff, int tcnt
     for (int n = 0; n < 6; n++) { wm[n] = w[n]; w[n] = wp[n]; }
     load_sweep<D, NS>(src, g.nc, mf + s, u); cons_to_prim<NS>(u, wp, g.Gamma_1);
     recon_cell<NS, MODE != MODE_VL, ORD, D>(g, mf, wm, w, wp, dtodx, wl_next, wr);  // cell f -> Wl[f+1], Wr[f]
-#if SW_PARK
-    asm volatile("" ::: "memory");
-#pragma unroll
-    for (int n = 0; n < 6; n++) { wl_cur[n] = s_pk[n][ln]; s_pk[n][ln] = wl_next[n]; }
-#if SW_PARK == 2
-#pragma unroll
-    for (int n = 0; n < 6; n++) { s_pk[6 + n][ln] = w[n]; s_pk[12 + n][ln] = wp[n]; }
-#endif
-    asm volatile("" ::: "memory");
-#endif
     if (f >= f0) face_work<NS, D, GRAV, MODE>(g, mf, i, D == 1 ? f : t, D == 1 ? t : f, dt, wl_cur, wr);
-#if SW_PARK == 2
-    asm volatile("" ::: "memory");
-#pragma unroll
-    for (int n = 0; n < 6; n++) { w[n] = s_pk[6 + n][ln]; wp[n] = s_pk[12 + n][ln]; }
-#elif !SW_PARK
 #pragma unroll
     for (int n = 0; n < 6; n++) wl_cur[n] = wl_next[n];
-#endif
   }
 }
 
@@ -530,12 +492,6 @@ k_sweep_tile(DevGrid g, const Real *src, Real dt)
 #ifndef SW_X1_FLAT
 #define SW_X1_FLAT 1
 #endif
-#ifndef X1_ALIGNED
-#define X1_ALIGNED 0
-#endif
-#ifndef SW_X1_LINES
-#define SW_X1_LINES 0
-#endif
 // The x1 sweep with the rows of a k-plane laid end to end (SW_X1_FLAT, the default): a plane's (je-js+5) rows of nc = ie-is+5
 // cells l..u are ONE line of slots, cut into blocks of B-1 faces wherever they fall, so that only the plane's last block has
 // idle lanes (a block per row piece left 576 lanes for 516 cells at 512^3, 128 for 68 at 64^3).  A row's first cell has no
@@ -595,90 +551,6 @@ k_sweep_x1_flat(DevGrid g, const Real *src, Real dt, int koff, unsigned nslots, 
   }
 }
 
-// The x1 sweep on whole lines (SW_X1_LINES): as k_sweep_x1_flat, but a row is a whole number of 128-byte lines of slots beginning on
-// the line that holds is-2 (544 slots for the 517 cells of a 512^3 row, like the march kernels) and a block is 256 slots = 16 lines,
-// so that no line of first-pass flux is written in parts by two blocks (on two XCDs): k_correct_all behind it reads those lines
-// (same-box A/B with a block-per-row-piece kernel whose stores were aligned: -0.8 ms there).  Blocks do not overlap: the left state
-// of a block's first face comes from a second turn of the ONE reconstruction instance by lane 0 (cell i-1, from two halo cells).
-// EXPERIMENT, off: the second turn holds the whole block at the barrier (x1 4.25 -> 5.07 ms, k_correct_all 18.76 -> 17.96: a draw);
-// with the second turn behind the barrier in one uniform two-turn loop the kernel took 7.3 ms (profiles/r03_ab_experiments.txt).
-// Idle slots at the row ends lend their LDS places to the rows' outside neighbours.
-template <int NS, bool GRAV, int MODE, int ORD>
-__global__ void __launch_bounds__(256, 4)
-k_sweep_x1_lines(DevGrid g, const Real *src, Real dt, int koff, unsigned nslots, unsigned nq, unsigned rmul, int rsh)
-{
-  extern __shared__ Real sm[];
-  const int B = blockDim.x, t = threadIdx.x;
-  const int PW = B + 3, PL = B + 1;                    // pitches: cells (2 halo in front, 1 behind), left states (1 in front)
-  Real *sw = sm, *sl = sm + (5 + NS)*PW;
-  const unsigned s = blockIdx.x*(unsigned)B + t;
-  const bool slot = (s < nslots);
-  const unsigned r = slot ? (unsigned)(((unsigned long long)s*rmul) >> rsh) : 0u;
-  const int q = slot ? (int)(s - r*nq) : 0;
-  const int i = g.is - 16 + q;
-  const int j = g.js - 2 + (int)r, k = g.ks - 2 + koff + blockIdx.y;
-  const long row = (long)k*g.sK + (long)j*g.sJ;
-  const Real dtodx = dt/g.dx[0];
-  const bool have = slot && i >= g.is - 2 && i <= g.ie + 2;
-  const bool face = have && i >= g.is - 1;
-  const bool lo_own = have && (t == 0 || i == g.is - 2);
-  const bool hi_own = have && (t == B - 1 || i == g.ie + 2);
-  const bool extra = face && t == 0;
-  Real u[6], w[6], ulo[6], uhi[6], ull[6];
-  if (have) load_sweep<0, NS>(src, g.nc, row + i, u);
-  if (lo_own) load_sweep<0, NS>(src, g.nc, row + i - 1, ulo);
-  if (hi_own) load_sweep<0, NS>(src, g.nc, row + i + 1, uhi);
-  if (extra) load_sweep<0, NS>(src, g.nc, row + i - 2, ull);
-  if (have) {
-    cons_to_prim<NS>(u, w, g.Gamma_1);
-#pragma unroll
-    for (int n = 0; n < 5 + NS; n++) sw[n*PW + t + 2] = w[n];
-  }
-  if (lo_own) {
-    cons_to_prim<NS>(ulo, w, g.Gamma_1);
-#pragma unroll
-    for (int n = 0; n < 5 + NS; n++) sw[n*PW + t + 1] = w[n];
-  }
-  if (hi_own) {
-    cons_to_prim<NS>(uhi, w, g.Gamma_1);
-#pragma unroll
-    for (int n = 0; n < 5 + NS; n++) sw[n*PW + t + 3] = w[n];
-  }
-  if (extra) {
-    cons_to_prim<NS>(ull, w, g.Gamma_1);
-#pragma unroll
-    for (int n = 0; n < 5 + NS; n++) sw[n*PW + 0] = w[n];
-  }
-  __syncthreads();
-  Real wr[6];
-#pragma unroll
-  for (int n = 0; n < 6; n++) wr[n] = 1.0;
-  if (have) {
-#pragma nounroll
-    for (int it = extra ? 0 : 1; it < 2; it++) {       // it == 0: lane 0 reconstructs the cell before the block
-      Real a[6], b[6], c[6], ol[6], orr[6];
-#pragma unroll
-      for (int n = 0; n < 5 + NS; n++) { a[n] = sw[n*PW + t + it]; b[n] = sw[n*PW + t + it + 1]; c[n] = sw[n*PW + t + it + 2]; }
-      if (!NS) { a[5] = 0.0; b[5] = 0.0; c[5] = 0.0; }
-      recon_cell<NS, MODE != MODE_VL, ORD, 0>(g, row + i - 1 + it, a, b, c, dtodx, ol, orr);
-#pragma unroll
-      for (int n = 0; n < 5 + NS; n++) sl[n*PL + t + it] = ol[n];
-      if (it == 1) {
-#pragma unroll
-        for (int n = 0; n < 6; n++) wr[n] = orr[n];
-      }
-    }
-  }
-  __syncthreads();
-  if (face) {                                          // interface i, between cells i-1 and i
-    Real wl[6];
-#pragma unroll
-    for (int n = 0; n < 5 + NS; n++) wl[n] = sl[n*PL + t];
-    if (!NS) wl[5] = 0.0;
-    face_work<NS, 0, GRAV, MODE>(g, row + i, i, j, k, dt, wl, wr);
-  }
-}
-
 template <int NS, bool GRAV, int MODE, int ORD>
 __global__ void __launch_bounds__(256, 4)
 k_sweep_x1(DevGrid g, const Real *src, Real dt, int koff)
@@ -686,15 +558,8 @@ k_sweep_x1(DevGrid g, const Real *src, Real dt, int koff)
   extern __shared__ Real sm[];
   const int B = blockDim.x, t = threadIdx.x;
   const int j = g.js - 2 + blockIdx.y, k = g.ks - 2 + koff + blockIdx.z;
-#if X1_ALIGNED
-  // experiment: a block's stored faces begin and end on 128-byte lines (zone is is line-aligned): block 0 holds cells is-2 .. is+239
-  // (faces is-1 .. is+239), block b >= 1 cells is-1+240b .. (faces is+240b .. is+240b+239); B = 256, 14 - 15 lanes of the last wave idle
-  const int c0 = blockIdx.x ? g.is - 1 + 240*(int)blockIdx.x : g.is - 2;
-  const int cend = g.is + 240*(int)blockIdx.x + 239;   // last face this block stores
-#else
   const int c0 = g.is - 2 + blockIdx.x*(B - 1);
   const int cend = c0 + B - 1;
-#endif
   const int c = c0 + t;
   const long row = (long)k*g.sK + (long)j*g.sJ;
   const Real dtodx = dt/g.dx[0];
@@ -893,11 +758,8 @@ AA_DEV void cell_states(const DevGrid &g, long m, Real dt, const Real q[3], cons
 #ifndef CA_PARK
 #define CA_PARK 1
 #endif
-#ifndef CA_LB2SEL
-#define CA_LB2SEL 1
-#endif
 template <int NS, bool GRAV, int ORD, bool X3F>
-__global__ void __launch_bounds__(64*CA_TJ, (CA_LB2SEL == 2 || (CA_LB2SEL == 1 && X3F && NS && GRAV)) ? 2 : 1)
+__global__ void __launch_bounds__(64*CA_TJ, (X3F && NS && GRAV) ? 2 : 1)
 k_correct_all(DevGrid g, Real dt, int kchunk)
 {
   __shared__ Real s_w[CA_TJ][6][64];
@@ -1321,9 +1183,6 @@ k_cfl_fold(const Real *part, int nb, DevScalars *sc)
 #endif
 // operands of one second-pass Riemann problem: the corrected face states (sweep frame) and the 9 etas
 struct FaceIn { Real ul[6], ur[6], eta[9]; };
-#ifndef FU_ABL
-#define FU_ABL 0          // timing experiments only (profiles/r03_ab_experiments.txt; wrong results): 1 = the update's operands not loaded and U not stored, 2 = only the face's own eta loaded
-#endif
 template <int NS, int D>
 AA_DEV void face_load(const DevGrid &g, long m, FaceIn &in)
 {
@@ -1332,13 +1191,8 @@ AA_DEV void face_load(const DevGrid &g, long m, FaceIn &in)
   const long s1 = stride<E1>(g), s2 = stride<E2>(g);
   const Real *e1 = Ef(g, E1), *e2 = Ef(g, E2);
   in.eta[8] = Ef(g, D)[m];
-  if (FU_ABL & 2) {
-#pragma unroll
-    for (int n = 0; n < 8; n++) in.eta[n] = in.eta[8];
-  } else {
   in.eta[0] = e1[ml]; in.eta[1] = e1[m]; in.eta[2] = e1[ml + s1]; in.eta[3] = e1[m + s1];
   in.eta[4] = e2[ml]; in.eta[5] = e2[m]; in.eta[6] = e2[ml + s2]; in.eta[7] = e2[m + s2];
-  }
   load_sweep<D, NS>(LRf(g, D, 0, 0), g.nc, m, in.ul);
   load_sweep<D, NS>(LRf(g, D, 1, 0), g.nc, m, in.ur);
 }
@@ -1386,26 +1240,6 @@ AA_DEV bool on_plane(const KeepPlanes &kp, int d, int x)
          x == kp.p[d][4] || x == kp.p[d][5] || x == kp.p[d][6] || x == kp.p[d][7];
 }
 
-// ---- experiment FU_DMA (off): the update's operands by LDS-DMA -------------------------------------------------------
-// VERDICT r02's proposal taken literally for the one place in k_flux2_update where a load is consumed at once: the zone's own
-// U, the potential values and d^{n+1/2} of the update.  One global_load_lds_dwordx4 moves 64 x 16 bytes = two 512-byte rows
-// (lanes 0..31 the first field, 32..63 the second) into the wavefront's own LDS rows without a register; issued right behind
-// the wait for the x1 face's operands, they land during the x1 solve and are covered by the compiler's own wait for the x2
-// face's operands (loads retire in order), so no s_waitcnt of ours is needed and none of the compiler's is lengthened.
-#ifndef FU_DMA
-#define FU_DMA 0
-#endif
-// lds_dst: wave-uniform byte address; lane L's 16 bytes come from base + off (its own 32-bit byte offset) and land at lds_dst + 16 L.
-// Scalar base + one offset register for all requests of an iteration: per-lane 64-bit addresses (seven pairs at the kernel's register
-// peak) cost 18 spilled registers in the first form of this experiment (18.95 ms).
-AA_DEV void dma16(const Real *base, unsigned off, unsigned lds_dst)
-{
-  unsigned keep;
-  const unsigned long long b = (unsigned long long)base;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
-               : "=&s"(keep) : "v"(off), "s"(b), "s"(lds_dst) : "memory");
-}
-
 // CFL: the zone's contribution to new_dt's maxima is taken from the updated state while it is in registers (k_cfl would
 // read the five fields again: 0.9 ms at 512^3); zones marked in `pinmask` are left out, the caller adds them after it
 // has overwritten them (k_pinned_cfl).
@@ -1417,7 +1251,6 @@ k_flux2_update(DevGrid g, const Real *dhalf, Real dt, int kchunk, KeepPlanes kp,
   //  next plane's writers off this plane's readers -- 8 wavefronts, a whole CU, wait at every barrier of this block)
   __shared__ Real s_f2[2][FU_TJ][6][64];
   __shared__ Real s_f1e[2][FU_TJ - 1][6], s_f1s[2][FU_TJ - 1][6];
-  constexpr bool DMA = (FU_DMA != 0) && NS && GRAV;
 #ifndef FU_PARK
 #define FU_PARK 1
 #endif
@@ -1427,7 +1260,6 @@ k_flux2_update(DevGrid g, const Real *dhalf, Real dt, int kchunk, KeepPlanes kp,
   // parked alone 13.70).  FU_PARK=0 / FU_XD=0: the round's earlier form.
   constexpr bool FPARK = (FU_PARK != 0);
   __shared__ Real s_f3[FPARK ? 6 : 1][FPARK ? FU_TJ : 1][64];
-  __shared__ Real s_dma[DMA ? FU_TJ - 1 : 1][DMA ? 14 : 1][64];      // rows: U0..U5, phi_c, phi_1, phi_2, phi_3, phi_2(j+1), phi_3(k+1), d^{n+1/2} (twice)
   const int lane = threadIdx.x, row = threadIdx.y;
   // Tiles of 64 x (FU_TJ - 1) zones; the rows start on a 128-byte line (zone is) and do not overlap in x1: with a stride
   // of 63 zones every 512-byte row request touched a fifth line and 512 zones took 9 tiles (rocprofv3: 559 B/zone fetched
@@ -1450,10 +1282,6 @@ k_flux2_update(DevGrid g, const Real *dhalf, Real dt, int kchunk, KeepPlanes kp,
   const long mcol = (long)jc*g.sJ + ic;
   // where this thread's x1 face is, relative to its zone: 0, or for the edge wavefront the hop to (i0 + 64, j0 + lane)
   const long m1off = edge ? ((long)(j0 + lane)*g.sJ + (i0 + 64)) - mcol : 0L;
-  // DMA: whole 64-zone rows, so only tiles that lie inside the row of the Grid (block-uniform), and only the wavefronts that own zones
-  const int wave = __builtin_amdgcn_readfirstlane(row);
-  const bool dma_go = DMA && (i0 + 63 <= g.ie + 1) && (wave < FU_TJ - 1);
-  const unsigned dma_base = DMA ? (unsigned)(size_t)&s_dma[DMA ? wave : 0][0][0] : 0u;
   Real dtodx[3];
 #pragma unroll
   for (int d = 0; d < 3; d++) dtodx[d] = dt/g.dx[d];
@@ -1490,41 +1318,11 @@ k_flux2_update(DevGrid g, const Real *dhalf, Real dt, int kchunk, KeepPlanes kp,
     asm volatile("" : "+v"(m));
     const int pb = k & 1;
     if (need2) face_load<NS, 1>(g, m, in2);
-    // DMA: what is left of the update's loads travels with the x2 face's operands (lane 63's upper x1-face potential: the
-    // next tile's first value, outside the wavefront's row; the pin-mask byte)
-    Real p1e = 0.0; unsigned char pin_early = 0;
-    if (DMA && cell) { if (lane == 63) p1e = Pf(g, 1)[m + 1]; if (CFL && pinmask) pin_early = pinmask[m]; }
     __builtin_amdgcn_sched_barrier(0);
     {
       Real f[6];
 #pragma unroll
       for (int n = 0; n < 6; n++) f[n] = 0.0;
-      if (DMA) {
-        // the x1 face's operands named as inputs of an empty statement: the compiler's wait for them sits HERE, in front of the
-        // DMA requests, and counts exactly what it issued itself (a statement of ours in front of that wait would make it drain
-        // the stores of the previous plane: loads and stores retire through one in-order counter)
-        if (need1) {
-          asm volatile("" :: "v"(in1.ul[0]), "v"(in1.ul[1]), "v"(in1.ul[2]), "v"(in1.ul[3]), "v"(in1.ul[4]), "v"(in1.ul[5]),
-                             "v"(in1.ur[0]), "v"(in1.ur[1]), "v"(in1.ur[2]), "v"(in1.ur[3]), "v"(in1.ur[4]), "v"(in1.ur[5]));
-          asm volatile("" :: "v"(in1.eta[0]), "v"(in1.eta[1]), "v"(in1.eta[2]), "v"(in1.eta[3]), "v"(in1.eta[4]), "v"(in1.eta[5]),
-                             "v"(in1.eta[6]), "v"(in1.eta[7]), "v"(in1.eta[8]));
-        }
-        if (dma_go) {
-          // rows in LDS: U0..U5, phi_c, phi_1, phi_2, phi_3, phi_2(j+1), phi_3(k+1), d^{n+1/2} (twice); the fields of a pair are
-          // nc doubles apart, so the upper half of the lanes adds that to the one offset
-          const bool hi = lane >= 32;
-          const unsigned mr8 = (unsigned)((m - lane + 2*(lane & 31))*8);
-          const unsigned nc8 = (unsigned)(g.nc*8);
-          const unsigned off = mr8 + (hi ? nc8 : 0u);
-          dma16(Uf(g, 0), off, dma_base);
-          dma16(Uf(g, 2), off, dma_base + 1024u);
-          dma16(Uf(g, 4), off, dma_base + 2048u);
-          dma16(Pf(g, 0), off, dma_base + 3072u);
-          dma16(Pf(g, 2), off, dma_base + 4096u);
-          dma16(Pf(g, 2), mr8 + (hi ? nc8 + (unsigned)(g.sK*8) : (unsigned)(g.sJ*8)), dma_base + 5120u);
-          dma16(dhalf, mr8, dma_base + 6144u);
-        }
-      }
       if (need1) face_solve<NS>(g, in1, f);
       if (keep1) store_sweep<0, NS>(Ff(g, 0, 0), g.nc, m + m1off, f);
 #pragma unroll
@@ -1580,33 +1378,13 @@ k_flux2_update(DevGrid g, const Real *dhalf, Real dt, int kchunk, KeepPlanes kp,
 #pragma unroll
       for (int n = 0; n < NV; n++) { if (FPARK) s_f3[FPARK ? n : 0][FPARK ? row : 0][lane] = f3[n]; else f3lo[n] = f3[n]; }
       Real u[6];
-      constexpr bool from_lds = DMA;       // (the experiment build takes Grids whose rows are whole tiles only: Nx1 a multiple of 64)
-      if (from_lds) {
 #pragma unroll
-        for (int v = 0; v < NV; v++) u[v] = s_dma[DMA ? row : 0][DMA ? v : 0][lane];
-      } else {
-#pragma unroll
-      for (int v = 0; v < NV; v++) u[v] = (FU_ABL & 1) ? f3lo[v] : Uf(g, v)[m];
-      }
+      for (int v = 0; v < NV; v++) u[v] = Uf(g, v)[m];
       // (the mask byte with the zone's other operands, not behind the stores of U: a load that is consumed at once waits
       //  for everything issued before it, i.e. the wave sat out the six stores' round trip in every plane)
       unsigned char pinned = 0;
-      if (from_lds) pinned = pin_early;
-      else if (CFL && pinmask && !(FU_ABL & 1)) pinned = pinmask[m];
-      if (GRAV && from_lds) {        // the same expressions on the operands the DMA brought
-        const int rw = DMA ? row : 0;
-        const Real phic = s_dma[rw][DMA ? 6 : 0][lane], dh = s_dma[rw][DMA ? 12 : 0][lane];
-        { const Real phil = s_dma[rw][DMA ? 7 : 0][lane], phir = (lane < 63) ? s_dma[rw][DMA ? 7 : 0][(lane + 1) & 63] : p1e;
-          u[1] -= dtodx[0]*(phir - phil)*dh;
-          u[4] -= dtodx[0]*(m1lo*(phic - phil) + m1hi*(phir - phic)); }
-        { const Real phir = s_dma[rw][DMA ? 10 : 0][lane], phil = s_dma[rw][DMA ? 8 : 0][lane];
-          u[2] -= dtodx[1]*(phir - phil)*dh;
-          u[4] -= dtodx[1]*(m2lo*(phic - phil) + m2hi*(phir - phic)); }
-        { const Real phir = s_dma[rw][DMA ? 11 : 0][lane], phil = s_dma[rw][DMA ? 9 : 0][lane];
-          u[3] -= dtodx[2]*(phir - phil)*dh;
-          u[4] -= dtodx[2]*(m3lo*(phic - phil) + m3hi*(phir - phic)); }
-      } else
-      if (GRAV && !(FU_ABL & 1)) {   // :2741-2782, with the mass fluxes (sweep component 0) of the faces just solved
+      if (CFL && pinmask) pinned = pinmask[m];
+      if (GRAV) {   // :2741-2782, with the mass fluxes (sweep component 0) of the faces just solved
         const Real phic = Pf(g, 0)[m], dh = dhalf[m];
         { const Real phir = Pf(g, 1)[m + 1], phil = Pf(g, 1)[m];
           u[1] -= dtodx[0]*(phir - phil)*dh;
@@ -1628,11 +1406,9 @@ k_flux2_update(DevGrid g, const Real *dhalf, Real dt, int kchunk, KeepPlanes kp,
       for (int n = 0; n < NV; n++) u[gv<1>(n)] -= dtodx[1]*d2[n];
 #pragma unroll
       for (int n = 0; n < NV; n++) u[gv<2>(n)] -= dtodx[2]*d3[n];
-      if (!(FU_ABL & 1) || kchunk < 0) {        // (FU_ABL 1: U neither loaded nor stored -- the state stands still, the arithmetic stays; run with AA_CFL_FUSED=0)
 #pragma unroll
       for (int v = 0; v < NV; v++) Uf(g, v)[m] = u[v];
-      }
-      if (CFL && !(FU_ABL & 1)) {
+      if (CFL) {
         if (!pinned) {
           Real cmx[3] = {s_cmx[0][row][lane], s_cmx[1][row][lane], s_cmx[2][row][lane]};
           cfl_zone(u[0], u[1], u[2], u[3], u[4], g.Gamma, g.Gamma_1, cmx);
@@ -2114,15 +1890,7 @@ __global__ void k_test_lr(Real Gamma, int n, const Real *W, Real dt, Real dx, in
 void launch_test_xdiv(int n, const Real *a, const Real *b, Real *out, hipStream_t st)
 { hipLaunchKernelGGL(k_test_xdiv, dim3((n + 255)/256), dim3(256), 0, st, n, a, b, out); }
 static inline unsigned nblk(long n, int b) { return (unsigned)((n + b - 1)/b); }
-static Order zone_order()
-{
-  static Order o = {-1, -1};
-  if (o.strip < 0) {
-    const char *e = getenv("AA_STRIP"); o.strip = e ? atoi(e) : 64;
-    e = getenv("AA_XCD"); o.xcd = e ? atoi(e) : 1;
-  }
-  return o;
-}
+static Order zone_order(const HostGrid &g) { Order o = {g.cfg.strip, g.cfg.xcd}; return o; }      // (AA_STRIP / AA_XCD as aa_create found them: grid.h LaunchCfg)
 // Grid-stride reduction kernels end in a few same-address atomics per block (one word sustains ~90
 // atomics/us): at least 8 zones per thread, between 256 and 4096 blocks.
 unsigned reduce_blocks(long n)
@@ -2130,7 +1898,7 @@ unsigned reduce_blocks(long n)
 static inline unsigned nblk8(long n, int b) { unsigned x = nblk(n, b); return ((x + 7u)/8u)*8u; }   // for xcd_block()
 
 template <int NS, bool GRAV, int MODE, int ORD>
-static void sweep_impl_o(const DevGrid &g, const Real *src, int dir, Real dt, hipStream_t st, int koff = 0, int kcnt = -1)
+static void sweep_impl_o(const HostGrid &g, const Real *src, int dir, Real dt, hipStream_t st, int koff = 0, int kcnt = -1)
 {
   // (koff, kcnt): for the x1 and x2 sweeps, the k-planes ks-2+koff .. +kcnt-1 only (every pencil is on its own: any
   // partition of the planes gives the same bits)
@@ -2138,23 +1906,8 @@ static void sweep_impl_o(const DevGrid &g, const Real *src, int dir, Real dt, hi
   if (kcnt < 0) kcnt = nk_all - koff;
   if (kcnt <= 0) return;
   if (dir == 0) {
-#if SW_X1_LINES
-    static const int lines = getenv("AA_X1_LINES") ? atoi(getenv("AA_X1_LINES")) : 1;
-    if (lines && !(g.sJ & 15) && g.is == 4) {
-      const long nq = ((long)(g.ie + 2 - (g.is - 16) + 1) + 15) & ~15L, nsl = nq*(g.je - g.js + 5);
-      if (nsl < (1L << 30)) {
-        int rsh = 31; while ((2L << (rsh - 31)) <= nq) rsh++;
-        const unsigned long long rmul = ((1ULL << rsh) + nq - 1)/nq;
-        dim3 gl((unsigned)((nsl + 255)/256), kcnt);
-        const size_t lds = (size_t)(5 + NS)*(256 + 3 + 256 + 1)*sizeof(Real);
-        hipLaunchKernelGGL((k_sweep_x1_lines<NS, GRAV, MODE, ORD>), gl, dim3(256), lds, st, g, src, dt, koff, (unsigned)nsl, (unsigned)nq,
-                           (unsigned)rmul, rsh);
-        return;
-      }
-    }
-#endif
 #if SW_X1_FLAT
-    static const int flat = getenv("AA_X1_FLAT") ? atoi(getenv("AA_X1_FLAT")) : 1;
+    const int flat = g.cfg.x1_flat;
     const long nc = g.ie - g.is + 5, nslots = nc*(g.je - g.js + 5);
     if (flat && nslots < (1L << 30)) {
       int rsh = 31; while ((2L << (rsh - 31)) <= nc) rsh++;            // 31 + floor(log2 nc)
@@ -2172,9 +1925,6 @@ static void sweep_impl_o(const DevGrid &g, const Real *src, int dir, Real dt, hi
     int B = (nfaces + nb - 1)/nb + 1;                  // B-1 interfaces per block
     B = ((B + 63)/64)*64; if (B > 256) B = 256;
     nb = (nfaces + (B - 1) - 1)/(B - 1);
-#if X1_ALIGNED
-    B = 256; nb = (g.ie + 2 - g.is + 240)/240;        // faces is-1 .. ie+2, block b ends with face is + 240 b + 239
-#endif
     dim3 grid(nb, g.je - g.js + 5, kcnt);
     size_t lds = (size_t)(5 + NS)*(B + 2)*sizeof(Real);
     hipLaunchKernelGGL((k_sweep_x1<NS, GRAV, MODE, ORD>), grid, dim3(B), lds, st, g, src, dt, koff);
@@ -2206,21 +1956,21 @@ static void sweep_impl_o(const DevGrid &g, const Real *src, int dir, Real dt, hi
   }
 }
 template <int NS, bool GRAV, int MODE>
-static void sweep_impl(const DevGrid &g, const Real *src, int dir, Real dt, hipStream_t st, int koff = 0, int kcnt = -1)
+static void sweep_impl(const HostGrid &g, const Real *src, int dir, Real dt, hipStream_t st, int koff = 0, int kcnt = -1)
 {
   // third order: the slope arrays were filled from the state the sweep reconstructs (U; U^{n+1/2} for the van Leer corrector)
   if (g.slope) sweep_impl_o<NS, GRAV, MODE, 3>(g, src, dir, dt, st, koff, kcnt);
   else sweep_impl_o<NS, GRAV, MODE, 2>(g, src, dir, dt, st, koff, kcnt);
 }
 template <int NS>
-static void slopes_impl(const DevGrid &g, int dir, hipStream_t st, const Real *src)
+static void slopes_impl(const HostGrid &g, int dir, hipStream_t st, const Real *src)
 {
   long n = 1;
   const int lo[3] = {g.is, g.js, g.ks}, hi[3] = {g.ie, g.je, g.ke};
   for (int d = 0; d < 3; d++) n *= hi[d] - lo[d] + 1 + (d == dir ? 6 : 4);
   dim3 grid(nblk(n, 256)), blk(256);
 #if SLOPES_MARCH
-  static const int march = getenv("AA_SLOPES_MARCH") ? atoi(getenv("AA_SLOPES_MARCH")) : 1;
+  const int march = g.cfg.slopes_march;
   if (march && dir != 0) {
     const long nq = march_slots(g), nt = (dir == 1 ? g.ke - g.ks : g.je - g.js) + 5;
     const int ncell = (dir == 1 ? g.je - g.js : g.ke - g.ks) + 7;
@@ -2238,14 +1988,13 @@ static void slopes_impl(const DevGrid &g, int dir, hipStream_t st, const Real *s
 }
 // the correct passes of all three directions in one kernel (after the three first passes)
 template <int NS, bool GRAV>
-static void correct_all_impl(const DevGrid &g, Real dt, bool x3f, hipStream_t st)
+static void correct_all_impl(const HostGrid &g, Real dt, bool x3f, hipStream_t st)
 {
   const int ni = g.ie - g.is + 3, nj = g.je - g.js + 3, nk = g.ke - g.ks + 3;    // zones s-1 .. e+1
   // planes per block: with the x3 first pass on board a chunk starts three planes early (two of first-pass work only and the
   // provider plane), so longer chunks pay: 64 planes 19.7 against 20.0 - 20.6 ms for 32 at 512^3 (128: 20.4, 16: 20.2);
   // AA_CA_KC overrides
-  static int kc_env = -1;
-  if (kc_env < 0) { const char *e = getenv("AA_CA_KC"); kc_env = e ? atoi(e) : 0; }
+  const int kc_env = g.cfg.ca_kc;
   int kc = kc_env > 0 ? kc_env : (x3f ? 64 : 32);
   // ... on Grids with fewer columns shorter chunks pay more than their start-up planes cost: the launch should hold about
   // eight rounds of the 512 blocks that are resident at a time (measured, profiles/microbench/kc_small.sh: 128^3 and 192^3 best
@@ -2263,34 +2012,34 @@ static void correct_all_impl(const DevGrid &g, Real dt, bool x3f, hipStream_t st
   if (nb1 > 0) hipLaunchKernelGGL((k_eta_edges<0>), dim3(nblk(nb1*nj*nk, 256)), dim3(256), 0, st, g);
   if (nb2 > 0) hipLaunchKernelGGL((k_eta_edges<1>), dim3(nblk((long)ni*nb2*nk, 256)), dim3(256), 0, st, g);
 }
-void launch_correct_all(const DevGrid &g, int nscal, Real dt, bool grav, bool x3f, hipStream_t st)
+void launch_correct_all(const HostGrid &g, int nscal, Real dt, bool grav, bool x3f, hipStream_t st)
 {
   if (nscal) { if (grav) correct_all_impl<1, true>(g, dt, x3f, st); else correct_all_impl<1, false>(g, dt, x3f, st); }
   else       { if (grav) correct_all_impl<0, true>(g, dt, x3f, st); else correct_all_impl<0, false>(g, dt, x3f, st); }
 }
 
-void launch_slopes(const DevGrid &g, int nscal, int dir, hipStream_t st, const Real *src)
+void launch_slopes(const HostGrid &g, int nscal, int dir, hipStream_t st, const Real *src)
 { if (!src) src = g.U; if (nscal) slopes_impl<1>(g, dir, st, src); else slopes_impl<0>(g, dir, st, src); }
 
-void launch_sweep(const DevGrid &g, int nscal, int dir, Real dt, bool grav, hipStream_t st, int koff, int kcnt)
+void launch_sweep(const HostGrid &g, int nscal, int dir, Real dt, bool grav, hipStream_t st, int koff, int kcnt)
 {
   if (nscal) { if (grav) sweep_impl<1, true, MODE_FLUX1>(g, g.U, dir, dt, st, koff, kcnt); else sweep_impl<1, false, MODE_FLUX1>(g, g.U, dir, dt, st, koff, kcnt); }
   else       { if (grav) sweep_impl<0, true, MODE_FLUX1>(g, g.U, dir, dt, st, koff, kcnt); else sweep_impl<0, false, MODE_FLUX1>(g, g.U, dir, dt, st, koff, kcnt); }
 }
 // x1 first pass + x1 correct pass in one sweep (must run after the x2 and x3 first passes)
-void launch_sweep_correct_x1(const DevGrid &g, int nscal, Real dt, bool grav, hipStream_t st)
+void launch_sweep_correct_x1(const HostGrid &g, int nscal, Real dt, bool grav, hipStream_t st)
 {
   if (nscal) { if (grav) sweep_impl<1, true, MODE_BOTH>(g, g.U, 0, dt, st); else sweep_impl<1, false, MODE_BOTH>(g, g.U, 0, dt, st); }
   else       { if (grav) sweep_impl<0, true, MODE_BOTH>(g, g.U, 0, dt, st); else sweep_impl<0, false, MODE_BOTH>(g, g.U, 0, dt, st); }
 }
 // CTU steps 5-7, 8a, 9a for the faces of one direction (after all three first-pass sweeps)
-void launch_correct(const DevGrid &g, int nscal, int dir, Real dt, bool grav, hipStream_t st)
+void launch_correct(const HostGrid &g, int nscal, int dir, Real dt, bool grav, hipStream_t st)
 {
   if (nscal) { if (grav) sweep_impl<1, true, MODE_CORR>(g, g.U, dir, dt, st); else sweep_impl<1, false, MODE_CORR>(g, g.U, dir, dt, st); }
   else       { if (grav) sweep_impl<0, true, MODE_CORR>(g, g.U, dir, dt, st); else sweep_impl<0, false, MODE_CORR>(g, g.U, dir, dt, st); }
 }
 // VL second-order fluxes: PLM without tracing on U^{n+1/2} (kept in LR[0][L]), etah = 0
-void launch_vl_flux2(const DevGrid &g, int nscal, int dir, Real dt, hipStream_t st)
+void launch_vl_flux2(const HostGrid &g, int nscal, int dir, Real dt, hipStream_t st)
 {
   if (nscal) sweep_impl<1, false, MODE_VL>(g, g.LR, dir, dt, st); else sweep_impl<0, false, MODE_VL>(g, g.LR, dir, dt, st);
 }
@@ -2328,15 +2077,15 @@ void launch_vl_uhalf(const DevGrid &g, int nscal, Real dt, bool grav, hipStream_
 }
 
 template <int NS>
-static void flux2_impl(const DevGrid &g, int dir, hipStream_t st)
+static void flux2_impl(const HostGrid &g, int dir, hipStream_t st)
 {
   const long n = (long)(g.ie - g.is + 1 + (dir == 0))*(g.je - g.js + 1 + (dir == 1))*(g.ke - g.ks + 1 + (dir == 2));
   dim3 grid(nblk8(n, 256)), blk(256);
-  if (dir == 0) hipLaunchKernelGGL((k_flux2<NS, 0>), grid, blk, 0, st, g, zone_order());
-  else if (dir == 1) hipLaunchKernelGGL((k_flux2<NS, 1>), grid, blk, 0, st, g, zone_order());
-  else hipLaunchKernelGGL((k_flux2<NS, 2>), grid, blk, 0, st, g, zone_order());
+  if (dir == 0) hipLaunchKernelGGL((k_flux2<NS, 0>), grid, blk, 0, st, g, zone_order(g));
+  else if (dir == 1) hipLaunchKernelGGL((k_flux2<NS, 1>), grid, blk, 0, st, g, zone_order(g));
+  else hipLaunchKernelGGL((k_flux2<NS, 2>), grid, blk, 0, st, g, zone_order(g));
 }
-void launch_flux2(const DevGrid &g, int nscal, int dir, hipStream_t st)
+void launch_flux2(const HostGrid &g, int nscal, int dir, hipStream_t st)
 { if (nscal) flux2_impl<1>(g, dir, st); else flux2_impl<0>(g, dir, st); }
 
 // fused second-pass fluxes + update (CTU); `keep`: the face planes whose fluxes are stored as well
@@ -2358,11 +2107,10 @@ void launch_pinned_cfl(const DevGrid &g, long long n, const long long *idx, DevS
                hipLaunchKernelGGL(k_pinned_cfl, dim3(nb), dim3(256), 0, st, g, n, idx, sc); } }
 void launch_pin_mask(const DevGrid &g, long long n, const long long *idx, unsigned char *mask, hipStream_t st)
 { if (n > 0) hipLaunchKernelGGL(k_pin_mask, dim3(nblk(n, 256)), dim3(256), 0, st, g, n, idx, mask); }
-void launch_flux2_update(const DevGrid &g, int nscal, Real dt, bool grav, const KeepPlanes *keep, hipStream_t st, DevScalars *sc, const unsigned char *pinmask)
+void launch_flux2_update(const HostGrid &g, int nscal, Real dt, bool grav, const KeepPlanes *keep, hipStream_t st, DevScalars *sc, const unsigned char *pinmask)
 {
   const int ni = g.ie - g.is + 1, nj = g.je - g.js + 1, nk = g.ke - g.ks + 1;
-  static int kc_env = -1;
-  if (kc_env < 0) { const char *e = getenv("AA_FU_KC"); kc_env = e ? atoi(e) : 0; }
+  const int kc_env = g.cfg.fu_kc;
   int kc = kc_env > 0 ? kc_env : 32;
   if (kc_env <= 0) while (kc > 4 && (long)nblk(ni, 64)*nblk(nj, FU_TJ - 1)*((nk + kc - 1)/kc) < 1024) kc >>= 1;
   dim3 grid(nblk(ni, 64), nblk(nj, FU_TJ - 1), (nk + kc - 1)/kc), blk(64, FU_TJ);
@@ -2373,24 +2121,24 @@ void launch_flux2_update(const DevGrid &g, int nscal, Real dt, bool grav, const 
 long update_blocks(const DevGrid &g)
 { return (long)nblk8((long)(g.ie - g.is + 1)*(g.je - g.js + 1)*(g.ke - g.ks + 1), 256); }
 // sc != nullptr: new_dt's maxima ride on the update (cfl_part: 3 * update_blocks(g) doubles of scratch; pinmask: zones left out)
-void launch_update(const DevGrid &g, int nscal, const Real *dhalf, Real dt, bool grav, hipStream_t st, DevScalars *sc, Real *cfl_part,
+void launch_update(const HostGrid &g, int nscal, const Real *dhalf, Real dt, bool grav, hipStream_t st, DevScalars *sc, Real *cfl_part,
                    const unsigned char *pinmask)
 {
   const long n = (long)(g.ie - g.is + 1)*(g.je - g.js + 1)*(g.ke - g.ks + 1);
   dim3 grid(nblk8(n, 256)), blk(256);
   if (sc && cfl_part) {
-    if (nscal) { if (grav) hipLaunchKernelGGL((k_update<1, true, true>), grid, blk, 0, st, g, dhalf, dt, zone_order(), cfl_part, pinmask);
-                 else      hipLaunchKernelGGL((k_update<1, false, true>), grid, blk, 0, st, g, dhalf, dt, zone_order(), cfl_part, pinmask); }
-    else       { if (grav) hipLaunchKernelGGL((k_update<0, true, true>), grid, blk, 0, st, g, dhalf, dt, zone_order(), cfl_part, pinmask);
-                 else      hipLaunchKernelGGL((k_update<0, false, true>), grid, blk, 0, st, g, dhalf, dt, zone_order(), cfl_part, pinmask); }
+    if (nscal) { if (grav) hipLaunchKernelGGL((k_update<1, true, true>), grid, blk, 0, st, g, dhalf, dt, zone_order(g), cfl_part, pinmask);
+                 else      hipLaunchKernelGGL((k_update<1, false, true>), grid, blk, 0, st, g, dhalf, dt, zone_order(g), cfl_part, pinmask); }
+    else       { if (grav) hipLaunchKernelGGL((k_update<0, true, true>), grid, blk, 0, st, g, dhalf, dt, zone_order(g), cfl_part, pinmask);
+                 else      hipLaunchKernelGGL((k_update<0, false, true>), grid, blk, 0, st, g, dhalf, dt, zone_order(g), cfl_part, pinmask); }
     unsigned nf = nblk(grid.x, 256*8); if (nf > 256) nf = 256;
     hipLaunchKernelGGL(k_cfl_fold, dim3(nf), dim3(256), 0, st, cfl_part, (int)grid.x, sc);
     return;
   }
-  if (nscal) { if (grav) hipLaunchKernelGGL((k_update<1, true, false>), grid, blk, 0, st, g, dhalf, dt, zone_order(), nullptr, nullptr);
-               else      hipLaunchKernelGGL((k_update<1, false, false>), grid, blk, 0, st, g, dhalf, dt, zone_order(), nullptr, nullptr); }
-  else       { if (grav) hipLaunchKernelGGL((k_update<0, true, false>), grid, blk, 0, st, g, dhalf, dt, zone_order(), nullptr, nullptr);
-               else      hipLaunchKernelGGL((k_update<0, false, false>), grid, blk, 0, st, g, dhalf, dt, zone_order(), nullptr, nullptr); }
+  if (nscal) { if (grav) hipLaunchKernelGGL((k_update<1, true, false>), grid, blk, 0, st, g, dhalf, dt, zone_order(g), nullptr, nullptr);
+               else      hipLaunchKernelGGL((k_update<1, false, false>), grid, blk, 0, st, g, dhalf, dt, zone_order(g), nullptr, nullptr); }
+  else       { if (grav) hipLaunchKernelGGL((k_update<0, true, false>), grid, blk, 0, st, g, dhalf, dt, zone_order(g), nullptr, nullptr);
+               else      hipLaunchKernelGGL((k_update<0, false, false>), grid, blk, 0, st, g, dhalf, dt, zone_order(g), nullptr, nullptr); }
 }
 
 void launch_bc(const DevGrid &g, int nscal, int dir, int side, int flag, hipStream_t st)

@@ -2,25 +2,25 @@
 // and once more inside `aa_cool` for the second compilation of the same file with -DAA_COOLING=1 (optically thin cooling in the
 // CTU integrator: integrate_3d_ctu.c Steps 1c-3c, 8b, 11c), whose kernels api.hip launches when a cooling function is enrolled.
 // ---- launch wrappers (hydro_kernels.hip) ------------------------------------------
-void launch_slopes(const DevGrid &g, int nscal, int dir, hipStream_t st, const Real *src = nullptr);   // order 3: before the sweeps of a step (src: the conserved state they reconstruct; null = U)
+void launch_slopes(const HostGrid &g, int nscal, int dir, hipStream_t st, const Real *src = nullptr);   // order 3: before the sweeps of a step (src: the conserved state they reconstruct; null = U)
 // first-pass sweep of one direction; for dir 0 / 1 optionally only the k-planes ks-2+koff .. +kcnt-1 (kcnt < 0: to the end)
-void launch_sweep(const DevGrid &g, int nscal, int dir, Real dt, bool grav, hipStream_t st, int koff = 0, int kcnt = -1);
-void launch_correct(const DevGrid &g, int nscal, int dir, Real dt, bool grav, hipStream_t st);
-void launch_sweep_correct_x1(const DevGrid &g, int nscal, Real dt, bool grav, hipStream_t st);
+void launch_sweep(const HostGrid &g, int nscal, int dir, Real dt, bool grav, hipStream_t st, int koff = 0, int kcnt = -1);
+void launch_correct(const HostGrid &g, int nscal, int dir, Real dt, bool grav, hipStream_t st);
+void launch_sweep_correct_x1(const HostGrid &g, int nscal, Real dt, bool grav, hipStream_t st);
 // the three correct passes in one kernel; x3f: and the x3 first pass (then launch_sweep(.., 2, ..) is not needed)
-void launch_correct_all(const DevGrid &g, int nscal, Real dt, bool grav, bool x3f, hipStream_t st);
-void launch_flux2(const DevGrid &g, int nscal, int dir, hipStream_t st);
-void launch_update(const DevGrid &g, int nscal, const Real *dhalf, Real dt, bool grav, hipStream_t st, DevScalars *sc = nullptr,
+void launch_correct_all(const HostGrid &g, int nscal, Real dt, bool grav, bool x3f, hipStream_t st);
+void launch_flux2(const HostGrid &g, int nscal, int dir, hipStream_t st);
+void launch_update(const HostGrid &g, int nscal, const Real *dhalf, Real dt, bool grav, hipStream_t st, DevScalars *sc = nullptr,
                    Real *cfl_part = nullptr, const unsigned char *pinmask = nullptr);
 long update_blocks(const DevGrid &g);
-void launch_flux2_update(const DevGrid &g, int nscal, Real dt, bool grav, const KeepPlanes *keep, hipStream_t st,
+void launch_flux2_update(const HostGrid &g, int nscal, Real dt, bool grav, const KeepPlanes *keep, hipStream_t st,
                          DevScalars *sc = nullptr, const unsigned char *pinmask = nullptr);   // sc: also new_dt's maxima (k_flux2_update<CFL>)
 void launch_pinned_cfl(const DevGrid &g, long long n, const long long *idx, DevScalars *sc, hipStream_t st);
 void launch_pin_mask(const DevGrid &g, long long n, const long long *idx, unsigned char *mask, hipStream_t st);   // flux2 x3 + update fused
 void launch_vl_flux1(const DevGrid &g, int nscal, int dir, hipStream_t st);
 void launch_vl_uhalf(const DevGrid &g, int nscal, Real dt, bool grav, hipStream_t st);
 void launch_vl_predict(const DevGrid &g, int nscal, Real dt, bool grav, hipStream_t st);   // vl_flux1 x3 + vl_uhalf fused
-void launch_vl_flux2(const DevGrid &g, int nscal, int dir, Real dt, hipStream_t st);
+void launch_vl_flux2(const HostGrid &g, int nscal, int dir, Real dt, hipStream_t st);
 void launch_bc(const DevGrid &g, int nscal, int dir, int side, int flag, hipStream_t st);
 void launch_bc_dir(const DevGrid &g, int nscal, int dir, int flag_in, int flag_out, hipStream_t st);   // both sides, one launch
 unsigned reduce_blocks(long nzones);      // launch size of the grid-stride reduction kernels

@@ -638,19 +638,17 @@ void launch_test_explog(int n, const Real *x, Real *ye, Real *yl, hipStream_t st
 // =============================================================================================
 static inline unsigned nblk(long n, int b) { return (unsigned)((n + b - 1)/b); }
 
-int ion_pass_blocks(const DevGrid &g)
+int ion_pass_blocks(const HostGrid &g)
 {
   const long nrays = (long)g.Nx2*g.Nx3;
-  long nb = (nrays + 3)/4;
-  static int cap = -1;
-  if (cap < 0) { const char *e = getenv("AA_ION_PASS_BLOCKS"); cap = e ? atoi(e) : 4096; if (cap < 1) cap = 1; }
+  const long nb = (nrays + 3)/4, cap = g.cfg.ion_pass_cap;      // (AA_ION_PASS_BLOCKS as aa_create found it: grid.h LaunchCfg)
   return (int)(nb < cap ? nb : cap);
 }
 
 void launch_ion_begin16(const DevGrid &g, const IonPar &p, hipStream_t st)
 { const long n = (long)g.Nx1*g.Nx2*g.Nx3; hipLaunchKernelGGL(k_ion_begin16, dim3(nblk(n, 256)), dim3(256), 0, st, g, p); }
 
-void launch_ion_pass(const DevGrid &g, const IonPar &p, bool update, bool sweep, bool begin, Real flux0, bool from_edgeflux,
+void launch_ion_pass(const HostGrid &g, const IonPar &p, bool update, bool sweep, bool begin, Real flux0, bool from_edgeflux,
                      const DevScalars *sc, int cur, IonPart *part, Real *words, hipStream_t st, Real spec_dt)
 {
   const int nb = ion_pass_blocks(g);
