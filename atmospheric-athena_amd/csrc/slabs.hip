@@ -17,8 +17,9 @@
 //     multi-process driver does behind its all-gather), all ordered by events -- the host reads back ONCE per
 //     sub-cycle (slab 0's scalars), and the next pass is already queued behind it (MIN / MAX / integer SUM: bitwise
 //     independent of the cut);
-//   * peer access between neighbouring devices is asked for and CHECKED; where it is refused (or with
-//     AA_SLAB_NO_PEER=1) the halo travels through pinned host buffers instead, and the library says so on stderr;
+//   * peer access between neighbouring devices (halo) and between slab 0's device and every other (sub-cycle words) is asked for
+//     and CHECKED; where it is refused (or with AA_SLAB_NO_PEER=1 / AA_SLAB_WORDS_STAGED=1) the halo / the words travel through
+//     pinned host buffers instead, and the library says so on stderr;
 //   * StaticGravPot is evaluated at the positions of the caller's undivided Grid, and the problem generator /
 //     Userwork hooks work on the caller's block, so an N-slab run reproduces the 1-slab run bit for bit.
 // Block decomposition as init_mesh.c:583-620: Nx3/N planes each, the remainder to the first slabs.
@@ -55,6 +56,13 @@ struct SlabLink {
   std::vector<Real*> hstage[2];            // pinned: the slab's two send buffers on the host
   std::vector<hipStream_t> xout;           // the slab's device -> host copies
   std::vector<hipEvent_t> staged_ev;       // ... are complete
+  // the radiation sub-cycle's words: slab 0 <-> every slab.  Where peer access between device 0 and ANY slab's device is missing (checked at
+  // create time for every pair, not only neighbours), or the halo is staged anyway, the words go through pinned host memory instead: every
+  // slab copies its words into hwords[round & 1][s] behind its pass and, once all have, reads the whole set back -- no peer copy at all.
+  // Two rounds of buffers: a slab can be one pick ahead of another, never two (its next pass waits for everybody's words of this one).
+  bool words_staged = false;
+  Real *hwords[2] = {nullptr, nullptr};    // pinned: n x AA_ION_WORDS each
+  unsigned wround = 0;
   size_t halo = 0;
   int home = 0;                            // the caller's current device when the handle was made
 };
@@ -138,6 +146,31 @@ int slabs_create(const aa_params *p, int nslab, aa_grid **out)
         }
       }
   }
+  // ... and between slab 0's device and EVERY slab's device for the sub-cycle's words (slab 0 pulls from all, all pull from slab 0)
+  { const char *e = getenv("AA_SLAB_WORDS_STAGED"); L->words_staged = L->staged || (e && atoi(e) != 0); }
+  for (int s = 1; s < nslab && !L->words_staged; s++) {
+    if (L->dev[s] == L->dev[0]) continue;
+    for (int dir = 0; dir < 2 && !L->words_staged; dir++) {
+      const int from = dir ? L->dev[s] : L->dev[0], to = dir ? L->dev[0] : L->dev[s];
+      CREATE_CHK(hipSetDevice(from));
+      int can = 0;
+      hipError_t e = hipDeviceCanAccessPeer(&can, from, to);
+      if (e == hipSuccess && can) {
+        e = hipDeviceEnablePeerAccess(to, 0);
+        if (e == hipErrorPeerAccessAlreadyEnabled) { (void)hipGetLastError(); e = hipSuccess; }
+      }
+      if (e != hipSuccess || !can) {
+        (void)hipGetLastError();
+        fprintf(stderr, "[athena_amd] WARNING: no peer access from HIP device %d to %d (%s): the radiation sub-cycle's reduction words of the slabs "
+                        "travel through pinned host memory\n", from, to, e != hipSuccess ? hipGetErrorString(e) : "refused");
+        L->words_staged = true;
+      }
+    }
+  }
+  if (L->words_staged) for (int w = 0; w < 2; w++) {
+    CREATE_CHK(hipHostMalloc(&L->hwords[w], (size_t)nslab*AA_ION_WORDS*sizeof(Real)));
+    memset(L->hwords[w], 0, (size_t)nslab*AA_ION_WORDS*sizeof(Real));
+  }
   for (int s = 0; s < nslab; s++) {
     CREATE_CHK(hipSetDevice(L->dev[s]));
     for (int w = 0; w < 2; w++) {
@@ -190,6 +223,7 @@ void slabs_destroy(aa_grid *g)      // (also the error path of slabs_create: wha
   }
   if (L->gathered) hipEventDestroy(L->gathered);
   if (L->hsc) hipHostFree(L->hsc);
+  for (int w = 0; w < 2; w++) if (L->hwords[w]) hipHostFree(L->hwords[w]);
   if (g->sc_host) hipHostFree(g->sc_host);
   delete L;
   g->link = nullptr;
@@ -512,6 +546,8 @@ int slabs_ion_pass(aa_grid *g, int update, int sweep)
     SLAB_DEV(L, s);
     aa_grid *c = g->slab[s];
     int rc = aa_ion_pass(c, update, sweep, nullptr); if (rc) return rc;
+    if (L->words_staged)      // the slab's words to the host buffer of this round (slabs_ion_pick closes the round)
+      HIPCHK(hipMemcpyAsync(L->hwords[L->wround & 1] + (size_t)s*AA_ION_WORDS, c->ion_words, AA_ION_WORDS*sizeof(double), hipMemcpyDeviceToHost, c->st));
     HIPCHK(hipEventRecord(L->wdone[s], c->st));
   }
   return 0;
@@ -526,6 +562,23 @@ int slabs_ion_pick(aa_grid *g, int first, double limit)
   DevGuard keep;
   SlabLink *L = g->link;
   const size_t wb = AA_ION_WORDS*sizeof(double);
+  if (L->words_staged) {
+    // through pinned host memory: every slab waits for everybody's words of this round and reads the whole set back itself
+    const Real *hw = L->hwords[L->wround & 1];
+    L->wround++;
+    for (int s = 0; s < L->n; s++) {
+      SLAB_DEV(L, s);
+      aa_grid *c = g->slab[s];
+      if (first && c->ion_spec_armed && limit != c->ion_spec_limit)
+        return aa_fail(-1, "[aa_ion_pick]: limit %.17g, but aa_ion_speculate was told %.17g", limit, c->ion_spec_limit);
+      for (int t = 0; t < L->n; t++) if (t != s) HIPCHK(hipStreamWaitEvent(c->st, L->wdone[t], 0));
+      HIPCHK(hipMemcpyAsync(L->dwords_all[s], hw, (size_t)L->n*wb, hipMemcpyHostToDevice, c->st));
+      launch_ion_pick2(L->dwords_all[s], L->n, c->sc, first, limit, c->st, first ? (c->ion_spec_armed ? 1 : 0) : 0);
+      if (!first) c->ion_spec_armed = false;
+    }
+    HIPCHK(hipGetLastError());
+    return 0;
+  }
   {
     SLAB_DEV(L, 0);
     aa_grid *c0 = g->slab[0];

@@ -256,11 +256,17 @@ struct aa_mesh {
 extern "C" {
 
 void aa_mesh_destroy(aa_mesh *m);
+// error paths of the create functions: the caller keeps its Grids as they were (mesh_alloc marked them as levels of a Mesh)
+static void mesh_drop(aa_mesh *m)
+{
+  for (int l = 0; l < m->nl; l++) if (m->lev[l]) { m->lev[l]->keep_flux = false; m->lev[l]->keep = {0, {{0}}}; }
+  delete m;
+}
 static int mesh_finish(aa_mesh *m, aa_grid **levels, aa_mesh **out)
 {
   hipError_t e = hipSetDevice(levels[0]->p.device);
   if (e == hipSuccess) e = hipStreamCreate(&m->st);
-  if (e != hipSuccess) { delete m; return aa_fail(-2, "[aa_mesh_create]: %s", hipGetErrorString(e)); }
+  if (e != hipSuccess) { mesh_drop(m); return aa_fail(-2, "[aa_mesh_create]: %s", hipGetErrorString(e)); }
   for (int l = 0; l < m->nl; l++) aa_set_stream(m->lev[l], (void*)m->st);
   for (int l = 0; l + 1 < m->nl; l++) {
     const Link &L = m->link[l];
@@ -297,12 +303,13 @@ static aa_mesh *mesh_alloc(int nlevels, aa_grid **levels)
   if (!levels || nlevels < 1 || nlevels > AA_MAXLEV) { aa_fail(-1, "[aa_mesh_create]: bad arguments"); return nullptr; }
   aa_mesh *m = new aa_mesh();
   m->nl = nlevels;
+  for (int l = 0; l < AA_MAXLEV; l++) { m->lev[l] = nullptr; m->box[l] = nullptr; }
   for (int l = 0; l < nlevels; l++) {
     aa_grid *g = levels[l];
     if (!g || (l == 0 ? g->level != 0 : (g->level < 1 || g->level < levels[l - 1]->level || g->level > levels[l - 1]->level + 1))) {
-      delete m; aa_fail(-1, "[aa_mesh_create]: grids must come level by level from the root (grid %d)", l); return nullptr; }
-    if (!g->slab.empty()) { delete m; aa_fail(-1, "[aa_mesh_create]: levels[%d] is cut into slabs (aa_params.nslab / AA_NGPU): nested levels stay on one device", l); return nullptr; }
-    if (g->p.device != levels[0]->p.device) { delete m; aa_fail(-1, "[aa_mesh_create]: all levels must live on one device"); return nullptr; }
+      mesh_drop(m); aa_fail(-1, "[aa_mesh_create]: grids must come level by level from the root (grid %d)", l); return nullptr; }
+    if (!g->slab.empty()) { mesh_drop(m); aa_fail(-1, "[aa_mesh_create]: levels[%d] is cut into slabs (aa_params.nslab / AA_NGPU): nested levels stay on one device", l); return nullptr; }
+    if (g->p.device != levels[0]->p.device) { mesh_drop(m); aa_fail(-1, "[aa_mesh_create]: all levels must live on one device"); return nullptr; }
     m->lev[l] = g; m->box[l] = nullptr; m->par[l] = l;
     g->keep_flux = true;
   }
@@ -330,7 +337,7 @@ int aa_mesh_create(int nlevels, aa_grid **levels, const int *disp, aa_mesh **out
       }
       if (inside) pi = q;
     }
-    if (pi < 0) { delete m; return aa_fail(-1, "[aa_mesh_create]: grid %d (level %d) is not nested in a Domain of level %d", c, C->level, C->level - 1); }
+    if (pi < 0) { mesh_drop(m); return aa_fail(-1, "[aa_mesh_create]: grid %d (level %d) is not nested in a Domain of level %d", c, C->level, C->level - 1); }
     const int l = c - 1;
     m->par[l] = pi;
     const aa_grid *P = m->lev[pi];
@@ -341,14 +348,14 @@ int aa_mesh_create(int nlevels, aa_grid **levels, const int *disp, aa_mesh **out
     for (int d = 0; d < 3; d++) {
       const int a = dc[d]/2 - dp[d], b = (dc[d] + C->p.Nx[d])/2 - dp[d];
       if ((dc[d] & 1) || (C->p.Nx[d] & 1) || a < 0 || b > P->p.Nx[d]) {
-        delete m; return aa_fail(-1, "[aa_mesh_create]: grid %d is not nested in grid %d along x%d", c, pi, d + 1);
+        mesh_drop(m); return aa_fail(-1, "[aa_mesh_create]: grid %d is not nested in grid %d along x%d", c, pi, d + 1);
       }
       L.cs[d] = a + lo[d]; L.ce[d] = b + lo[d] - 1; L.n[d] = b - a; L.cdisp[d] = dc[d];
       L.prol[2*d]     = L.corr[2*d]     = (dc[d] != 0);
       L.prol[2*d + 1] = L.corr[2*d + 1] = ((dc[d] + C->p.Nx[d])/irefine != C->p.rootNx[d]);
       // init_mesh.c:320-360: a child may touch its parent's edge only on the root boundary
       if ((a == 0 && L.prol[2*d]) || (b == P->p.Nx[d] && L.prol[2*d + 1])) {
-        delete m; return aa_fail(-1, "[init_mesh] child Domain (grid %d) touches its parent in x%d", c, d + 1);
+        mesh_drop(m); return aa_fail(-1, "[init_mesh] child Domain (grid %d) touches its parent in x%d", c, d + 1);
       }
     }
     // init_mesh.c:398-418: Domains on the same level neither overlap nor touch
@@ -357,7 +364,7 @@ int aa_mesh_create(int nlevels, aa_grid **levels, const int *disp, aa_mesh **out
       if (Q->level != C->level) continue;
       bool sep = false;
       for (int d = 0; d < 3; d++) if (dc[d] > disp[3*q + d] + Q->p.Nx[d] || disp[3*q + d] > dc[d] + C->p.Nx[d]) sep = true;
-      if (!sep) { delete m; return aa_fail(-1, "[init_mesh]: Domains at the same level overlap or touch (grids %d and %d)", q, c); }
+      if (!sep) { mesh_drop(m); return aa_fail(-1, "[init_mesh]: Domains at the same level overlap or touch (grids %d and %d)", q, c); }
     }
     // ionrad_smr.c:97-98 mixes a parent-local index with the child's root-relative Disp: with a displaced
     // parent (3+ levels) the reference writes out of bounds.  Refused by default; AA_SMR_DEEP_RADIATION=fixed
@@ -366,7 +373,7 @@ int aa_mesh_create(int nlevels, aa_grid **levels, const int *disp, aa_mesh **out
     if (P->p.ion && (dp[1] || dp[2])) {
       const char *e = getenv("AA_SMR_DEEP_RADIATION");
       if (!(e && strcmp(e, "fixed") == 0)) {
-        delete m; return aa_fail(-1, "[aa_mesh_create]: radiation across a displaced parent (grid %d) is undefined in the reference "
+        mesh_drop(m); return aa_fail(-1, "[aa_mesh_create]: radiation across a displaced parent (grid %d) is undefined in the reference "
                                      "(set AA_SMR_DEEP_RADIATION=fixed for the corrected hand-off)", pi);
       }
       for (int d = 0; d < 3; d++) L.cdisp[d] = dc[d] - 2*dp[d];
@@ -385,6 +392,9 @@ int aa_mesh_create_local(int nlevels, aa_grid **levels, const int *links, aa_mes
   if ((nlevels > 1 && !links) || !out) return aa_fail(-1, "[aa_mesh_create_local]: bad arguments");
   aa_mesh *m = mesh_alloc(nlevels, levels);
   if (!m) return -1;
+  // links join grid l+1 to grid l here (par[l] = l): ONE Domain per level, a strict chain (mesh_alloc alone would also take siblings)
+  for (int l = 0; l < nlevels; l++)
+    if (m->lev[l]->level != l) { mesh_drop(m); return aa_fail(-1, "[aa_mesh_create_local]: grid %d is on level %d: a rank's stack holds one Domain per level", l, levels[l]->level); }
   for (int l = 0; l + 1 < nlevels; l++) {
     const int *q = links + 21*l;
     const aa_grid *P = m->lev[l], *C = m->lev[l + 1];
@@ -392,7 +402,7 @@ int aa_mesh_create_local(int nlevels, aa_grid **levels, const int *links, aa_mes
     for (int d = 0; d < 3; d++) {
       L.cs[d] = q[d]; L.n[d] = q[3 + d]; L.ce[d] = q[d] + q[3 + d] - 1; L.cdisp[d] = q[18 + d];
       if (L.n[d]*2 != C->p.Nx[d] || L.cs[d] < AA_NGHOST || L.ce[d] >= AA_NGHOST + P->p.Nx[d]) {
-        delete m; return aa_fail(-1, "[aa_mesh_create_local]: link %d does not match the slabs along x%d", l, d + 1);
+        mesh_drop(m); return aa_fail(-1, "[aa_mesh_create_local]: link %d does not match the slabs along x%d", l, d + 1);
       }
     }
     for (int d = 0; d < 6; d++) { L.prol[d] = q[6 + d]; L.corr[d] = q[12 + d]; }
@@ -404,7 +414,10 @@ void aa_mesh_destroy(aa_mesh *m)      // the levels stay alive and go back to th
 {
   if (!m) return;
   hipStreamSynchronize(m->st);
-  for (int l = 0; l < m->nl; l++) { m->lev[l]->st = nullptr; m->lev[l]->own_stream = false; if (m->box[l]) hipFree(m->box[l]); }
+  for (int l = 0; l < m->nl; l++) {
+    m->lev[l]->st = nullptr; m->lev[l]->own_stream = false; if (m->box[l]) hipFree(m->box[l]);
+    m->lev[l]->keep_flux = false; m->lev[l]->keep = {0, {{0}}};      // no longer a level of a Mesh
+  }
   if (m->own_stream) hipStreamDestroy(m->st);
   delete m;
 }

@@ -98,6 +98,21 @@ def test_halo_through_pinned_host_memory_when_peer_access_is_refused(problem, nx
         assert np.array_equal(many["ef"], one["ef"])
 
 
+@pytest.mark.parametrize("problem,nx,nsteps,nslab", [("ioniz_sphere", (64, 20, 20), 2, 4), ("ifront", (70, 9, 13), 3, 3)])
+def test_subcycle_words_through_pinned_host_memory(problem, nx, nsteps, nslab, monkeypatch, capfd):
+    """The one-kernel sub-cycle's reduction words travel slab 0 <-> every slab; peer access is checked for every such pair,
+    and where it is missing (forced here: AA_SLAB_WORDS_STAGED=1, the halo still device to device) every slab copies its
+    words into a pinned host buffer behind its pass and reads the whole set back once all have -- two rounds of buffers,
+    ordered by events, still ONE host read-back per sub-cycle.  Bit for bit the one-Grid run (strict build)."""
+    one = _run(problem, nx, nsteps, 1, "ctu", True)
+    monkeypatch.setenv("AA_SLAB_WORDS_STAGED", "1")
+    many = _run(problem, nx, nsteps, nslab, "ctu", True)
+    assert "travels through pinned host memory" not in capfd.readouterr().err      # (only the words are staged)
+    assert many["its"] == one["its"] and many["time"] == one["time"] and many["dt"] == one["dt"]
+    assert np.array_equal(many["U"], one["U"], equal_nan=True)
+    assert np.array_equal(many["ef"], one["ef"])
+
+
 def test_composite_handles_refuse_what_they_cannot_do_and_keep_the_callers_device():
     """Entry points that make no sense on a Grid cut into slabs fail with a message instead of touching null pointers, and
     every composite call leaves the caller's current HIP device as it found it."""
