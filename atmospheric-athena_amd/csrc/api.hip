@@ -833,20 +833,32 @@ int aa_edgeflux_ready(aa_grid *g)
 }
 extern "C" {
 
-static int ion_run_fused(aa_grid *g, bool fine, double limit, int *niter_out, double *dt_done_out)
+// the words of the pass just queued to all ranks (the driver's collective, on the Grid's stream): nothing to do with one rank
+struct IonGather { double *words = nullptr; const double *all = nullptr; int nranks = 1; aa_gather_fn fn = nullptr; void *ctx = nullptr; };
+static int ion_gather(const IonGather &G)
+{
+  if (!G.fn) return 0;
+  const int rc = G.fn(G.ctx);
+  return rc ? aa_fail(-5, "[ion_radtransfer_3d]: the driver's all-gather of the sub-cycle's words failed (%d)", rc) : 0;
+}
+static int ion_run_fused(aa_grid *g, bool fine, double limit, int *niter_out, double *dt_done_out, const IonGather &G = IonGather())
 {
   double dt, dt_chem = 0, dt_therm = 0, dt_hydro = 0, dt_done = 0.0;
   long long cellcount = 0;
   int hit, neg, niter = 0, rc;
+  const double *all = G.fn ? G.all : nullptr;
+  const int nr = G.fn ? G.nranks : 1;
   if ((rc = aa_ion_begin(g))) return rc;
   if ((rc = aa_ion_speculate(g, limit))) return rc;                          // (the first pass may already apply update(0) with the whole step)
-  if ((rc = aa_ion_pass(g, 0, 1, nullptr))) return rc;                       // sweep(0) + rates(0)
-  if ((rc = aa_ion_pick(g, nullptr, 1, 1, limit))) return rc;                // -> dt_0 (stays on the device)
+  if ((rc = aa_ion_pass(g, 0, 1, G.fn ? G.words : nullptr))) return rc;      // sweep(0) + rates(0)
+  if ((rc = ion_gather(G))) return rc;
+  if ((rc = aa_ion_pick(g, all, nr, 1, limit))) return rc;                   // -> dt_0 (stays on the device)
   for (;;) {
     // update(n) with the step picked on the device, then -- unless that step was cut back to the limit -- sweep(n+1) and
     // rates(n+1), speculatively: whether the loop goes on is only known from this pass's own reductions
-    if ((rc = aa_ion_pass(g, 1, 1, nullptr))) return rc;
-    if ((rc = aa_ion_pick(g, nullptr, 1, 0, limit))) return rc;
+    if ((rc = aa_ion_pass(g, 1, 1, G.fn ? G.words : nullptr))) return rc;
+    if ((rc = ion_gather(G))) return rc;
+    if ((rc = aa_ion_pick(g, all, nr, 0, limit))) return rc;
     if ((rc = aa_ion_fetch(g, &dt, &hit, &dt_chem, &dt_therm, &cellcount, &dt_hydro, &neg))) return rc;   // the one read-back
     if (neg) return fail(-4, "[compute_chem_rates]: negative dt_chem");      // ionrad_3d.c:389-391 (of the rates behind dt)
     dt_done += dt;
@@ -897,6 +909,22 @@ int aa_ion_radtransfer_3d(aa_grid *g, int *niter_out)
   // ionrad_3d.c:862-1047, root level
   int niter = 0, rc; double dt_done = 0.0;
   if ((rc = aa_ion_run(g, 0, g->dt, &niter, &dt_done))) return rc;
+  if (niter == g->p.maxiter) g->dt = dt_done;
+  if (g->dt < 0) return fail(-4, "[ion_radtransfer_3d]: dt = %e, dt_done = %e", g->dt, dt_done);
+  if (niter_out) *niter_out = niter;
+  return 0;
+}
+
+int aa_ion_radtransfer_3d_gather(aa_grid *g, double *dev_words, const double *dev_words_all, int nranks, aa_gather_fn gather,
+                                 void *ctx, int *niter_out)
+{
+  g->cfl_ready = false;
+  if (!g->slab.empty()) return fail(-1, "[aa_ion_radtransfer_3d_gather]: a Grid cut into slabs reduces over its slabs itself (aa_ion_radtransfer_3d)");
+  if (!g->ion_fused) return fail(-1, "[aa_ion_radtransfer_3d_gather]: this Grid runs the two-kernel sub-cycle (aa_ion_rates / aa_ion_update)");
+  if (gather && (!dev_words || !dev_words_all || nranks < 1)) return fail(-1, "[aa_ion_radtransfer_3d_gather]: word buffers");
+  IonGather G; G.words = dev_words; G.all = dev_words_all; G.nranks = nranks; G.fn = gather; G.ctx = ctx;
+  int niter = 0, rc; double dt_done = 0.0;
+  if ((rc = ion_run_fused(g, false, g->dt, &niter, &dt_done, G))) return rc;
   if (niter == g->p.maxiter) g->dt = dt_done;
   if (g->dt < 0) return fail(-4, "[ion_radtransfer_3d]: dt = %e, dt_done = %e", g->dt, dt_done);
   if (niter_out) *niter_out = niter;

@@ -93,6 +93,20 @@ class HipEngine:
 
     def ion_fetch(self): return self.g.ion_fetch()
     def ion_finish(self): self.g.ion_finish()
+
+    def ion_radtransfer_gather(self, dist) -> int:
+        """the whole sub-cycle loop inside the library (aa_ion_radtransfer_3d_gather): the only thing left to this side is the
+        all-gather of the slabs' words, once per pass -- ONE crossing per sub-cycle, as a one-rank run has none"""
+        if dist.get_backend() == "gloo":                     # rehearsal on one GPU: gloo moves host tensors
+            def gather():
+                w = self.words.cpu(); wa = self.words_all.cpu()
+                dist.all_gather_into_tensor(wa, w)
+                self.words_all.copy_(wa)
+        else:
+            def gather():
+                dist.all_gather_into_tensor(self.words_all, self.words)
+        return self.g.ion_radtransfer_3d_gather(self.words.data_ptr(), self.words_all.data_ptr(), self.cfg.nranks, gather)
+
     def host_syncs(self, reset=False): return self.g.host_syncs(reset)
     def set_mesh_state(self, time, dt, nstep): self.g.set_mesh_state(time, dt, nstep)
     def has_radiation(self) -> bool: return self.g.has_radplane()      # main.c:546, as aa_step: the ion step runs iff nradplane > 0
@@ -284,6 +298,11 @@ class Driver:
         read-back; the sweep after a data-dependent stop is speculative and dropped by ion_finish."""
         e = self.eng
         dist = self.dist if self.distributed else None
+        if dist is not None and hasattr(e, "ion_radtransfer_gather") and not os.environ.get("AA_DRIVER_PY_SUBCYCLES"):
+            # the loop below inside the library, the all-gather as its callback (AA_DRIVER_PY_SUBCYCLES=1: the loop as written here)
+            niter = e.ion_radtransfer_gather(dist)
+            self.dt = e.mesh_state()[1]
+            return niter
         dt_done, niter = 0.0, 0
         e.ion_begin()
         if hasattr(e, "ion_speculate"):

@@ -40,6 +40,7 @@ class aa_params(C.Structure):
 ION_WORDS = 8     # AA_ION_WORDS of include/athena_amd.h
 
 GRAVPOT = C.CFUNCTYPE(C.c_double, C.c_double, C.c_double, C.c_double)
+GATHER = C.CFUNCTYPE(C.c_int, C.c_void_p)      # aa_gather_fn of include/athena_amd.h
 
 _libs = {}
 _host = None
@@ -99,7 +100,8 @@ def load(strict: bool | None = None) -> C.CDLL:
         "aa_new_dt_local": (I, [P, dp]), "aa_ion_begin": (I, [P]), "aa_ion_rates": (I, [P, dp, dp]),
         "aa_ion_update": (I, [P, D, llp, dp]),
         "aa_ion_is_fused": (I, [P]), "aa_ion_speculate": (I, [P, D]), "aa_ion_pass": (I, [P, I, I, P]), "aa_ion_pick": (I, [P, P, I, I, D]),
-        "aa_ion_fetch": (I, [P, dp, ip, dp, dp, llp, dp, ip]), "aa_ion_finish": (I, [P]), "aa_host_syncs": (I, [P, I]),
+        "aa_ion_fetch": (I, [P, dp, ip, dp, dp, llp, dp, ip]), "aa_ion_finish": (I, [P]),
+        "aa_ion_radtransfer_3d_gather": (I, [P, P, P, I, GATHER, P, ip]), "aa_host_syncs": (I, [P, I]),
         "aa_halo_doubles": (LL, [P]), "aa_pack_x3": (I, [P, I, P]), "aa_unpack_x3": (I, [P, I, P]),
         "aa_halo_doubles_x2": (LL, [P]), "aa_pack_x2": (I, [P, I, P]), "aa_unpack_x2": (I, [P, I, P]),
         "aa_halo_doubles_dir": (LL, [P, I]), "aa_halo_get": (I, [P, I, I, dp]), "aa_halo_put": (I, [P, I, I, dp]), "aa_device_count": (I, []),
@@ -319,6 +321,24 @@ class Grid:
         return dt.value, bool(hit.value), a.value, b.value, n.value, h.value, bool(neg.value)
 
     def ion_finish(self): self._chk(self.L.aa_ion_finish(self._h))
+
+    def ion_radtransfer_3d_gather(self, dev_words: int, dev_words_all: int, nranks: int, gather) -> int:
+        """ion_radtransfer_3d of one rank of a multi-rank run in ONE call: `gather()` is the driver's all-gather of the
+        AA_ION_WORDS doubles at dev_words into dev_words_all, called once per pass on this Grid's stream."""
+        err = []
+
+        def cb(_ctx):
+            try:
+                gather(); return 0
+            except BaseException as e:      # an exception must not cross the C frames: hand it over afterwards
+                err.append(e); return 1
+        n = C.c_int()
+        rc = self.L.aa_ion_radtransfer_3d_gather(self._h, C.c_void_p(dev_words), C.c_void_p(dev_words_all), nranks, GATHER(cb), None, C.byref(n))
+        if err:
+            raise err[0]
+        self._chk(rc)
+        return n.value
+
     def host_syncs(self, reset: bool = False) -> int: return int(self.L.aa_host_syncs(self._h, int(reset)))
 
     def cfl_max_v(self):

@@ -149,14 +149,19 @@ def _run_ref(exe, deck, tmp, tag, nx, nlim, ranks):
     return float(m[-1]), its, wall     # the last line is the total over ranks (main.c:735)
 
 
-def cpu_baseline(nx=128, nlim=12):
+def cpu_baseline(nx=128, nlim=12, all_cores=False):
     """The reference's own MPI CPU path (oracle/_ref/athena_*_mpi: the unmodified sources built with
     MPI_PARALLEL by oracle/Makefile.ref) on the host cores of this box, on a bounded sample of the same
     deck: the coupled run, and the same deck without ion radiation, so that the cost of a hydro step and
     of a radiation sub-cycle can be stated separately (ns per zone), like the GPU's `phases`."""
     ref = os.path.join(ROOT, "oracle", "_ref")
     deck0 = os.path.join(ROOT, PKG, "decks", "athinput.ioniz_sphere")
-    cores = min(len(os.sched_getaffinity(0)), 16)      # a one-GPU box's CPU share
+    # N = 1: a one-GPU box's CPU share (16 cores; the boxes of the build pool have exactly those).  N > 1 (or AA_CPU_BASELINE_ALL=1):
+    # every core this process may run on -- north_star's "the GPU box's host cores" -- on a sample scaled with them
+    avail = len(os.sched_getaffinity(0))
+    cores = avail if (all_cores or os.environ.get("AA_CPU_BASELINE_ALL")) else min(avail, 16)
+    if cores > 32:
+        nx = 256
     tmp = tempfile.mkdtemp(prefix="cpu_baseline_")
     try:
         if os.path.exists(os.path.join(ref, "athena_ioniz_sphere_mpi")) and os.path.exists(MPIEXEC):
@@ -166,7 +171,7 @@ def cpu_baseline(nx=128, nlim=12):
                 txt = open(deck0).read().replace("<domain1>", f"<domain1>\nNGrid_x1 = 1\nNGrid_x2 = {p2}\nNGrid_x3 = {p3}", 1)
                 open(deck, "w").write(txt)
                 zc, its, wall = _run_ref(os.path.join(ref, "athena_ioniz_sphere_mpi"), deck, tmp, "ion", nx, nlim, p2 * p3)
-                out = {"value": zc, "unit": "cell-updates/s", "cores": p2 * p3, "kind": "reference-mpi",
+                out = {"value": zc, "unit": "cell-updates/s", "cores": p2 * p3, "cores_available": avail, "kind": "reference-mpi",
                        "sample": f"ioniz_sphere {nx}^3, {nlim} steps, NGrid 1x{p2}x{p3} (mpiexec -n {p2 * p3}), sub-cycles/step {its}, {wall:.1f} s wall"}
                 nsub = sum(its) / max(1, len(its))
                 out["nsub_mean"] = nsub
@@ -426,18 +431,95 @@ def run_window(c, strong, spinup, steps, warmup, nslab=1):
     return w
 
 
-def chain_traffic(a, w, world, names):
-    """HBM bytes per launch of the named kernels from the committed rocprofv3 PMC passes of this same command
-    (profiles/r03_traffic.json / r03_burst_traffic.json); only valid for the workload they were taken on."""
-    try:
-        tf = {"auto": "r03_traffic.json", "burst": "r03_burst_traffic.json", "19": "r03_burst_traffic.json"}.get(w["spinup"])
-        tj = json.load(open(os.path.join(ROOT, "profiles", tf)))
-        if tj.get("workload", "").startswith(f"{a.problem} {w['nx']}x{w['nx2']}x{w['nx3']}") and a.integrator == "ctu" and a.order == 2 \
-                and world == 1 and w["nslab"] == 1 and not a.ionized_slab and not a.strict:
-            return {k: tj["kernels"].get(k) for k in names}
-    except Exception:
-        pass
+KERNEL_SOURCES = ("hydro_kernels.hip", "hydro_dev.h", "ion_pass.hip", "ion_dev.h", "ion_kernels.hip", "grid.h")
+
+
+def source_fingerprint():
+    """sha256 over the kernel sources: a committed traffic profile carries the fingerprint it was taken on, and is stale -- not
+    quoted -- once a kernel has changed (tests/test_gpu_bench_contract.py fails then: re-run profiles/prof_r04.sh)."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in KERNEL_SOURCES:
+        h.update(open(os.path.join(ROOT, PKG, "csrc", f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+PMC = {}      # --pmc-pass: bytes per launch counted in THIS invocation (child processes under rocprofv3)
+TRAFFIC_FILES = {"auto": ("r04_traffic.json", "r03_traffic.json"), "burst": ("r04_burst_traffic.json", "r03_burst_traffic.json"),
+                 "19": ("r04_burst_traffic.json", "r03_burst_traffic.json")}
+
+
+def chain_traffic(a, w, world, names, meta=None):
+    """HBM bytes per launch of the named kernels: counted by this invocation's own rocprofv3 PMC passes (--pmc-pass), else from
+    the committed passes of this same command (profiles/r04_traffic.json / r04_burst_traffic.json) -- only for the workload
+    they were taken on and only while the kernel sources still have the fingerprint recorded with them."""
+    plain = a.integrator == "ctu" and a.order == 2 and world == 1 and w["nslab"] == 1 and not a.ionized_slab and not a.strict
+    if PMC.get("kernels") and plain and w["spinup"] == a.spinup:      # (the children ran this invocation's own window)
+        if meta is not None:
+            meta.update(kind="pmc-pass of this invocation", passes=PMC.get("passes"), seconds=PMC.get("seconds"))
+        return {k: PMC["kernels"].get(k) for k in names}
+    for tf in TRAFFIC_FILES.get(w["spinup"], ()):
+        try:
+            tj = json.load(open(os.path.join(ROOT, "profiles", tf)))
+        except Exception:
+            continue
+        if not (tj.get("workload", "").startswith(f"{a.problem} {w['nx']}x{w['nx2']}x{w['nx3']}") and plain):
+            return {}
+        fp = source_fingerprint()
+        stale = tj.get("source_fingerprint") != fp
+        if meta is not None:
+            meta.update(kind="committed profile", file="profiles/" + tf, profile_commit=tj.get("commit"),
+                        profile_source_fingerprint=tj.get("source_fingerprint"), source_fingerprint=fp, stale=stale)
+        return {} if stale else {k: tj["kernels"].get(k) for k in names}
     return {}
+
+
+def pmc_passes(argv):
+    """--pmc-pass: count the hydro chain's HBM bytes in this invocation.  Two CHILD processes, started before this one touches the
+    GPU, run this same script for three timed steps under `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` (separate passes: the TCC
+    counters do not fit together; the program directly behind `--`); the last three launches of every hydro kernel are averaged.
+    FETCH_SIZE x 2 per the gfx950 correction of MI355X_MICROARCH.md (HBM section), WRITE_SIZE exact, KiB."""
+    import csv
+    import glob
+    exe = shutil.which("rocprofv3")
+    if not exe:
+        sys.stderr.write("[bench] --pmc-pass: rocprofv3 is not on PATH; roofline.traffic stays with the committed profile\n")
+        return
+    keep = [x for x in argv if x not in ("--pmc-pass",)]
+    alias = (("k_flux2_update<", "flux2_update"), ("k_correct_all<", "correct_all"), ("k_eta_edges<", "correct_all"),
+             ("k_sweep_x1_flat<", "sweep_x1"), ("k_sweep_x1<", "sweep_x1"), ("k_sweep_march<1, 1,", "sweep_x2"), ("k_sweep_march<0, 1,", "sweep_x2"),
+             ("k_sweep_march<1, 2,", "sweep_x3"), ("k_sweep_march<0, 2,", "sweep_x3"))
+    tmp = tempfile.mkdtemp(prefix="bench_pmc_", dir="/tmp")
+    t0 = time.time()
+    got = {}
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(tmp, counter)
+            cmd = [exe, "--pmc", counter, "-d", d, "-o", "p", "--output-format", "csv", "--", sys.executable, os.path.abspath(__file__)] + keep + \
+                  ["--steps", "3", "--warmup", "1", "--no-burst", "--no-cpu-baseline", "--no-kernel-times", "--no-driver-window"]
+            env = dict(os.environ, TMPDIR="/tmp")
+            pr = subprocess.run(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True, cwd="/tmp", env=env, timeout=900)
+            f = glob.glob(d + "/**/*counter_collection.csv", recursive=True)
+            if pr.returncode != 0 or not f:
+                sys.stderr.write(f"[bench] --pmc-pass: the {counter} pass failed (rc {pr.returncode}): {pr.stderr[-300:]}\n")
+                return
+            per = {}
+            for r in csv.DictReader(open(f[0])):
+                per.setdefault(r["Kernel_Name"], []).append((int(r.get("Start_Timestamp", 0) or 0), float(r["Counter_Value"])))
+            acc = {}
+            for n, rows in per.items():
+                key = next((k for pat, k in alias if pat in n), None)
+                if key is None:
+                    continue
+                rows.sort()
+                last = [v for _, v in rows[-3:]]
+                acc[key] = acc.get(key, 0.0) + sum(last) / len(last)
+            got[counter] = acc
+        PMC["kernels"] = {k: (2.0 * got["FETCH_SIZE"].get(k, 0.0) + got["WRITE_SIZE"].get(k, 0.0)) * 1024.0 for k in got["FETCH_SIZE"]}
+        PMC["passes"] = "rocprofv3 --pmc FETCH_SIZE; --pmc WRITE_SIZE (children of this run, 3 timed steps each; fetch x2 per the gfx950 correction)"
+        PMC["seconds"] = time.time() - t0
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
 
 
 def analyse(c, w):
@@ -509,12 +591,14 @@ def analyse(c, w):
             ms_unit = 0.0
         if ms_unit > 0:
             ach = b_unit * zones_gpu / (ms_unit * 1e-3) / 1e9
-            tr = chain_traffic(a, w, world, names)
+            tmeta = {}
+            tr = chain_traffic(a, w, world, names, tmeta)
             per_unit = steps if unit_hydro else max(nsub_tot, 1)
             traffic = (sum(tr[k] * prof[k][1] for k in names) / per_unit) if tr and all(tr.get(k) is not None for k in names) else None
             rf = {"bound": "hbm", "kernel": names[0] if len(names) == 1 else "chain(" + "+".join(names) + ")", "achieved": ach,
                   "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
-                  "bytes_per_launch": b_unit * zones_gpu, "bytes_basis": unit, "avg_launch_ms": ms_unit}
+                  "bytes_per_launch": b_unit * zones_gpu, "bytes_basis": unit, "avg_launch_ms": ms_unit,
+                  "traffic_source": tmeta or None}
             if dom:
                 ms, n = prof[dom]
                 scale = (nvar / 6.0) if kernel_class(dom) == "hydro" else 1.0
@@ -601,6 +685,12 @@ def main():
     ap.add_argument("--ionized-slab", action="store_true",
                     help="SURVEY 8(d) worst case for the ray sweep: neutral fraction 1e-4 everywhere, so every ray crosses the whole box")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-driver-window", action="store_true",
+                    help="N=1: skip the windows that run the step as the RANKS of an N>1 job run it (driver.Driver.step with its collectives, "
+                         "one-rank communicator) -- `driver_path`: what the host side of the multi-GPU path costs against aa_step")
+    ap.add_argument("--pmc-pass", action="store_true",
+                    help="count roofline.traffic in this run: two child processes under rocprofv3 --pmc (FETCH_SIZE, WRITE_SIZE) before "
+                         "the timed windows; otherwise the committed profile is quoted while the kernel sources are unchanged")
     ap.add_argument("--no-kernel-times", action="store_true")
     a = ap.parse_args()
     if a.strong:
@@ -608,6 +698,8 @@ def main():
 
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ and not a.inlib:
         self_launch(a, sys.argv[1:])        # does not return
+    if a.pmc_pass and a.gpus == 1 and "WORLD_SIZE" not in os.environ and not a.smr and not a.inlib:
+        pmc_passes(sys.argv[1:])            # children under rocprofv3, before this process touches the GPU
 
     import torch
     aa = importlib.import_module(PKG)
@@ -677,10 +769,37 @@ def main():
                                         "hydro_ms_per_step": b.get("phases", {}).get("hydro", {}).get("ms_per_step"),
                                         "step_roofline_frac": b["step_roofline"]["frac"], "state_ok": b["state_check"]["ok"],
                                         "roofline": b.get("roofline")}}
+    if world == 1 and not multi and not a.no_driver_window:
+        # The same step as the RANKS of an N > 1 job run it: driver.Driver.step -- Python between the phases, the sub-cycle loop inside
+        # the library with the all-gather as its callback, new_dt's all-reduce -- on a one-rank communicator.  N = 1 above is ONE C
+        # call per step (aa_step); a future 1 -> N curve compares like with like only through this number.
+        try:
+            import torch.distributed as dist1
+            os.environ["AA_FORCE_DISTRIBUTED"] = "1"
+            init_pg(dist1, torch, 0, 1, local)
+            cd = Ctx(a, aa, driver, torch, dist1, 0, 1, local, True)
+            wd = run_window(cd, False, a.spinup, a.steps, a.warmup)
+            d = analyse(cd, wd)
+            dp = {"ms_per_step": d["ms_per_step"], "value": d["value"], "steps": d["steps"], "nsub": d["config"]["radiation_subcycles_per_step"],
+                  "host_path_overhead_ms": d["ms_per_step"] - out["ms_per_step"], "host_syncs_per_step": d["host_syncs_per_step"],
+                  "host_syncs_per_subcycle": d["host_syncs_per_subcycle"], "kernel_ms_per_step": d.get("kernel_ms_per_step"),
+                  "what": "driver.Driver.step on a one-rank communicator (backend %s): the host path of every rank of an N>1 job" % dist1.get_backend()}
+            if "regimes" in out and "burst" in out["regimes"] and "ms_per_step" in out["regimes"]["burst"]:
+                wdb = run_window(cd, False, "burst", min(6, a.steps), 0)
+                db = analyse(cd, wdb)
+                dp["burst"] = {"ms_per_step": db["ms_per_step"], "nsub": db["config"]["radiation_subcycles_per_step"],
+                               "host_path_overhead_ms": db["ms_per_step"] - out["regimes"]["burst"]["ms_per_step"],
+                               "host_syncs_per_subcycle": db["host_syncs_per_subcycle"]}
+            out["driver_path"] = dp
+            dist1.barrier(); dist1.destroy_process_group()
+        except Exception as e:
+            out["driver_path"] = {"error": f"{type(e).__name__}: {e}"[:300]}
+        finally:
+            os.environ.pop("AA_FORCE_DISTRIBUTED", None)
     if rank == 0:
-        if not a.no_cpu_baseline and world == 1:
+        if not a.no_cpu_baseline:
             try:
-                cb = cpu_baseline()
+                cb = cpu_baseline(all_cores=(world > 1))
             except Exception as e:
                 cb = {"value": None, "unit": "cell-updates/s", "cores": 0, "kind": "none", "sample": f"failed: {type(e).__name__}: {e}"[:300]}
             out["cpu_baseline"] = cb

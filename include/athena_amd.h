@@ -161,6 +161,14 @@ int aa_ion_pick(aa_grid *g, const double *dev_words_all, int nranks, int first, 
 int aa_ion_fetch(aa_grid *g, double *dt, int *limit_hit, double *dt_chem, double *dt_therm, long long *cellcount,
                  double *dt_hydro, int *neg_dt_chem);
 int aa_ion_finish(aa_grid *g);
+/* ion_radtransfer_3d (ionrad_3d.c:862-1047, root level) of a rank of a multi-rank run in ONE call: the loop above with the
+ * driver's collective as a callback.  `gather(ctx)` must all-gather this rank's AA_ION_WORDS doubles at dev_words into
+ * dev_words_all (nranks x AA_ION_WORDS, DEVICE memory) on the Grid's stream and return 0; it is called once per pass, between
+ * aa_ion_pass and aa_ion_pick.  pGrid->dt (aa_get_mesh_state) is cut back as the reference does (:985-1000, :1019-1023).
+ * gather == NULL: one rank (dev_words / dev_words_all may be NULL).  Needs the one-kernel sub-cycle (aa_ion_is_fused). */
+typedef int (*aa_gather_fn)(void *ctx);
+int aa_ion_radtransfer_3d_gather(aa_grid *g, double *dev_words, const double *dev_words_all, int nranks, aa_gather_fn gather,
+                                 void *ctx, int *niter);
 int aa_host_syncs(aa_grid *g, int reset);   /* stream synchronisations that returned scalars to the host so far */
 /* x3 halo: pack_ix3/pack_ox3/unpack_* (bvals_mhd.c:2608-3175).  side 0 = inner (ks..ks+3),
  * side 1 = outer; buffers are DEVICE pointers of aa_halo_doubles() doubles.                */

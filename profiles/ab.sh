@@ -5,7 +5,7 @@ mkdir -p gpurun_out
 for r in $(seq 1 ${ROUNDS:-2}); do
 for v in "$@"; do
   if [ "$v" = default ]; then unset ATHENA_AMD_VARIANT; else export ATHENA_AMD_VARIANT=$v; fi
-  timeout -k 10 300 python bench.py --spinup burst --steps 6 --warmup 2 --no-cpu-baseline --no-burst > gpurun_out/ab_$v.json 2> gpurun_out/ab_$v.err || { echo "$v FAILED"; tail -3 gpurun_out/ab_$v.err; continue; }
+  timeout -k 10 300 python bench.py --spinup burst --steps 6 --warmup 2 --no-cpu-baseline --no-burst --no-driver-window > gpurun_out/ab_$v.json 2> gpurun_out/ab_$v.err || { echo "$v FAILED"; tail -3 gpurun_out/ab_$v.err; continue; }
   python - "$v" <<'P'
 import json, sys
 v = sys.argv[1]

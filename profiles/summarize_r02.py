@@ -11,11 +11,21 @@ usage: summarize_r02.py <trace_dir> <fetch_dir> <write_dir> <zones> <steps> <wor
 import csv
 import glob
 import json
+import os
 import re
 import sys
 from collections import defaultdict
 
 trace, fetch, write, zones, steps, workload, out_md, out_json = sys.argv[1:9]
+
+
+def _fp():
+    """the kernel sources' fingerprint (bench.source_fingerprint): bench.py quotes these bytes only while it still matches"""
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    return bench.source_fingerprint()
+
+
 zones = float(zones); steps = int(steps)
 
 # kernel name (rocprof) -> name used by bench.py's hipEvent profiler; several kernels may share a bench name (the
@@ -113,5 +123,6 @@ with open(out_md, "w") as o:
 json.dump({"_comment": "HBM bytes per launch of bench.py's kernel names (ion_pass = one updating pass incl. its reduce / pick kernels) from rocprofv3 --pmc "
                        "FETCH_SIZE / WRITE_SIZE, separate passes, over the timed region; FETCH_SIZE doubled per the gfx950 correction of "
                        "MI355X_MICROARCH.md (HBM section); KiB -> bytes",
-           "workload": workload, "kernels": {k: v / main_launches[k][1] for k, v in sorted(traffic.items())}}, open(out_json, "w"), indent=1)
+           "workload": workload, "source_fingerprint": _fp(), "commit": os.environ.get("AA_COMMIT"),
+           "kernels": {k: v / main_launches[k][1] for k, v in sorted(traffic.items())}}, open(out_json, "w"), indent=1)
 print(open(out_md).read())

@@ -65,7 +65,7 @@ def test_second_window_times_the_burst_regime():
     """N = 1: after the headline window a second Driver is spun up to the first burst of radiation sub-cycles behind the
     dt-doubling phase and a few steps are timed there, so that the sub-cycle kernel's roofline fraction on 64 B per cell is a
     number of the driver's own run (`regimes.burst`)."""
-    d = run_bench("--nx", "64", "--steps", "3", "--warmup", "1", "--spinup", "2", "--burst-window", "--no-cpu-baseline")
+    d = run_bench("--nx", "64", "--steps", "3", "--warmup", "1", "--spinup", "2", "--burst-window", "--no-cpu-baseline", "--no-driver-window")
     b = d["regimes"]["burst"]
     assert d["regimes"]["stationary"]["ms_per_step"] == d["ms_per_step"]
     assert b["steps"] == 3 and b["spinup_steps"] >= 4 and b["nsub"] >= 2 and b["ms_per_step"] > 0
@@ -96,7 +96,7 @@ def test_slabs_inside_the_library_as_a_bench_mode():
     """--inlib N: one process, aa_params.nslab = N (csrc/slabs.hip), the path of the drop-in executables; rehearsed with both
     slabs on the one device.  The radiation sub-cycle may cost ONE host round trip there too."""
     d = run_bench("--inlib", "2", "--nx", "64", "--steps", "2", "--warmup", "1", "--spinup", "2", "--no-cpu-baseline")
-    one = run_bench("--nx", "64", "--steps", "2", "--warmup", "1", "--spinup", "2", "--no-cpu-baseline")
+    one = run_bench("--nx", "64", "--steps", "2", "--warmup", "1", "--spinup", "2", "--no-cpu-baseline", "--no-driver-window")
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and "inside the library" in d["config"]["partition"]
     assert d["config"]["subcycle_trace"] == one["config"]["subcycle_trace"] and d["state_check"]["ok"] is True
     assert abs(d["state_check"]["mass_after"] / one["state_check"]["mass_after"] - 1) < 1e-12
@@ -106,7 +106,7 @@ def test_slabs_inside_the_library_as_a_bench_mode():
 def test_other_workloads_keep_the_contract():
     for args in (("--problem", "blast", "--nx", "48"), ("--smr", "--nx", "32"), ("--integrator", "vl", "--nx", "48"), ("--order", "3", "--nx", "48"),
                  ("--strict", "--nx", "48")):
-        d = run_bench(*args, "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--spinup", "1")
+        d = run_bench(*args, "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--spinup", "1", "--no-driver-window")
         assert d["value"] > 0 and d["roofline"]["achieved"] > 0 and "workload" in d["config"]
 
 
@@ -115,7 +115,7 @@ def test_two_ranks_rehearsed_on_one_gpu(strong):
     """The N>1 path of bench.py (torchrun, one rank per GPU) with both ranks on cuda:0 over gloo: not a measurement,
     but every collective of the real run is issued.  The radiation sub-cycle may cost ONE host round trip."""
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
-    d = run_bench("--gpus", "2", "--nx", "64", "--steps", "2", "--warmup", "1", "--spinup", "2", *(("--strong",) if strong else ()),
+    d = run_bench("--gpus", "2", "--nx", "64", "--steps", "2", "--warmup", "1", "--spinup", "2", *(("--strong",) if strong else ("--no-cpu-baseline",)),
                   env={"AA_BENCH_REHEARSAL": "1"},
                   launcher=("-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
                             "--master-port", str(port)))
@@ -124,6 +124,9 @@ def test_two_ranks_rehearsed_on_one_gpu(strong):
     assert d["config"]["zones_per_gpu"] == (64 ** 3 // 2 if strong else 64 ** 3)
     assert d["state_check"]["ok"] is True
     assert d["host_syncs_per_subcycle"] <= 1.0 + 1e-9, d["host_syncs_per_subcycle"]
+    if strong:      # N > 1: the CPU leg uses every core this process may run on, and says how many
+        c = d["cpu_baseline"]
+        assert c["cores"] >= 1 and c["value"] > 0 and ("cores_available" not in c or c["cores"] <= c["cores_available"])
 
 
 def test_two_ranks_rehearsed_on_one_gpu_smr():
@@ -143,7 +146,7 @@ def test_one_rank_over_rccl():
     memory all go through RCCL (the point-to-point halo needs a second GPU and stays unrehearsed on this backend).
     Same answer as the plain one-GPU run."""
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
-    args = ("--nx", "64", "--steps", "2", "--warmup", "1", "--spinup", "2", "--no-cpu-baseline")
+    args = ("--nx", "64", "--steps", "2", "--warmup", "1", "--spinup", "2", "--no-cpu-baseline", "--no-driver-window")
     d = run_bench(*args, env={"AA_FORCE_DISTRIBUTED": "1", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "RANK": "0",
                               "WORLD_SIZE": "1", "LOCAL_RANK": "0"})
     one = run_bench(*args)
@@ -160,7 +163,39 @@ def test_two_ranks_as_pencils():
                   env={"AA_BENCH_REHEARSAL": "1"},
                   launcher=("-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
                             "--master-port", str(port)))
-    one = run_bench("--nx", "64", "--steps", "2", "--warmup", "1", "--spinup", "2", "--no-cpu-baseline")
+    one = run_bench("--nx", "64", "--steps", "2", "--warmup", "1", "--spinup", "2", "--no-cpu-baseline", "--no-driver-window")
     assert d["n_gpus"] == 2 and "pencils 2x1" in d["config"]["partition"] and d["state_check"]["ok"] is True
     assert d["config"]["subcycle_trace"] == one["config"]["subcycle_trace"]
     assert abs(d["state_check"]["mass_after"] / one["state_check"]["mass_after"] - 1) < 1e-9
+
+
+def test_driver_path_window_beside_the_aa_step_line():
+    """N = 1 runs ONE C call per step (aa_step); the ranks of an N > 1 job run driver.Driver.step -- Python between the phases, the
+    sub-cycle loop inside the library with the all-gather as its callback (aa_ion_radtransfer_3d_gather), new_dt's all-reduce.  The
+    same invocation times that path too, on a one-rank RCCL communicator (`driver_path`), so that a 1 -> N curve can be read like
+    for like: same sub-cycle counts, ONE host round trip per sub-cycle, and what the host side costs per step."""
+    d = run_bench("--nx", "64", "--steps", "3", "--warmup", "1", "--spinup", "2", "--burst-window", "--no-cpu-baseline")
+    p = d["driver_path"]
+    assert "error" not in p, p
+    assert p["steps"] == 3 and p["ms_per_step"] > 0 and p["nsub"] == d["config"]["radiation_subcycles_per_step"]
+    assert abs(p["host_path_overhead_ms"] - (p["ms_per_step"] - d["ms_per_step"])) < 1e-9
+    assert p["host_syncs_per_subcycle"] <= 1.0 + 1e-9 and "nccl" in p["what"]
+    assert p["burst"]["nsub"] == d["regimes"]["burst"]["nsub"] and p["burst"]["host_syncs_per_subcycle"] <= 1.0 + 1e-9
+    # the sub-cycle loop as Python wrote it before (three crossings per sub-cycle) still gives the same run
+    q = run_bench("--nx", "64", "--steps", "3", "--warmup", "1", "--spinup", "2", "--no-burst", "--no-cpu-baseline",
+                  env={"AA_DRIVER_PY_SUBCYCLES": "1"})["driver_path"]
+    assert q["nsub"] == p["nsub"] and q["host_syncs_per_subcycle"] <= 1.0 + 1e-9
+
+
+def test_traffic_is_quoted_with_its_source():
+    """roofline.traffic comes from the committed PMC passes of this command only while the kernel sources still have the fingerprint
+    recorded with them (`traffic_source`); --pmc-pass counts it in the run itself (children under rocprofv3)."""
+    import shutil
+    d = run_bench("--nx", "64", "--steps", "2", "--warmup", "1", "--spinup", "2", "--no-burst", "--no-cpu-baseline", "--no-driver-window")
+    assert d["roofline"]["traffic"] is None                     # (no profile of a 64^3 workload is committed)
+    if shutil.which("rocprofv3"):
+        d = run_bench("--nx", "64", "--steps", "2", "--warmup", "1", "--spinup", "2", "--no-burst", "--no-cpu-baseline", "--no-driver-window",
+                      "--pmc-pass")
+        r = d["roofline"]
+        assert r["traffic_source"]["kind"].startswith("pmc-pass") and r["traffic"] > r["bytes_per_launch"] > 0
+        assert r["traffic"] < 40 * r["bytes_per_launch"]

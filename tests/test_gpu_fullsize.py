@@ -192,3 +192,26 @@ def test_the_two_builds_agree_at_256_cubed():
     xa = 1.0 - A[..., 5] / A[..., 0]; xb = 1.0 - B[..., 5] / B[..., 0]
     print("256^3 default vs strict build, 4 steps: max rel err per field", err, "ion fraction", np.abs(xa - xb).max())
     assert err.max() < 1e-8 and np.abs(xa - xb).max() < 1e-8
+
+
+def test_driver_path_agrees_with_aa_step_at_512():
+    """bench.py's two N = 1 host paths at the headline size: ONE C call per step (aa_step) and the loop as the ranks of an N > 1
+    job run it (driver.Driver.step on a one-rank RCCL communicator).  Where the step takes ONE radiation sub-cycle they must agree
+    within 2 % (the kernels are the same; the rest is a dozen Python -> C crossings and two tiny collectives per step); the
+    burst-window difference (dozens of sub-cycles per step, one callback each) is reported."""
+    import json
+    import subprocess
+    import sys
+    pr = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "10", "--warmup", "3", "--no-cpu-baseline"],
+                        stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, cwd=ROOT, timeout=1200)
+    assert pr.returncode == 0, pr.stderr[-2000:]
+    d = json.loads([ln for ln in pr.stdout.splitlines() if ln.strip().startswith("{")][-1])
+    p = d["driver_path"]
+    assert "error" not in p, p
+    print(f"aa_step {d['ms_per_step']:.2f} ms/step, Driver.step {p['ms_per_step']:.2f} ({p['host_path_overhead_ms']:+.2f}); burst window "
+          f"{d['regimes']['burst']['ms_per_step']:.1f} against {p['burst']['ms_per_step']:.1f} ({p['burst']['host_path_overhead_ms']:+.2f} ms at "
+          f"{p['burst']['nsub']:.1f} sub-cycles per step)")
+    assert p["nsub"] == d["config"]["radiation_subcycles_per_step"]
+    if p["nsub"] == 1.0:
+        assert abs(p["ms_per_step"] / d["ms_per_step"] - 1.0) < 0.02, (p["ms_per_step"], d["ms_per_step"])
+    assert p["burst"]["host_syncs_per_subcycle"] <= 1.0 + 1e-9

@@ -5,6 +5,7 @@ import ctypes as C
 import importlib
 import os
 import re
+import sys
 
 import numpy as np
 import pytest
@@ -255,3 +256,15 @@ def test_boundary_docs_match_the_shim():
     assert row.split("|")[2].strip() == m.group(1)
     assert "dir = -1 (rays along +x1) or -2" in hdr and "dir must be -1" not in hdr
     assert "nslab > 1" in hdr and "AA_NGPU" in doc
+
+
+def test_committed_traffic_profile_belongs_to_the_kernel_sources():
+    """bench.py quotes roofline.traffic from profiles/r04_traffic.json only while the kernel sources have the fingerprint recorded in
+    it; a kernel change without a new `profiles/prof_r04.sh` run must not pass unnoticed."""
+    import json
+    sys.path.insert(0, ROOT)
+    import bench
+    for f in ("r04_traffic.json", "r04_burst_traffic.json"):
+        tj = json.load(open(os.path.join(ROOT, "profiles", f)))
+        assert tj["source_fingerprint"] == bench.source_fingerprint(), f"profiles/{f} was taken on other kernel sources: re-run profiles/prof_r04.sh"
+        assert tj["workload"].startswith("ioniz_sphere 512x512x512")
