@@ -149,17 +149,20 @@ def _run_ref(exe, deck, tmp, tag, nx, nlim, ranks):
     return float(m[-1]), its, wall     # the last line is the total over ranks (main.c:735)
 
 
-def cpu_baseline(nx=128, nlim=12, all_cores=False):
+def cpu_baseline(nx=128, nlim=12, gpus=1):
     """The reference's own MPI CPU path (oracle/_ref/athena_*_mpi: the unmodified sources built with
     MPI_PARALLEL by oracle/Makefile.ref) on the host cores of this box, on a bounded sample of the same
     deck: the coupled run, and the same deck without ion radiation, so that the cost of a hydro step and
     of a radiation sub-cycle can be stated separately (ns per zone), like the GPU's `phases`."""
     ref = os.path.join(ROOT, "oracle", "_ref")
     deck0 = os.path.join(ROOT, PKG, "decks", "athinput.ioniz_sphere")
-    # N = 1: a one-GPU box's CPU share (16 cores; the boxes of the build pool have exactly those).  N > 1 (or AA_CPU_BASELINE_ALL=1):
-    # every core this process may run on -- north_star's "the GPU box's host cores" -- on a sample scaled with them
+    # The host cores that belong to the GPUs of this job: 16 per GPU (a one-GPU box's CPU share; its affinity mask shows the whole
+    # host, whose other cores belong to other boxes), i.e. 16 N of an N-GPU node -- north_star's "the GPU box's host cores" --
+    # on a sample scaled with them.  AA_CPU_BASELINE_CORES overrides.
     avail = len(os.sched_getaffinity(0))
-    cores = avail if (all_cores or os.environ.get("AA_CPU_BASELINE_ALL")) else min(avail, 16)
+    cores = min(avail, 16 * max(1, 1 if REHEARSAL else gpus))
+    if os.environ.get("AA_CPU_BASELINE_CORES"):
+        cores = max(1, min(avail, int(os.environ["AA_CPU_BASELINE_CORES"])))
     if cores > 32:
         nx = 256
     tmp = tempfile.mkdtemp(prefix="cpu_baseline_")
@@ -799,7 +802,7 @@ def main():
     if rank == 0:
         if not a.no_cpu_baseline:
             try:
-                cb = cpu_baseline(all_cores=(world > 1))
+                cb = cpu_baseline(gpus=world)
             except Exception as e:
                 cb = {"value": None, "unit": "cell-updates/s", "cores": 0, "kind": "none", "sample": f"failed: {type(e).__name__}: {e}"[:300]}
             out["cpu_baseline"] = cb
