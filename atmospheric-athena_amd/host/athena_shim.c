@@ -14,6 +14,17 @@
  * MPI_Allreduce(MIN) (new_dt.c:177) and the radiation sub-cycle with the reference's own two rounds of reductions
  * (ionrad_3d.c:275,399,554,672).  HIP device of a rank: AA_DEVICE, else rank modulo the visible devices.
  *
+ * -DAA_MPI and -DAA_SMR together (the reference's README.rst:25 configuration, --enable-mpi ... --enable-smr): every rank holds at
+ * most one Grid per Domain (init_mesh.c:583-700) and drives them as ONE stack of nested slabs on its GPU (aa_mesh_create_local).
+ * Supported decompositions: one Domain per level, every Domain cut along x3 only (NGrid_x1 = NGrid_x2 = 1), and the Grids a rank
+ * holds nested in each other -- the child slab of a rank lies over that rank's parent slab, which the reference's equal division
+ * gives when a refined Domain is centred on the cuts of its parent (two ranks) or spans the whole x3 extent (any number).  Then
+ * RestrictCorrect, Prolongate, ionradRestrictCorrect and the coarse -> fine radiation hand-off never leave the rank
+ * (smr.c:136,176,1169,1191 and ionrad_smr.c:105,122,452 exchange with a rank's own Grids only); what crosses ranks is the x3 halo
+ * of every level in its Domain's communicator (bvals_mhd.c:423-493), new_dt's MIN (new_dt.c:177; max_v carried from Grid to
+ * Grid on each rank first, :33, as the reference does) and the sub-cycle reductions of each level in its Comm_Domain
+ * (ionrad_3d.c:275,399,554,672).  Anything else is refused with a message.  Host/device coherence: `step` only.
+ *
  * Host/device coherence (the reference's problem files and outputs index pG->U on the host):
  *   AA_COHERENCE=step  (default) the host block is refreshed after Integrate() (so that
  *                      Userwork_in_loop sees and may edit it; re-uploaded before new_dt) and
@@ -58,18 +69,21 @@ extern double par_getd_def(char *block, char *name, double def);
 extern int par_geti_def(char *block, char *name, int def);
 extern int par_exist(char *block, char *name);
 extern void ath_error(char *fmt, ...);
+#define MAXLEV 16
 #ifdef AA_MPI
 #ifdef AA_SMR
-#error "AA_MPI and AA_SMR together are not built: nested levels stay on one GPU"
+#define AA_MPISMR 1
 #endif
 extern int myID_Comm_world;                 /* globals.h:27 */
-static MPI_Comm comm_dom;                   /* pD->Comm_Domain of the root Domain */
-static int nb_id[4] = {-1, -1, -1, -1};     /* lx2, rx2, lx3, rx3 neighbour Grids (ID_Comm_Domain; -1: none) */
-static double *hbuf[2][2][2];               /* [dir - 1][side][send, recv] host buffers of the halo */
-static int nranks_dom = 1;
+static MPI_Comm comm_lev[MAXLEV];           /* pD->Comm_Domain of every Domain this rank holds a Grid of */
+static int nb_lev[MAXLEV][4];               /* lx2, rx2, lx3, rx3 neighbour Grids in that communicator (ID_Comm_Domain; -1: none) */
+static double *hbuf[MAXLEV][2][2][2];       /* [level][dir - 1][side][send, recv] host buffers of the halo */
+static int nranks_lev[MAXLEV];
+#define comm_dom comm_lev[0]
+#define nb_id nb_lev[0]
+#define nranks_dom nranks_lev[0]
 #endif
 
-#define MAXLEV 16
 static int NL = 0;                          /* Grids: one per Domain, level by level (1 without SMR) */
 static int LBASE[MAXLEV + 1];               /* index of the first Domain of a level in that order */
 #define GI(pD) (LBASE[(pD)->Level] + (pD)->DomNumber)
@@ -79,6 +93,12 @@ static MeshS *M = NULL, *M0 = NULL;
 #ifdef AA_SMR
 static aa_mesh *MM = NULL;
 #endif
+#ifdef AA_MPISMR
+static int LI[MAXLEV];              /* Domain index -> place in this rank's stack of nested slabs (aa_mesh_create_local) */
+static int NLOC = 0;
+static double tcoarse_ = 0.0;       /* ionrad_3d.c:44 */
+#endif
+#define HAVE(l) (G[l] != NULL)      /* (MPI + SMR: a rank need not hold a Grid of every Domain) */
 static int host_newer[MAXLEV];      /* the host block of this level holds data the device has not seen */
 static int active_same[MAXLEV];     /* host and device agree on the ACTIVE zones of this level (only ghost zones may differ) */
 static int learn = 0, learned = 0, sync_every = 1;
@@ -181,27 +201,37 @@ static void ensure_grid(MeshS *pM)
   env = getenv("AA_SYNC_EVERY"); sync_every = env ? atoi(env) : 1; if (sync_every < 1) sync_every = 1;
   for (l = 0; l < LBASE[pM->NLevels]; l++) {
     { int nl_ = 0; while (LBASE[nl_ + 1] <= l) nl_++; pD = &pM->Domain[nl_][l - LBASE[nl_]]; irefine = 1 << nl_; }
-    PG[l] = pD->Grid;
+    PG[l] = pD->Grid; G[l] = NULL;
 #ifdef AA_MPI
     if (pD->NGrid[0] != 1) ath_error("[athena_amd]: NGrid_x1 = %d: x1 is never cut (the rays travel along it)\n", pD->NGrid[0]);
-    comm_dom = pD->Comm_Domain;
-    MPI_Comm_size(comm_dom, &nranks_dom);
+#ifdef AA_MPISMR
+    if (pD->NGrid[1] != 1) ath_error("[athena_amd]: MPI + SMR: NGrid_x2 = %d in <domain%d>: nested levels are cut along x3 only\n", pD->NGrid[1], pD->InputBlock);
+    if (pM->DomainsPerLevel[pD->Level] != 1) ath_error("[athena_amd]: MPI + SMR: several Domains on level %d are not cut across ranks\n", pD->Level);
+    if (PG[l] == NULL) {                              /* this rank holds no Grid of this Domain (and then of no finer one: checked below) */
+      if (l == 0) ath_error("[athena_amd]: this rank holds no Grid of the root Domain\n");
+      continue;
+    }
+#endif
+    comm_lev[l] = pD->Comm_Domain;
+    MPI_Comm_size(comm_lev[l], &nranks_lev[l]);
     { /* bvals_init (bvals_mhd.c:537-821, which this shim replaces): on a periodic Domain the Grids at either end of a
        * direction are each other's neighbours */
       int L = -1, Mi = -1, Ni = -1, a, b, c;
       for (c = 0; c < pD->NGrid[2]; c++) for (b = 0; b < pD->NGrid[1]; b++) for (a = 0; a < pD->NGrid[0]; a++)
         if (pD->GData[c][b][a].ID_Comm_world == myID_Comm_world) { L = a; Mi = b; Ni = c; }
       if (L < 0) ath_error("[athena_amd]: this rank holds no Grid of the root Domain\n");
+      if (pD->Level > 0) { /* (a refined Domain has no periodic wrap of its own) */ }
+      else
       if (pM->BCFlag_ix2 == 4 && pM->BCFlag_ox2 == 4 && pD->NGrid[1] > 1) {
         if (Mi == 0 && PG[l]->lx2_id < 0) PG[l]->lx2_id = pD->GData[Ni][pD->NGrid[1] - 1][L].ID_Comm_Domain;
         if (Mi == pD->NGrid[1] - 1 && PG[l]->rx2_id < 0) PG[l]->rx2_id = pD->GData[Ni][0][L].ID_Comm_Domain;
       }
-      if (pM->BCFlag_ix3 == 4 && pM->BCFlag_ox3 == 4 && pD->NGrid[2] > 1) {
+      if (pD->Level == 0 && pM->BCFlag_ix3 == 4 && pM->BCFlag_ox3 == 4 && pD->NGrid[2] > 1) {
         if (Ni == 0 && PG[l]->lx3_id < 0) PG[l]->lx3_id = pD->GData[pD->NGrid[2] - 1][Mi][L].ID_Comm_Domain;
         if (Ni == pD->NGrid[2] - 1 && PG[l]->rx3_id < 0) PG[l]->rx3_id = pD->GData[0][Mi][L].ID_Comm_Domain;
       }
     }
-    nb_id[0] = PG[l]->lx2_id; nb_id[1] = PG[l]->rx2_id; nb_id[2] = PG[l]->lx3_id; nb_id[3] = PG[l]->rx3_id;
+    nb_lev[l][0] = PG[l]->lx2_id; nb_lev[l][1] = PG[l]->rx2_id; nb_lev[l][2] = PG[l]->lx3_id; nb_lev[l][3] = PG[l]->rx3_id;
 #else
     if (pD->NGrid[0]*pD->NGrid[1]*pD->NGrid[2] != 1) ath_error("[athena_amd]: one Grid per Domain only\n");
 #endif
@@ -220,9 +250,14 @@ static void ensure_grid(MeshS *pM)
       if ((pD->Disp[d] + pD->Nx[d])/irefine != pM->Nx[d]) p.bc[2*d + 1] = 0;
     }
 #ifdef AA_MPI
-    for (d = 0; d < 4; d++) if (nb_id[d] >= 0) p.bc[2 + d] = 0;     /* a neighbour Grid fills these ghost zones */
+    for (d = 0; d < 4; d++) if (nb_lev[l][d] >= 0) p.bc[2 + d] = 0;     /* a neighbour Grid fills these ghost zones */
     p.nslab = 1;                                   /* the reference's ranks ARE the decomposition */
-    if (nranks_dom > 1) p.ion_path = 2;            /* the two-kernel sub-cycle: its reductions sit where the reference's are */
+    if (nranks_lev[l] > 1) p.ion_path = 2;         /* the two-kernel sub-cycle: its reductions sit where the reference's are */
+#ifdef AA_MPISMR
+    p.ion_path = 2;                                /* ... on every level (the levels of a rank's stack use one protocol) */
+    /* a Grid inside its Domain: the fine/coarse sides are those of the DOMAIN (above, pD->Disp); an x3 side that is a cut between
+     * two Grids of the Domain is filled by the halo exchange */
+#endif
 #endif
     p.level = pD->Level;
 #ifdef AA_SMR
@@ -272,7 +307,44 @@ static void ensure_grid(MeshS *pM)
             p.Nx[0], p.Nx[1], p.Nx[2], l, p.device, aa_device_bytes(G[l])/1e9, automode ? "auto" : (learn ? "learn" : "step"));
   }
   NL = LBASE[pM->NLevels];
-#ifdef AA_SMR
+#ifdef AA_MPISMR
+  {
+    /* this rank's stack: the Grids it holds, root first, each nested in the one before (links as config.mesh_slabs /
+     * aa_mesh_create_local want them: the child's overlap on the parent in local parent indices incl. ghost zones, zones per
+     * direction, which of its six sides are fine/coarse boundaries of the LEVEL (prolonged) and corrected on this rank) */
+    aa_grid *loc[MAXLEV]; int links[21*MAXLEV]; int nloc = 0;
+    (void)disp;
+    if (learn) { fprintf(stderr, "[athena_amd] MPI + SMR: AA_COHERENCE=step (auto / learn are one-process modes)\n"); learn = 0; automode = 0; }
+    for (l = 0; l < NL; l++) {
+      if (!HAVE(l)) { LI[l] = -1; continue; }
+      if (l > 0 && !HAVE(l - 1)) ath_error("[athena_amd]: MPI + SMR: this rank holds a Grid of level %d but none of level %d\n", l, l - 1);
+      LI[l] = nloc; loc[nloc++] = G[l];
+    }
+    for (l = 0; l + 1 < nloc; l++) {
+      const GridS *P = PG[l], *C = PG[l + 1]; const DomainS *cD = &pM->Domain[l + 1][0];
+      int *q = links + 21*l; const int ir = 1 << (l + 1);
+      for (d = 0; d < 3; d++) {
+        const int a = C->Disp[d]/2 - P->Disp[d], b = (C->Disp[d] + C->Nx[d])/2 - P->Disp[d];
+        const int glo = cD->Disp[d], ghi = cD->Disp[d] + cD->Nx[d];
+        const int at_lo = (C->Disp[d] == glo) && glo != 0;
+        const int at_hi = (C->Disp[d] + C->Nx[d] == ghi) && (ghi/ir != pM->Nx[d]);
+        if ((C->Disp[d] & 1) || (C->Nx[d] & 1) || a < 0 || b > P->Nx[d])
+          ath_error("[athena_amd]: MPI + SMR: the level-%d Grid of this rank (x%d zones %d..%d) does not lie over its level-%d Grid (%d..%d): "
+                    "choose NGrid_x3 so that every rank's Grids are nested (DESIGN.md 5)\n", l + 1, d + 1, C->Disp[d]/2, (C->Disp[d] + C->Nx[d])/2,
+                    l, P->Disp[d], P->Disp[d] + P->Nx[d]);
+        /* a fine/coarse boundary of the level that coincides with a cut of the parent would be corrected on the neighbouring rank
+         * (aa_flux_x3_export / _apply): the reference's equal division of every Domain cannot produce it with nested Grids */
+        if (d == 2 && ((at_lo && a == 0) || (at_hi && b == P->Nx[d])))
+          ath_error("[athena_amd]: MPI + SMR: level %d ends exactly on a cut of level %d along x3: not supported\n", l + 1, l);
+        q[d] = a + AA_NGHOST; q[3 + d] = b - a;
+        q[6 + 2*d] = at_lo; q[6 + 2*d + 1] = at_hi; q[12 + 2*d] = at_lo; q[12 + 2*d + 1] = at_hi;
+        q[18 + d] = C->Disp[d] - 2*P->Disp[d];
+      }
+    }
+    NLOC = nloc;
+    CHK(aa_mesh_create_local(nloc, loc, links, &MM));
+  }
+#elif defined(AA_SMR)
   CHK(aa_mesh_create(NL, G, disp, &MM));
 #else
   (void)disp;
@@ -281,6 +353,7 @@ static void ensure_grid(MeshS *pM)
 
 static void to_device(int l)
 {
+  if (!HAVE(l)) return;
   if (host_newer[l]) { CHK(aa_upload_cons(G[l], host_block(l))); host_newer[l] = 0; active_same[l] = 1; }
   CHK(aa_set_mesh_state(G[l], M->time, PG[l]->dt, M->nstep));
 }
@@ -289,7 +362,8 @@ static void to_device(int l)
  * travelled (active_same): then the ghost shell is all that differs */
 static void to_host_x(int l, int ghosts_only)
 {
-  static int shell_ok = -1;      /* AA_GHOST_REFRESH=0: always the whole block (A/B measurements) */
+  static int shell_ok = -1;
+  if (!HAVE(l)) return;      /* AA_GHOST_REFRESH=0: always the whole block (A/B measurements) */
   if (shell_ok < 0) { const char *e = getenv("AA_GHOST_REFRESH"); shell_ok = !(e && atoi(e) == 0); }
   if (shell_ok && ghosts_only && active_same[l] && !host_newer[l]) CHK(aa_download_ghost_zones(G[l], host_block(l)));
   else CHK(aa_download_cons(G[l], host_block(l)));
@@ -304,6 +378,7 @@ static void to_host(int l) { to_host_x(l, 0); }
 /* after the integrator (and, with SMR, RestrictCorrect): Userwork_in_loop reads and may write pG->U */
 static void refresh_for_userwork(int l)
 {
+  if (!HAVE(l)) return;
   if (learn && learned && automode && l == 0) {        /* is this a step on which the imprint is looked at again? */
     verify_now = verify_next || (++steps_since_reval >= reval_every);
     verify_next = 0;
@@ -348,7 +423,7 @@ void integrate_destruct(void)
 #endif
   for (l = 0; l < NL; l++) { if (G[l]) { aa_destroy(G[l]); G[l] = NULL; } free(snap[l]); snap[l] = NULL; }
 #ifdef AA_MPI
-  { int a, b, c; for (a = 0; a < 2; a++) for (b = 0; b < 2; b++) for (c = 0; c < 2; c++) { free(hbuf[a][b][c]); hbuf[a][b][c] = NULL; } }
+  { int a, b, c; for (l = 0; l < MAXLEV; l++) for (a = 0; a < 2; a++) for (b = 0; b < 2; b++) for (c = 0; c < 2; c++) { free(hbuf[l][a][b][c]); hbuf[l][a][b][c] = NULL; } }
 #endif
   NL = 0;
 }
@@ -406,22 +481,23 @@ static void refresh_for_output(void)
 /* bvals_mhd.c:296-493 for one direction (dir 1 = x2, 2 = x3): the four planes either side travel between neighbouring Grids.
  * Tag = the way the message travels (down / up), so that two Grids that are each other's neighbour on both sides (periodic
  * Domain cut in two) keep their messages apart. */
-static void halo_exchange(int dir)
+static void halo_exchange(int l, int dir)
 {
-  const int lo = nb_id[2*(dir - 1)], hi = nb_id[2*(dir - 1) + 1];
-  const long long n = aa_halo_doubles_dir(G[0], dir);
+  const int lo = nb_lev[l][2*(dir - 1)], hi = nb_lev[l][2*(dir - 1) + 1];
+  const long long n = aa_halo_doubles_dir(G[l], dir);
   MPI_Request rq[4]; MPI_Status st[4]; int nrq = 0, side, w;
+  double *(*hb)[2] = hbuf[l][dir - 1];
   if (lo < 0 && hi < 0) return;
   for (side = 0; side < 2; side++) for (w = 0; w < 2; w++)
-    if (!hbuf[dir - 1][side][w] && !(hbuf[dir - 1][side][w] = (double*)malloc((size_t)n*sizeof(double))))
+    if (!hb[side][w] && !(hb[side][w] = (double*)malloc((size_t)n*sizeof(double))))
       ath_error("[athena_amd]: out of host memory for the MPI halo buffers\n");
-  if (lo >= 0) MPI_Irecv(hbuf[dir - 1][0][1], (int)n, MPI_DOUBLE, lo, 100 + 2*dir + 1, comm_dom, &rq[nrq++]);   /* travelled up   */
-  if (hi >= 0) MPI_Irecv(hbuf[dir - 1][1][1], (int)n, MPI_DOUBLE, hi, 100 + 2*dir,     comm_dom, &rq[nrq++]);   /* travelled down */
-  if (lo >= 0) { CHK(aa_halo_get(G[0], dir, 0, hbuf[dir - 1][0][0])); MPI_Isend(hbuf[dir - 1][0][0], (int)n, MPI_DOUBLE, lo, 100 + 2*dir, comm_dom, &rq[nrq++]); }
-  if (hi >= 0) { CHK(aa_halo_get(G[0], dir, 1, hbuf[dir - 1][1][0])); MPI_Isend(hbuf[dir - 1][1][0], (int)n, MPI_DOUBLE, hi, 100 + 2*dir + 1, comm_dom, &rq[nrq++]); }
+  if (lo >= 0) MPI_Irecv(hb[0][1], (int)n, MPI_DOUBLE, lo, 100 + 2*dir + 1, comm_lev[l], &rq[nrq++]);   /* travelled up   */
+  if (hi >= 0) MPI_Irecv(hb[1][1], (int)n, MPI_DOUBLE, hi, 100 + 2*dir,     comm_lev[l], &rq[nrq++]);   /* travelled down */
+  if (lo >= 0) { CHK(aa_halo_get(G[l], dir, 0, hb[0][0])); MPI_Isend(hb[0][0], (int)n, MPI_DOUBLE, lo, 100 + 2*dir, comm_lev[l], &rq[nrq++]); }
+  if (hi >= 0) { CHK(aa_halo_get(G[l], dir, 1, hb[1][0])); MPI_Isend(hb[1][0], (int)n, MPI_DOUBLE, hi, 100 + 2*dir + 1, comm_lev[l], &rq[nrq++]); }
   MPI_Waitall(nrq, rq, st);
-  if (lo >= 0) CHK(aa_halo_put(G[0], dir, 0, hbuf[dir - 1][0][1]));
-  if (hi >= 0) CHK(aa_halo_put(G[0], dir, 1, hbuf[dir - 1][1][1]));
+  if (lo >= 0) CHK(aa_halo_put(G[l], dir, 0, hb[0][1]));
+  if (hi >= 0) CHK(aa_halo_put(G[l], dir, 1, hb[1][1]));
 }
 #endif
 
@@ -429,6 +505,7 @@ void bvals_mhd(DomainS *pD)
 {
   VGFun_t usr[6]; int d, side, any = 0; const int l = GI(pD);
   ensure_grid(M0);
+  if (!HAVE(l)) return;
   to_device(l);
   usr[0] = pD->ix1_BCFun; usr[1] = pD->ox1_BCFun; usr[2] = pD->ix2_BCFun;
   usr[3] = pD->ox2_BCFun; usr[4] = pD->ix3_BCFun; usr[5] = pD->ox3_BCFun;
@@ -443,7 +520,7 @@ void bvals_mhd(DomainS *pD)
     for (d = 0; d < 3; d++) {
       for (side = 0; side < 2; side++) {
 #ifdef AA_MPI
-        if (d > 0 && nb_id[2*(d - 1) + side] >= 0) continue;         /* not a physical side of this Grid */
+        if (d > 0 && nb_lev[l][2*(d - 1) + side] >= 0) continue;     /* not a physical side of this Grid */
 #endif
         if (usr[2*d + side] == NULL) { CHK(aa_bvals_mhd_side(G[l], d, side)); continue; }
         CHK(aa_download_cons(G[l], host_block(l)));
@@ -451,7 +528,7 @@ void bvals_mhd(DomainS *pD)
         CHK(aa_upload_cons(G[l], host_block(l)));
       }
 #ifdef AA_MPI
-      if (d > 0) halo_exchange(d);
+      if (d > 0) halo_exchange(l, d);
 #endif
     }
   }
@@ -544,7 +621,25 @@ void new_dt(MeshS *pM)
     if (learn && learned) host_newer[l] = 0;    /* the stale host copy must not travel back */
     to_device(l);
   }
-#ifdef AA_SMR
+#ifdef AA_MPISMR
+  { /* new_dt.c:32-185: max(|v| + a) per direction carried from Grid to Grid of THIS rank (:33: max_v1.. are set to zero once,
+     * before the loop over levels), (cum / dx_level) of every level, then the MIN over all ranks (:177) */
+    double cum[3] = {0.0, 0.0, 0.0}, max_dti = 0.0, mine, all, v[3];
+    for (l = 0; l < NL; l++) {
+      if (!HAVE(l)) continue;
+      CHK(aa_cfl_max_v(G[l], v));
+      { const double dxl[3] = {PG[l]->dx1, PG[l]->dx2, PG[l]->dx3}; int d_;
+        for (d_ = 0; d_ < 3; d_++) { cum[d_] = (cum[d_] > v[d_]) ? cum[d_] : v[d_]; }
+        for (d_ = 0; d_ < 3; d_++) { const double q_ = cum[d_]/dxl[d_]; max_dti = (max_dti > q_) ? max_dti : q_; } }
+    }
+    mine = CourNo/max_dti;
+    mine = (pM->nstep == 0) ? mine : ((2.0*pM->dt < mine) ? 2.0*pM->dt : mine);       /* :169-173 before the reduction (:177) */
+    MPI_Allreduce(&mine, &all, 1, MPI_DOUBLE, MPI_MIN, MPI_COMM_WORLD);
+    dt = all; t = pM->time; n = pM->nstep;
+    { const double tlim = par_getd("time", "tlim"); if (t < tlim && (tlim - t) < dt) dt = tlim - t; }
+    for (l = 0; l < NL; l++) if (HAVE(l)) CHK(aa_set_mesh_state(G[l], t, dt, n));
+  }
+#elif defined(AA_SMR)
   CHK(aa_mesh_set_state(MM, pM->time, pM->dt, pM->nstep));
   CHK(aa_mesh_new_dt(MM));
   CHK(aa_mesh_get_state(MM, &t, &dt, &n));
@@ -575,7 +670,7 @@ void RestrictCorrect(MeshS *pM)                        /* main.c:401, :591 */
   int l;
   ensure_grid(pM);
   for (l = 0; l < NL; l++) { to_device(l); active_same[l] = 0; }
-  CHK(aa_mesh_restrict_correct(MM));
+  CHK(aa_mesh_restrict_correct(MM));      /* (MPI + SMR: the pairs of this rank's own stack; nothing crosses a cut, see ensure_grid) */
   if (integrated) { integrated = 0; for (l = 0; l < NL; l++) refresh_for_userwork(l); }
 }
 
@@ -608,7 +703,44 @@ static void ion_radtransfer_3d_amd(DomainS *pD)
   GridS *pG = pD->Grid; MeshS *pM = pD->Mesh; int niter = 0; double t, dt; int n; const int l = GI(pD);
   to_device(l);
   active_same[l] = 0;
-#ifdef AA_SMR
+#ifdef AA_MPISMR
+  {
+    /* ionrad_3d.c:862-1047 on the Grid this rank holds of level pD->Level, with the reference's own reductions in the Domain's
+     * communicator: MIN of dt_chem / dt_therm behind the rates (:399, :554) on every level; on the root also SUM of the cells out
+     * of range and MIN of dt_hydro behind the update (:275, :672).  A refined level takes its incoming flux from this rank's own
+     * parent Grid (ionrad_smr.c:34, :345: the rays run along x1, which is never cut) and sub-cycles to the time the root covered. */
+    const int fine = (pD->Level != 0);
+    double dt_done = 0.0, hdt = pG->dt; int stop = 0;
+    if (!HAVE(l)) return;
+    if (fine) CHK(aa_mesh_ionflux_prolong(MM, LI[l])); else tcoarse_ = 0.0;
+    CHK(aa_set_mesh_state(G[l], pM->time, pG->dt, pM->nstep));
+    CHK(aa_ion_begin(G[l]));
+    while (fine || !stop) {
+      double a[2], b[2], dts, dth, dth_all; long long cnt; long cl, cl_all;
+      CHK(aa_ion_rates(G[l], &a[0], &a[1]));
+      MPI_Allreduce(a, b, 2, MPI_DOUBLE, MPI_MIN, comm_lev[l]);
+      dts = (b[1] < b[0]) ? b[1] : b[0];
+      if (!fine) { if (dt_done + dts > hdt) { dts = hdt - dt_done; stop = 1; } }
+      else if (dt_done + dts > tcoarse_) { dts = tcoarse_ - dt_done; stop = 1; }
+      CHK(aa_ion_update(G[l], dts, &cnt, &dth));
+      dt_done += dts; niter++;
+      if (!fine) {
+        cl = (long)cnt;
+        MPI_Allreduce(&cl, &cl_all, 1, MPI_LONG, MPI_SUM, comm_lev[l]);
+        if (cl_all > 20) { hdt = dt_done; break; }                 /* MAXCELLCOUNT, ionrad.h:38 */
+        if (stop) break;
+        MPI_Allreduce(&dth, &dth_all, 1, MPI_DOUBLE, MPI_MIN, comm_lev[l]);
+        if (dth_all < dt_done) { hdt = dt_done; break; }
+      } else if (stop) { hdt = dt_done; break; }
+    }
+    if (!fine) {
+      if (niter == (int)par_getd("ionradiation", "maxiter")) hdt = dt_done;
+      tcoarse_ = dt_done;
+      if (hdt < 0) ath_error("[ion_radtransfer_3d]: dt = %e, dt_done = %e\n", hdt, dt_done);
+    }
+    CHK(aa_set_mesh_state(G[l], pM->time, hdt, pM->nstep));
+  }
+#elif defined(AA_SMR)
   CHK(aa_mesh_set_state(MM, pM->time, pM->dt, pM->nstep));
   CHK(aa_mesh_ion_radtransfer(MM, l, &niter));
 #elif defined(AA_MPI)
@@ -652,7 +784,7 @@ VDFun_t ion_radtransfer_init(MeshS *pM, int ires)
 }
 
 void bvals_ionrad_init(MeshS *pM) { (void)pM; }
-void bvals_ionrad(DomainS *pD) { ensure_grid(pD->Mesh); CHK(aa_bvals_ionrad(G[GI(pD)])); }
+void bvals_ionrad(DomainS *pD) { ensure_grid(pD->Mesh); if (HAVE(GI(pD))) CHK(aa_bvals_ionrad(G[GI(pD)])); }
 void set_coarse_time(void) {}
 void clear_coarse_time(void) {}
 
@@ -661,6 +793,6 @@ void add_radplane_3d(GridS *pGrid, int dir, Real flux)   /* ionradplane_3d.c:56-
   MeshS *pMesh = pGrid->Mesh; int l;
   pMesh->radplanelist->dir[0] = dir;
   pMesh->radplanelist->flux_i = flux;
-  for (l = 0; l < NL; l++) CHK(aa_add_radplane_3d(G[l], dir, flux));
+  for (l = 0; l < NL; l++) if (HAVE(l)) CHK(aa_add_radplane_3d(G[l], dir, flux));
 }
 #endif /* AA_ION_RADPLANE */

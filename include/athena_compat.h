@@ -1,7 +1,8 @@
 /* include/athena_compat.h -- the reference's host-side data structures, restated for the one
  * configuration this package accelerates:
  *   HYDRO, ADIABATIC, CARTESIAN, NSCALARS = AA_NSCALARS (default 1), ION_RADIATION + ION_RADPLANE,
- *   NO_MPI_PARALLEL (or MPI_PARALLEL with -DAA_MPI), NO_MESH_REFINEMENT (or STATIC_MESH_REFINEMENT with -DAA_SMR; not both),
+ *   NO_MPI_PARALLEL (or MPI_PARALLEL with -DAA_MPI), NO_MESH_REFINEMENT (or STATIC_MESH_REFINEMENT with -DAA_SMR), also both
+ *   together (README.rst:25: --enable-mpi ... --enable-smr),
  *   no particles / self-gravity / shearing box.
  * A driver or problem file compiled against the reference's athena.h with those macros and one
  * compiled against this header agree on every offset, so the reference's own main.o, init_mesh.o,
@@ -54,6 +55,9 @@ typedef struct GridOvrlp_s {               /* athena.h:257-276 */
   ConsS **myFlx[6];
 #if AA_ION_RADPLANE
   Real *ionFlx[6];
+#ifdef AA_MPI
+  Real ion_mpitag;                         /* athena.h:266-268 */
+#endif
 #endif
 } GridOvrlpS;
 #endif
@@ -91,6 +95,10 @@ typedef struct Domain_s {                  /* athena.h:340-386 */
 #ifdef AA_MPI
   MPI_Comm Comm_Domain;                    /* athena.h:387-389 */
   MPI_Group Group_Domain;
+#ifdef AA_SMR
+  MPI_Comm Comm_Parent, Comm_Children;     /* athena.h:390-394 */
+  MPI_Group Group_Children;
+#endif
 #endif
 } DomainS;
 

@@ -72,3 +72,45 @@ def run(nx, nlim, overrides=(), cores=None, exe=None, problem="ioniz_sphere", gr
         return dict(U=U, niter=niter, time=time, dt=dt, ranks=p2 * p3, stderr=pr.stderr)
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
+
+
+def run_smr(problem, overrides, nlim, exe, ngrid3, nxs):
+    """MPI + SMR (the reference's README.rst:25 configuration): every Domain of the deck cut into `ngrid3` Grids along x3, one per
+    rank.  nxs: zones (Nx1, Nx2, Nx3) of every Domain, root first.  -> per level the reassembled U (and EdgeFlux rows of rank 0), the
+    sub-cycle counts printed by all ranks (a multiset: the ranks' lines interleave), time, dt."""
+    from collections import Counter
+    from make_golden import read_rst_levels
+    ion = problem != "blast"
+    deck0 = os.path.join(ROOT, "atmospheric-athena_amd", "decks", "athinput." + problem)
+    tmp = tempfile.mkdtemp(prefix="refmpismr_")
+    try:
+        txt = open(deck0).read()
+        for n in range(1, len(nxs) + 1):
+            txt = txt.replace(f"<domain{n}>", f"<domain{n}>\nNGrid_x1 = 1\nNGrid_x2 = 1\nNGrid_x3 = {ngrid3}", 1)
+        txt = re.sub(r"(?m)^maxout\s*=.*$", "maxout = 1", txt, count=1) + "\n<output1>\nout_fmt = rst\ndt = 1e300\n"
+        deck = os.path.join(tmp, "athinput")
+        open(deck, "w").write(txt)
+        rundir = os.path.join(tmp, "run")
+        env = dict(os.environ)
+        if not exe.endswith("_amd"):
+            env["LD_LIBRARY_PATH"] = "/opt/conda/lib:" + env.get("LD_LIBRARY_PATH", "")
+        args = [MPIEXEC, "-n", str(ngrid3), exe, "-i", deck, "-d", rundir, f"job/num_domains={len(nxs)}", f"time/nlim={nlim}"] + list(overrides)
+        pr = subprocess.run(args, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, cwd=tmp, timeout=1800, env=env)
+        if pr.returncode != 0:
+            raise RuntimeError(f"MPI + SMR run failed rc={pr.returncode}: {pr.stderr[-1500:]}")
+        niter = Counter(int(x) for x in re.findall(r"Radiation done in (\d+) iterations", pr.stderr))
+        U = [np.zeros((nx[2], nx[1], nx[0], 6)) for nx in nxs]
+        time = dt = None
+        for r in range(ngrid3):
+            d = os.path.join(rundir, f"id{r}")
+            f = sorted(x for x in os.listdir(d) if x.endswith(".rst"))[-1]
+            loc = [(nx[0], nx[1], nx[2] // ngrid3) for nx in nxs]
+            g = read_rst_levels(os.path.join(d, f), loc, 1 if ion else 0, ion)
+            assert g["nstep"] == nlim
+            for l, (Ul, _ef) in enumerate(g["levels"]):
+                n3 = loc[l][2]
+                U[l][r * n3:(r + 1) * n3] = Ul
+            time, dt = g["time"], g["dt"]
+        return dict(U=U, niter=niter, time=time, dt=dt, stderr=pr.stderr)
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
