@@ -489,9 +489,28 @@ def pmc_passes(argv):
         sys.stderr.write("[bench] --pmc-pass: rocprofv3 is not on PATH; roofline.traffic stays with the committed profile\n")
         return
     keep = [x for x in argv if x not in ("--pmc-pass",)]
-    alias = (("k_flux2_update<", "flux2_update"), ("k_correct_all<", "correct_all"), ("k_eta_edges<", "correct_all"),
-             ("k_sweep_x1_flat<", "sweep_x1"), ("k_sweep_x1<", "sweep_x1"), ("k_sweep_march<1, 1,", "sweep_x2"), ("k_sweep_march<0, 1,", "sweep_x2"),
-             ("k_sweep_march<1, 2,", "sweep_x3"), ("k_sweep_march<0, 2,", "sweep_x3"))
+
+    def bench_name(n):
+        """rocprofv3's kernel name -> the name bench.py's event profiler books the launch under (hydro chain of the CTU integrator)"""
+        m = re.search(r"(k_\w+)<([^>]*)>", n)
+        if not m:
+            return None
+        k, targs = m.group(1), [x.strip() for x in m.group(2).split(",")]
+        if k == "k_flux2_update":
+            return "flux2_update"
+        if k in ("k_correct_all", "k_eta_edges"):
+            return "correct_all"
+        if k in ("k_sweep_x1_flat", "k_sweep_x1"):         # <NS, GRAV, MODE, ORD>
+            return {"0": "sweep_x1", "3": "sweep_correct_x1", "1": "correct_x1"}.get(targs[2])
+        if k == "k_sweep_march":                            # <NS, D, GRAV, MODE, ORD>
+            return ("sweep_x2" if targs[1] == "1" else "sweep_x3") if targs[3] == "0" else None
+        if k == "k_sweep_tile":                             # <NS, D, GRAV, MODE, BT, ORD>
+            return "correct_x2" if targs[1] == "1" else "correct_x3"
+        if k == "k_flux2":                                  # <NS, D>
+            return "flux2_x%d" % (int(targs[1]) + 1)
+        if k == "k_update":
+            return "update"
+        return None
     tmp = tempfile.mkdtemp(prefix="bench_pmc_", dir="/tmp")
     t0 = time.time()
     got = {}
@@ -511,7 +530,7 @@ def pmc_passes(argv):
                 per.setdefault(r["Kernel_Name"], []).append((int(r.get("Start_Timestamp", 0) or 0), float(r["Counter_Value"])))
             acc = {}
             for n, rows in per.items():
-                key = next((k for pat, k in alias if pat in n), None)
+                key = bench_name(n)
                 if key is None:
                     continue
                 rows.sort()
