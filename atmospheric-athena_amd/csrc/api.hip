@@ -9,6 +9,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 #include <string>
 #include <thread>
 #include <vector>
@@ -94,6 +95,8 @@ int aa_create(const aa_params *p, aa_grid **out)
     c.ca_kc = env("AA_CA_KC", 0); c.fu_kc = env("AA_FU_KC", 0);
     c.ion_pass_cap = env("AA_ION_PASS_BLOCKS", 4096); if (c.ion_pass_cap < 1) c.ion_pass_cap = 1;
     c.pitch_align = env("AA_PITCH_ALIGN", 1);
+    c.mailbox = env("AA_MAILBOX", 1); c.mailbox_spin_us = env("AA_MAILBOX_SPIN_US", 300);
+    c.bc_one = env("AA_BC_ONE", 1); c.fuse_pick = env("AA_ION_FUSE_PICK", 1);
   }
   d.Nx1 = p->Nx[0]; d.Nx2 = p->Nx[1]; d.Nx3 = p->Nx[2];
   d.N1 = d.Nx1 + 2*AA_NGHOST; d.N2 = d.Nx2 + 2*AA_NGHOST; d.N3 = d.Nx3 + 2*AA_NGHOST;
@@ -176,18 +179,22 @@ int aa_create(const aa_params *p, aa_grid **out)
     for (int a = 0; a < 3; a++) ip.inv_dx[a] = 1.0/d.dx[a];
     ip.iso = (d.dx[0] == d.dx[1] && d.dx[1] == d.dx[2]);
   }
-  if (hipMalloc(&g->sc, sizeof(DevScalars)) != hipSuccess || hipHostMalloc(&g->sc_host, sizeof(DevScalars)) != hipSuccess) {
+  if (hipMalloc(&g->sc, sizeof(DevScalars)) != hipSuccess ||
+      hipHostMalloc(&g->mb, sizeof(Mailbox), hipHostMallocCoherent | hipHostMallocMapped) != hipSuccess) {
     hipFree(g->pool); delete g; return fail(-2, "[aa_create]: scalar buffers");
   }
+  memset(g->mb, 0, sizeof(Mailbox));
+  g->sc_host = &g->mb->s;
+  if (hipHostGetDevicePointer((void**)&g->mb_dev, g->mb, 0) != hipSuccess) { (void)hipGetLastError(); g->mb_dev = nullptr; d.cfg.mailbox = 0; }
   if (g->ion_fused) {
     if (hipMalloc(&g->ion_part, (size_t)ion_pass_blocks(d)*sizeof(IonPart)) != hipSuccess ||
         hipMalloc(&g->ion_words, AA_ION_WORDS*sizeof(Real)) != hipSuccess) {
-      hipFree(g->pool); hipFree(g->sc); hipHostFree(g->sc_host); delete g; return fail(-2, "[aa_create]: ion reduction buffers");
+      hipFree(g->pool); hipFree(g->sc); hipHostFree(g->mb); delete g; return fail(-2, "[aa_create]: ion reduction buffers");
     }
   }
   // (every word of these is written before it is read; zeroed all the same, so that no run ever depends on what a freed
   //  allocation of an earlier Grid left behind)
-  (void)hipMemset(g->sc, 0, sizeof(DevScalars)); memset(g->sc_host, 0, sizeof(DevScalars));
+  (void)hipMemset(g->sc, 0, sizeof(DevScalars));
   if (g->ion_part) (void)hipMemset(g->ion_part, 0, (size_t)ion_pass_blocks(d)*sizeof(IonPart));
   if (g->ion_words) (void)hipMemset(g->ion_words, 0, AA_ION_WORDS*sizeof(Real));
   hipStreamCreate(&g->st); g->own_stream = true;
@@ -201,7 +208,7 @@ void aa_destroy(aa_grid *g)
   if (g->link) { slabs_destroy(g); return; }          // a composite handle, whether or not it has slabs yet
   hipStreamSynchronize(g->st);
   prof_drain(g);
-  hipFree(g->pool); hipFree(g->sc); hipHostFree(g->sc_host);
+  hipFree(g->pool); hipFree(g->sc); hipHostFree(g->mb);
   if (g->ion_part) hipFree(g->ion_part);
   if (g->ion_words) hipFree(g->ion_words);
   if (g->pin_idx) hipFree(g->pin_idx);
@@ -419,6 +426,7 @@ int aa_bvals_mhd(aa_grid *g)
 {
   if (!g->slab.empty()) return slabs_bvals_mhd(g);
   Scope s(g, "bvals_mhd");
+  if (g->d.cfg.bc_one) { launch_bc_shell(g->d, g->p.nscal, g->p.bc, g->st); return 0; }      // the three passes as one launch: same bits
   for (int d = 0; d < 3; d++)            // x1, x2, x3 so the corners fill (bvals_mhd.c:170)
     launch_bc_dir(g->d, g->p.nscal, d, g->p.bc[2*d], g->p.bc[2*d + 1], g->st);
   return 0;
@@ -442,12 +450,34 @@ int aa_bvals_ionrad(aa_grid *g)
   return 0;
 }
 
+// DevScalars device -> host.  The mailbox way (grid.h Mailbox; AA_MAILBOX=0: a copy + a stream wait): a one-wave kernel behind the
+// producers writes the scalars into pinned host memory and stamps them; the host polls the stamp -- for a while: a wait that
+// outlasts AA_MAILBOX_SPIN_US (a long kernel in front) ends in hipStreamSynchronize like the other way, so no core spins for
+// milliseconds.  On the small Grids of the reference's own decks a step is a few dozen launches and 2 + N_sub read-backs, and a
+// copy + wait costs ~25 us against ~8 for a launch + poll.
 int aa_fetch_scalars(aa_grid *g)
 {
   if (!g->slab.empty()) return fail(-1, "[aa_fetch_scalars]: not available on a Grid cut into slabs");
+  g->host_syncs++;
+  if (g->d.cfg.mailbox && g->mb_dev) {
+    const unsigned long long seq = ++g->mb_seq;
+    launch_publish(g->sc, g->mb_dev, seq, g->st);
+    volatile unsigned long long *stamp = &g->mb->seq;
+    struct timespec t0; clock_gettime(CLOCK_MONOTONIC, &t0);
+    for (unsigned spins = 1;; spins++) {
+      if (__atomic_load_n(stamp, __ATOMIC_ACQUIRE) == seq) return 0;
+      if ((spins & 127u) == 0) {
+        struct timespec t1; clock_gettime(CLOCK_MONOTONIC, &t1);
+        if ((t1.tv_sec - t0.tv_sec)*1000000L + (t1.tv_nsec - t0.tv_nsec)/1000L > g->d.cfg.mailbox_spin_us) break;
+      }
+      __builtin_ia32_pause();
+    }
+    HIPCHK(hipStreamSynchronize(g->st));          // (also where a kernel in front failed: the error comes out here)
+    if (__atomic_load_n(stamp, __ATOMIC_ACQUIRE) != seq) return fail(-2, "[aa_fetch_scalars]: the mailbox kernel finished without its stamp");
+    return 0;
+  }
   HIPCHK(hipMemcpyAsync(g->sc_host, g->sc, sizeof(DevScalars), hipMemcpyDeviceToHost, g->st));
   HIPCHK(hipStreamSynchronize(g->st));
-  g->host_syncs++;
   return 0;
 }
 #define fetch_scalars aa_fetch_scalars
@@ -760,7 +790,7 @@ int aa_ion_pass(aa_grid *g, int update, int sweep, double *dev_words)
   g->ion_spec_dt = -1.0;
   { Scope s(g, update ? (sweep ? "ion_pass" : "ion_pass_last") : (begin ? "ion_pass_begin" : "ion_pass_first"));
     launch_ion_pass(g->d, g->ion, update != 0, sweep != 0, begin, flux0, g->level > 0 && g->nradplane > 0, g->sc, g->ion_cur,
-                    g->ion_part, dev_words ? dev_words : g->ion_words, g->st, spec_dt); }
+                    g->ion_part, dev_words ? dev_words : g->ion_words, g->st, spec_dt, !g->ion_fuse_pick); }
   if (sweep) g->ion_pending = true;
   HIPCHK(hipGetLastError());
   return 0;
@@ -788,6 +818,10 @@ int aa_ion_pick(aa_grid *g, const double *dev_words_all, int nranks, int first, 
   if (!g->slab.empty()) return slabs_ion_pick(g, first, limit);
   if (first && g->ion_spec_armed && limit != g->ion_spec_limit)
     return fail(-1, "[aa_ion_pick]: limit %.17g, but aa_ion_speculate was told %.17g", limit, g->ion_spec_limit);
+  if (g->ion_fuse_pick) {      // (ion_run_fused, one rank: the pass left its records unfolded)
+    if (dev_words_all) return fail(-1, "[aa_ion_pick]: internal: a fused pick with gathered words");
+    launch_ion_reduce_pick(g->d, g->ion_part, g->ion_words, g->sc, first, limit, g->st, first ? (g->ion_spec_armed ? 1 : 0) : 0);
+  } else
   launch_ion_pick2(dev_words_all ? dev_words_all : g->ion_words, dev_words_all ? nranks : 1, g->sc, first, limit, g->st,
                    first ? (g->ion_spec_armed ? 1 : 0) : 0);
   if (!first) g->ion_spec_armed = false;
@@ -848,6 +882,9 @@ static int ion_run_fused(aa_grid *g, bool fine, double limit, int *niter_out, do
   int hit, neg, niter = 0, rc;
   const double *all = G.fn ? G.all : nullptr;
   const int nr = G.fn ? G.nranks : 1;
+  // one rank: every pass of this loop is followed by its pick with nothing in between -- fold and pick in one launch
+  struct FuseGuard { aa_grid *g; ~FuseGuard() { g->ion_fuse_pick = false; } } fuse_guard{g};
+  g->ion_fuse_pick = !G.fn && g->d.cfg.fuse_pick != 0;
   if ((rc = aa_ion_begin(g))) return rc;
   if ((rc = aa_ion_speculate(g, limit))) return rc;                          // (the first pass may already apply update(0) with the whole step)
   if ((rc = aa_ion_pass(g, 0, 1, G.fn ? G.words : nullptr))) return rc;      // sweep(0) + rates(0)

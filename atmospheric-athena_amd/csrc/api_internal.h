@@ -22,7 +22,10 @@ struct aa_grid {
   hipStream_t st = nullptr; bool own_stream = false;
   aa::Real *pool = nullptr; size_t pool_doubles = 0;
   aa::DevScalars *sc = nullptr;        // device
-  aa::DevScalars *sc_host = nullptr;   // pinned
+  aa::DevScalars *sc_host = nullptr;   // pinned (= &mb->s)
+  aa::Mailbox *mb = nullptr, *mb_dev = nullptr;   // the pinned mailbox and its device address (grid.h Mailbox); mb_seq: stamps handed out
+  unsigned long long mb_seq = 0;
+  bool ion_fuse_pick = false;          // the pass just queued left its records unfolded: aa_ion_pick folds and picks in one launch (one rank)
   long long *pin_idx = nullptr; aa::Real *pin_val = nullptr; long long npin = 0;
   double *cfl_part = nullptr; long cfl_part_n = 0;   // the blocks' CFL maxima of k_update<CFL> (van Leer integrator), 3 x update_blocks
   unsigned char *pin_mask = nullptr;   // 1 where a zone is pinned (k_flux2_update<CFL> leaves those to k_pinned_cfl)

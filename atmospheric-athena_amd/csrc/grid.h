@@ -102,9 +102,18 @@ struct LaunchCfg {
   int ca_kc = 0, fu_kc = 0;  // AA_CA_KC / AA_FU_KC: planes per block of k_correct_all / k_flux2_update (0: by size)
   int ion_pass_cap = 4096;   // AA_ION_PASS_BLOCKS: most blocks of a k_ion_pass launch
   int pitch_align = 1;       // AA_PITCH_ALIGN=0: dense device rows
+  int mailbox = 1;           // AA_MAILBOX=0: scalars come back by hipMemcpyAsync + hipStreamSynchronize instead of the polled mailbox
+  int mailbox_spin_us = 300; // AA_MAILBOX_SPIN_US: how long the host polls before it falls back to hipStreamSynchronize
+  int bc_one = 1;            // AA_BC_ONE=0: bvals_mhd as one launch per direction instead of one for the whole ghost shell
+  int fuse_pick = 1;         // AA_ION_FUSE_PICK=0: k_ion_reduce and k_ion_pick2 as two launches also where one rank reduces alone
 };
 // the descriptor as the host keeps it: what the kernels get (DevGrid, passed by value: the launch slices it off) + the launch choices
 struct HostGrid : DevGrid { LaunchCfg cfg; };
+
+// the scalars' way back to the host (api.hip aa_fetch_scalars): pinned, device-visible host memory that a one-wave kernel fills
+// and stamps with a sequence number the host polls for -- a read-back costs a ~5 us launch instead of a copy + a stream wait
+struct Mailbox { DevScalars s; unsigned long long seq; };
+void launch_publish(const DevScalars *sc, Mailbox *mb_dev, unsigned long long seq, hipStream_t st);
 
 // face planes (index along the normal, incl. ghost offset) whose second-pass fluxes the fused kernel also
 // stores: the level boundaries static mesh refinement reads back (smr.hip)
@@ -135,8 +144,10 @@ void launch_ion_begin16(const DevGrid &g, const IonPar &p, hipStream_t st);
 // [entry of the ion step: floors, save_energy_and_x, if `begin`;] update(n-1) with sc->dt_sel, then sweep(n) + rates(n)
 // into buffer cur^1; folds the records into `words`
 void launch_ion_pass(const HostGrid &g, const IonPar &p, bool update, bool sweep, bool begin, Real flux0, bool from_edgeflux,
-                     const DevScalars *sc, int cur, IonPart *part, Real *words, hipStream_t st, Real spec_dt = -1.0);
+                     const DevScalars *sc, int cur, IonPart *part, Real *words, hipStream_t st, Real spec_dt = -1.0, bool reduce = true);
 void launch_ion_pick2(const Real *words, int nranks, DevScalars *sc, int first, Real dt_limit, hipStream_t st, int spec_armed = 0);
+// one rank: the fold of the pass's records (k_ion_reduce) and the pick in ONE launch; launch_ion_pass(..., reduce = false) goes before it
+void launch_ion_reduce_pick(const HostGrid &g, const IonPart *part, Real *words, DevScalars *sc, int first, Real dt_limit, hipStream_t st, int spec_armed);
 void launch_ion_finish(const DevGrid &g, int cur, hipStream_t st);
 void launch_test_explog(int n, const Real *x, Real *ye, Real *yl, hipStream_t st);   // n a multiple of 4
 

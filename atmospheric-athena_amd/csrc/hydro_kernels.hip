@@ -1716,6 +1716,55 @@ __global__ void k_bc(DevGrid g, int nvar, int d, int side, int flag, int flag1)
   }
 }
 
+// bvals_mhd in ONE launch.  The three passes x1 -> x2 -> x3 are copies along one coordinate each (k_bc), so what a ghost zone ends up
+// with is the value of ONE source zone, found by walking its ghost coordinates from x3 down: a pass d writes the zones whose
+// coordinate d is a ghost one (flag != 0), for every value of the coordinates below d and ACTIVE coordinates above it, from the
+// zone with coordinate d mapped into the active range -- whose lower ghost coordinates were filled by the passes before, the same
+// way.  So: map x3 if it is a ghost coordinate with a boundary function, then x2, then x1; stop at the first ghost coordinate whose
+// side has none (flag 0: a neighbour Grid's or a parent's data; the passes below never touch a zone with that coordinate outside
+// the active range).  A zone is written iff its HIGHEST ghost coordinate has a boundary function; no source zone is itself a
+// target, so the launch needs no ordering.  Reflecting sides negate their normal momentum once per mapped coordinate.  Same bits
+// as the three passes (copies and sign flips only).
+__global__ void __launch_bounds__(256)
+k_bc_shell(DevGrid g, int nvar, int f0, int f1, int f2, int f3, int f4, int f5)
+{
+  const int flag[3][2] = {{f0, f1}, {f2, f3}, {f4, f5}};
+  const int lo3[3] = {g.is, g.js, g.ks}, hi3[3] = {g.ie, g.je, g.ke}, N[3] = {g.N1, g.N2, g.N3};
+  const int G2 = 2*AA_NGHOST_;
+  // the shell in three pieces: ghost k (all i, j); ghost j, active k (all i); ghost i, active j and k
+  const long n3 = (long)G2*N[1]*N[0], n2 = (long)G2*N[0]*(hi3[2] - lo3[2] + 1), n1 = (long)G2*(hi3[1] - lo3[1] + 1)*(hi3[2] - lo3[2] + 1);
+  long lin = (long)blockIdx.x*blockDim.x + threadIdx.x;
+  int c[3];
+  auto ghost = [&](int q, int d) { return q < AA_NGHOST_ ? q : hi3[d] + 1 + (q - AA_NGHOST_); };      // q-th ghost index of direction d
+  if (lin < n3) {
+    c[0] = (int)(lin % N[0]); c[1] = (int)((lin / N[0]) % N[1]); c[2] = ghost((int)(lin / ((long)N[0]*N[1])), 2);
+  } else if ((lin -= n3) < n2) {
+    c[0] = (int)(lin % N[0]); c[1] = ghost((int)((lin / N[0]) % G2), 1); c[2] = lo3[2] + (int)(lin / ((long)N[0]*G2));
+  } else if ((lin -= n2) < n1) {
+    c[0] = ghost((int)(lin % G2), 0); c[1] = lo3[1] + (int)((lin / G2) % (hi3[1] - lo3[1] + 1)); c[2] = lo3[2] + (int)(lin / ((long)G2*(hi3[1] - lo3[1] + 1)));
+  } else return;
+  const long mdst = (long)c[2]*g.sK + (long)c[1]*g.sJ + c[0];
+  bool neg[3] = {false, false, false}, any = false;
+#pragma unroll
+  for (int d = 2; d >= 0; d--) {
+    const int x = c[d];
+    if (x >= lo3[d] && x <= hi3[d]) continue;
+    const int side = (x < lo3[d]) ? 0 : 1, fl = flag[d][side];
+    if (!fl) { if (!any) return; break; }              // (highest ghost coordinate without a boundary function: not ours; a lower one: stop)
+    const int gl = side ? x - hi3[d] : lo3[d] - x;       // ghost layer 1..4
+    if (side == 0) c[d] = (fl == 1) ? lo3[d] + (gl - 1) : (fl == 2) ? lo3[d] : hi3[d] - (gl - 1);
+    else           c[d] = (fl == 1) ? hi3[d] - (gl - 1) : (fl == 2) ? hi3[d] : lo3[d] + (gl - 1);
+    if (fl == 1) neg[d] = true;
+    any = true;
+  }
+  const long msrc = (long)c[2]*g.sK + (long)c[1]*g.sJ + c[0];
+  for (int v = 0; v < nvar; v++) {
+    Real x = Uf(g, v)[msrc];
+    if (v >= 1 && v <= 3 && neg[v - 1]) x = -x;
+    Uf(g, v)[mdst] = x;
+  }
+}
+
 // ---- CFL reduction: new_dt.c:72-170 -----------------------------------------------------
 __global__ void __launch_bounds__(256)
 k_cfl(DevGrid g, DevScalars *sc)
@@ -2159,6 +2208,12 @@ void launch_bc_dir(const DevGrid &g, int nscal, int dir, int flag_in, int flag_o
   hipLaunchKernelGGL(k_bc, dim3(nblk(n, 256), 2), dim3(256), 0, st, g, 5 + nscal, dir, -1, flag_in, flag_out);
 }
 
+void launch_bc_shell(const DevGrid &g, int nscal, const int flags[6], hipStream_t st)
+{
+  const long G2 = 2*AA_NGHOST_, nk = g.ke - g.ks + 1, nj = g.je - g.js + 1;
+  const long n = G2*g.N2*g.N1 + G2*g.N1*nk + G2*nj*nk;
+  hipLaunchKernelGGL(k_bc_shell, dim3(nblk(n, 256)), dim3(256), 0, st, g, 5 + nscal, flags[0], flags[1], flags[2], flags[3], flags[4], flags[5]);
+}
 void launch_cfl(const DevGrid &g, DevScalars *sc, hipStream_t st)
 {
   const long n = (long)(g.ie - g.is + 1)*(g.je - g.js + 1)*(g.ke - g.ks + 1);

@@ -23,6 +23,7 @@ void launch_vl_predict(const DevGrid &g, int nscal, Real dt, bool grav, hipStrea
 void launch_vl_flux2(const HostGrid &g, int nscal, int dir, Real dt, hipStream_t st);
 void launch_bc(const DevGrid &g, int nscal, int dir, int side, int flag, hipStream_t st);
 void launch_bc_dir(const DevGrid &g, int nscal, int dir, int flag_in, int flag_out, hipStream_t st);   // both sides, one launch
+void launch_bc_shell(const DevGrid &g, int nscal, const int flags[6], hipStream_t st);                 // all six sides, one launch (k_bc_shell)
 unsigned reduce_blocks(long nzones);      // launch size of the grid-stride reduction kernels
 void launch_cfl(const DevGrid &g, DevScalars *sc, hipStream_t st);
 int  launch_history(const DevGrid &g, int nscal, Real *partial, hipStream_t st);   // returns the number of partial rows

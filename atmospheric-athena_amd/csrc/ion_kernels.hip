@@ -388,6 +388,21 @@ __global__ void k_ion_pick(DevScalars *sc, Real dt_done, Real dt_limit)
 }
 void launch_ion_pick(DevScalars *sc, Real dt_done, Real dt_limit, hipStream_t st)
 { hipLaunchKernelGGL(k_ion_pick, dim3(1), dim3(1), 0, st, sc, dt_done, dt_limit); }
+// grid.h Mailbox: the scalars to pinned host memory, then the stamp (system scope: the host polls it)
+__global__ void __launch_bounds__(64)
+k_publish(const DevScalars *sc, Mailbox *mb, unsigned long long seq)
+{
+  constexpr int n = (int)(sizeof(DevScalars)/sizeof(unsigned long long));
+  static_assert(sizeof(DevScalars) % sizeof(unsigned long long) == 0, "DevScalars is copied word by word");
+  const unsigned long long *src = (const unsigned long long*)sc;
+  unsigned long long *dst = (unsigned long long*)&mb->s;
+  for (int i = threadIdx.x; i < n; i += 64) dst[i] = src[i];
+  __threadfence_system();
+  __syncthreads();
+  if (threadIdx.x == 0) __hip_atomic_store(&mb->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+void launch_publish(const DevScalars *sc, Mailbox *mb_dev, unsigned long long seq, hipStream_t st)
+{ hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, st, sc, mb_dev, seq); }
 void launch_edgeflux_bc(const DevGrid &g, Real flux_i, hipStream_t st)
 { const long n = (long)(g.Nx2 + 1)*(g.Nx3 + 1); hipLaunchKernelGGL(k_edgeflux_bc, dim3(nblk(n, 256)), dim3(256), 0, st, g, flux_i); }
 

@@ -547,6 +547,35 @@ k_ion_reduce(const IonPart *part, int n, Real *words)
   }
   if (threadIdx.x < 8) words[threadIdx.x] = (threadIdx.x < 5) ? red[threadIdx.x][0] : 0.0;
 }
+AA_DEV void ion_pick_body(Real dt_chem, Real dt_therm, Real max_dti, Real count, Real neg, DevScalars *sc, int first, Real dt_limit, int spec_armed);
+// ... and, where ONE rank reduces alone, the pick of k_ion_pick2 by the same launch (the same fold, the same arithmetic): a sub-cycle
+// on a small Grid is a handful of launches and one read-back, and every launch less is ~5 us of 40
+__global__ void __launch_bounds__(256)
+k_ion_reduce_pick(const IonPart *part, int n, Real *words, DevScalars *sc, int first, Real dt_limit, int spec_armed)
+{
+  __shared__ Real red[5][256];
+  Real a = DBL_MAX, b = DBL_MAX, c = 0.0, d = 0.0, e = 0.0;
+  for (int i = threadIdx.x; i < n; i += 256) {
+    const IonPart r = part[i];
+    a = rmin(a, r.dt_chem); b = rmin(b, r.dt_therm); c = rmax(c, r.max_dti); d += r.cellcount; e = rmax(e, r.neg);
+  }
+  red[0][threadIdx.x] = a; red[1][threadIdx.x] = b; red[2][threadIdx.x] = c; red[3][threadIdx.x] = d; red[4][threadIdx.x] = e;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) {
+      red[0][threadIdx.x] = rmin(red[0][threadIdx.x], red[0][threadIdx.x + s]);
+      red[1][threadIdx.x] = rmin(red[1][threadIdx.x], red[1][threadIdx.x + s]);
+      red[2][threadIdx.x] = rmax(red[2][threadIdx.x], red[2][threadIdx.x + s]);
+      red[3][threadIdx.x] += red[3][threadIdx.x + s];
+      red[4][threadIdx.x] = rmax(red[4][threadIdx.x], red[4][threadIdx.x + s]);
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x < 8) words[threadIdx.x] = (threadIdx.x < 5) ? red[threadIdx.x][0] : 0.0;
+  // (one rank: k_ion_pick2's fold over ranks is MIN / MAX / + of one operand with its neutral element: the operand itself)
+  if (threadIdx.x == 0)
+    ion_pick_body(rmin(DBL_MAX, red[0][0]), rmin(DBL_MAX, red[1][0]), rmax(0.0, red[2][0]), 0.0 + red[3][0], rmax(0.0, red[4][0]), sc, first, dt_limit, spec_armed);
+}
 
 // ionrad_3d.c:941-967 on the device, over the words of all ranks (AA_ION_WORDS doubles each; one rank: the
 // Grid's own): dt = MIN(dt_therm, dt_chem) cut back to what is left of the hydro step (root) or of the
@@ -559,6 +588,10 @@ __global__ void k_ion_pick2(const Real *words, int nranks, DevScalars *sc, int f
     const Real *w = words + (long)r*AA_ION_WORDS;
     dt_chem = rmin(dt_chem, w[0]); dt_therm = rmin(dt_therm, w[1]); max_dti = rmax(max_dti, w[2]); count += w[3]; neg = rmax(neg, w[4]);
   }
+  ion_pick_body(dt_chem, dt_therm, max_dti, count, neg, sc, first, dt_limit, spec_armed);
+}
+AA_DEV void ion_pick_body(Real dt_chem, Real dt_therm, Real max_dti, Real count, Real neg, DevScalars *sc, int first, Real dt_limit, int spec_armed)
+{
   // what belongs to the update the pass before this kernel applied (none after the first pass of an ion step)
   Real dt_done = 0.0;
   if (!first) {
@@ -648,8 +681,10 @@ int ion_pass_blocks(const HostGrid &g)
 void launch_ion_begin16(const DevGrid &g, const IonPar &p, hipStream_t st)
 { const long n = (long)g.Nx1*g.Nx2*g.Nx3; hipLaunchKernelGGL(k_ion_begin16, dim3(nblk(n, 256)), dim3(256), 0, st, g, p); }
 
+void launch_ion_reduce_pick(const HostGrid &g, const IonPart *part, Real *words, DevScalars *sc, int first, Real dt_limit, hipStream_t st, int spec_armed)
+{ hipLaunchKernelGGL(k_ion_reduce_pick, dim3(1), dim3(256), 0, st, part, ion_pass_blocks(g), words, sc, first, dt_limit, spec_armed); }
 void launch_ion_pass(const HostGrid &g, const IonPar &p, bool update, bool sweep, bool begin, Real flux0, bool from_edgeflux,
-                     const DevScalars *sc, int cur, IonPart *part, Real *words, hipStream_t st, Real spec_dt)
+                     const DevScalars *sc, int cur, IonPart *part, Real *words, hipStream_t st, Real spec_dt, bool reduce)
 {
   const int nb = ion_pass_blocks(g);
   const dim3 grid(nb), blk(256);
@@ -661,7 +696,7 @@ void launch_ion_pass(const HostGrid &g, const IonPar &p, bool update, bool sweep
   else if (sweep && begin) hipLaunchKernelGGL((k_ion_pass<false, true, true>), grid, blk, 0, st, g, p, flux0, fe, sc, cur, part, -1, spec_dt);
   else if (sweep)      hipLaunchKernelGGL((k_ion_pass<false, true, false>), grid, blk, 0, st, g, p, flux0, fe, sc, cur, part, -1, -1.0);
   else                 hipLaunchKernelGGL((k_ion_pass<true, false, false>), grid, blk, 0, st, g, p, flux0, fe, sc, cur, part, -1, -1.0);
-  hipLaunchKernelGGL(k_ion_reduce, dim3(1), dim3(256), 0, st, part, nb, words);
+  if (reduce) hipLaunchKernelGGL(k_ion_reduce, dim3(1), dim3(256), 0, st, part, nb, words);
 }
 void launch_ion_pick2(const Real *words, int nranks, DevScalars *sc, int first, Real dt_limit, hipStream_t st, int spec_armed)
 { hipLaunchKernelGGL(k_ion_pick2, dim3(1), dim3(1), 0, st, words, nranks, sc, first, dt_limit, spec_armed); }

@@ -43,3 +43,19 @@ def test_old_and_new_layouts(case, strict, tmp_path):
             err = float(np.max(np.abs(new - old_sl)/scale))
             print("default build, marching slopes against k_slopes: max error / field scale", err)
             assert err < 1e-11
+
+
+@pytest.mark.parametrize("strict", [True, False], ids=["strict", "default"])
+@pytest.mark.parametrize("case,ov", [(CASES[0], ""), (CASES[1], ""), (CASES[3], ""),
+                                     (("blast", 40, 21, 18, 2, "ctu", 3), "domain1/bc_ix1=1 domain1/bc_ox1=2 domain1/bc_ix2=2 domain1/bc_ox2=1 domain1/bc_ix3=1 domain1/bc_ox3=1")],
+                         ids=["blast-periodic", "sphere-outflow", "sphere-128", "blast-reflect-outflow-mix"])
+def test_fewer_launches_same_bits(case, ov, strict, tmp_path):
+    """Round 4, for the small Grids of the reference's own decks (a step there is a few dozen launches and 2 + N_sub read-backs):
+    bvals_mhd's three passes as ONE launch over the ghost shell (k_bc_shell; AA_BC_ONE=0: the passes), the scalars back through a
+    polled mailbox in pinned memory (AA_MAILBOX=0: copy + stream wait), the sub-cycle's fold and pick in one launch where one rank
+    reduces alone (AA_ION_FUSE_PICK=0).  Copies, sign flips and the same arithmetic: the whole block incl. every ghost zone and corner
+    must come out bit for bit, in both builds -- with periodic, outflow and reflecting sides mixed."""
+    new = _run(case, {"LAYOUT_OV": ov}, str(tmp_path / "new.npy"), strict)
+    old = _run(case, {"LAYOUT_OV": ov, "AA_BC_ONE": "0", "AA_MAILBOX": "0", "AA_ION_FUSE_PICK": "0"}, str(tmp_path / "old.npy"), strict)
+    assert np.isfinite(new).all() or case[0] == "ioniz_sphere"
+    assert np.array_equal(new, old, equal_nan=True)

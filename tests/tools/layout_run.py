@@ -12,7 +12,7 @@ sys.path.insert(0, ROOT)
 aa = importlib.import_module("atmospheric-athena_amd")
 lib = importlib.import_module("atmospheric-athena_amd.lib")
 problem, n1, n2, n3, order, integ, steps, out = sys.argv[1:9]
-ov = [f"domain1/Nx1={n1}", f"domain1/Nx2={n2}", f"domain1/Nx3={n3}"]
+ov = [f"domain1/Nx1={n1}", f"domain1/Nx2={n2}", f"domain1/Nx3={n3}"] + os.environ.get("LAYOUT_OV", "").split()      # (LAYOUT_OV: further deck overrides)
 run = aa.config.load(os.path.join(ROOT, "atmospheric-athena_amd", "decks", f"athinput.{problem}"), ov, problem, integ)
 run.order = int(order)
 g = lib.setup_problem(aa.config.slab(run), 0, len(sys.argv) > 9 and sys.argv[9] == "strict")
