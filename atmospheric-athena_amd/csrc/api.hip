@@ -135,7 +135,9 @@ int aa_create(const aa_params *p, aa_grid **out)
   { const char *e = getenv("AA_ION_BEGIN_FUSED"); g->ion_begin_fused = e ? atoi(e) != 0 : true; }
   { const char *e = getenv("AA_ION_SPECULATE"); g->ion_spec_on = e ? atoi(e) != 0 : true; }
   { const char *e = getenv("AA_ION_FUSED");
-    g->ion_fused = p->ion && (p->ion_path ? p->ion_path == 1 : (e ? atoi(e) != 0 : p->Nx[0] >= 64)); }
+    // (rays of 48 zones or more: the 52^3 level of the reference's own deck takes 6 sub-cycles of 4 launches + a read-back the other
+    //  way, 3 + a read-back this way -- there the launches count, not the 12 idle lanes of a wavefront; round 3: 64)
+    g->ion_fused = p->ion && (p->ion_path ? p->ion_path == 1 : (e ? atoi(e) != 0 : p->Nx[0] >= 48)); }
   const size_t nrays = (size_t)d.Nx2*d.Nx3;
   if (p->ion) n += nc*6 + nef;
   if (g->ion_fused) n += 2*nc + 2*nrays;

@@ -433,7 +433,7 @@ class HipMeshEngine:
         self.send = [[torch.empty(g.halo_doubles(), dtype=torch.float64, device=dev) for _ in range(2)] for g in self.lev]
         self.recv = [[torch.empty(g.halo_doubles(), dtype=torch.float64, device=dev) for _ in range(2)] for g in self.lev]
         self._fbuf = {}
-        # one-kernel radiation sub-cycle (levels with rays of 64 zones or more): this rank's reduction words of the level
+        # one-kernel radiation sub-cycle (levels with rays of 48 zones or more): this rank's reduction words of the level
         # being stepped, and those of all ranks, in device memory
         self.words = torch.zeros(lib.ION_WORDS, dtype=torch.float64, device=dev)
         self.words_all = torch.zeros(lib.ION_WORDS * max(1, cfg.nranks), dtype=torch.float64, device=dev)

@@ -46,7 +46,7 @@ typedef struct aa_params {
                               (init_mesh.c:245); 0 for a single-level run                      */
   int    order;            /* configure --with-order: 2 (or 0) piecewise linear, lr_states_plm.c;
                               3 piecewise parabolic, lr_states_ppm.c (CTU integrator only)    */
-  int    ion_path;         /* radiation sub-cycle: 0 by size (one kernel from rays of 64 zones, or as
+  int    ion_path;         /* radiation sub-cycle: 0 by size (one kernel from rays of 48 zones, or as
                               AA_ION_FUSED says), 1 the one-kernel form (aa_ion_pass ...), 2 the
                               two-kernel form (aa_ion_rates / aa_ion_update)                   */
   int    nslab;            /* > 1: this ONE Grid of the caller is cut into that many x3 slabs, one per
@@ -142,7 +142,7 @@ int aa_ion_update(aa_grid *g, double dt, long long *cellcount, double *dt_hydro)
  * left to do; otherwise the next pass restarts from the state the entry saved.  Same results bit for bit; optional
  * (AA_ION_SPECULATE=0 in the environment turns it off). */
 int aa_ion_speculate(aa_grid *g, double limit);
-/* The same loop for Grids that run the ONE-KERNEL sub-cycle (aa_ion_is_fused: rays of 64 zones or more; the two
+/* The same loop for Grids that run the ONE-KERNEL sub-cycle (aa_ion_is_fused: rays of 48 zones or more; the two
  * calls above refuse such a Grid).  The loop is cut at its only true barrier, the reduction that yields the step:
  * pass n applies update(n-1) and runs sweep(n) + rates(n) on the updated zones; its reduction words (MIN dt_chem,
  * MIN dt_therm, MAX (|v|+a)/dx, SUM cells out of range, OR negative-dt_chem -- the operands of the reference's four

@@ -10,10 +10,12 @@ k = d.get("kernel_ms_per_step") or d.get("kernel_ms_per_step_rank0") or {}
 n = d.get("kernel_launches_per_step", {})
 nsub = d["config"].get("radiation_subcycles_per_step", d["config"].get("subcycle_trace_per_level", [None])[-1])
 print(f"{name:10s} ms/step {d['ms_per_step']:.4f}  value {d['value']:.3e}  nsub {nsub}  host_syncs/step {d.get('host_syncs_per_step')}  unattributed {d.get('phases', {}).get('unattributed_ms')}")
-print("   " + "  ".join(f"{a} {b*1e3:.0f}us" + (f"/{n[a]:.0f}" if a in n else "") for a, b in list(k.items())[:16]), flush=True)
+if k: print("   " + "  ".join(f"{a} {b*1e3:.0f}us" + (f"/{n[a]:.0f}" if a in n else "") for a, b in list(k.items())[:16]), flush=True)
 P
 }
 run nx80 --nx 80 --steps 40 --warmup 5
+run nx128nk --nx 128 --steps 40 --warmup 5 --no-kernel-times
+run deck2nk --smr --smr-deck --steps 40 --warmup 10 --no-kernel-times
 run nx128 --nx 128 --steps 40 --warmup 5
 run nx192 --nx 192 --steps 20 --warmup 5
 run deck2 --smr --smr-deck --steps 40 --warmup 10
