@@ -31,7 +31,7 @@ static void prof_drain(aa_grid *g)
   for (auto &e : g->pe) {
     for (size_t i = 0; i + 1 < e.ev.size(); i += 2) {
       float ms = 0; hipEventElapsedTime(&ms, e.ev[i], e.ev[i + 1]); e.total_ms += ms;
-      hipEventDestroy(e.ev[i]); hipEventDestroy(e.ev[i + 1]);
+      g->ev_pool.push_back(e.ev[i]); g->ev_pool.push_back(e.ev[i + 1]);
     }
     e.ev.clear();
   }
@@ -211,6 +211,7 @@ void aa_destroy(aa_grid *g)
   hipStreamSynchronize(g->st);
   prof_drain(g);
   hipFree(g->pool); hipFree(g->sc); hipHostFree(g->mb);
+  for (hipEvent_t ev : g->ev_pool) hipEventDestroy(ev);
   if (g->ion_part) hipFree(g->ion_part);
   if (g->ion_words) hipFree(g->ion_words);
   if (g->pin_idx) hipFree(g->pin_idx);
@@ -1169,7 +1170,14 @@ int aa_history(aa_grid *g, double *sums)
 
 // ---- measurement -----------------------------------------------------------------------------
 // (a Grid cut into slabs reports its first slab's kernels)
-int aa_profile_enable(aa_grid *g, int on) { if (!g->slab.empty()) return aa_profile_enable(g->slab[0], on); prof_drain(g); g->prof = on != 0; return 0; }
+int aa_profile_enable(aa_grid *g, int on)
+{
+  if (!g->slab.empty()) return aa_profile_enable(g->slab[0], on);
+  prof_drain(g); g->prof = on != 0;
+  // events for a few dozen steps ahead: a timed region then creates none (hipEventCreate showed on the small Grids of the reference's decks)
+  if (on) while (g->ev_pool.size() < 4096) { hipEvent_t ev; if (hipEventCreate(&ev) != hipSuccess) break; g->ev_pool.push_back(ev); }
+  return 0;
+}
 int aa_profile_reset(aa_grid *g)
 { if (!g->slab.empty()) return aa_profile_reset(g->slab[0]); prof_drain(g); for (auto &e : g->pe) { e.total_ms = 0; e.launches = 0; } return 0; }
 int aa_profile_count(const aa_grid *g) { if (!g->slab.empty()) return aa_profile_count(g->slab[0]); return (int)g->pe.size(); }

@@ -64,6 +64,7 @@ struct aa_grid {
   struct SlabLink *link = nullptr;
   bool prof = false;
   std::vector<ProfEntry> pe;
+  std::vector<hipEvent_t> ev_pool;     // events of drained scopes, reused (a small Grid's step is ~25 scopes: creating 50 events per step showed)
 };
 
 // ---- profiling: an event pair around every kernel-chain stage, on the launch stream ----------
@@ -73,7 +74,9 @@ struct Scope {
     if (!g->prof) return;
     for (size_t i = 0; i < g->pe.size(); i++) if (g->pe[i].name == name) { id = (int)i; break; }
     if (id < 0) { g->pe.push_back(ProfEntry()); id = (int)g->pe.size() - 1; g->pe[id].name = name; }
-    hipEventCreate(&a); hipEventCreate(&b); hipEventRecord(a, g->st);
+    if (g->ev_pool.size() >= 2) { a = g->ev_pool.back(); g->ev_pool.pop_back(); b = g->ev_pool.back(); g->ev_pool.pop_back(); }
+    else { hipEventCreate(&a); hipEventCreate(&b); }
+    hipEventRecord(a, g->st);
   }
   ~Scope() {
     if (id < 0) return;
