@@ -463,8 +463,9 @@ int aa_fetch_scalars(aa_grid *g)
   if (!g->slab.empty()) return fail(-1, "[aa_fetch_scalars]: not available on a Grid cut into slabs");
   g->host_syncs++;
   if (g->d.cfg.mailbox && g->mb_dev) {
-    const unsigned long long seq = ++g->mb_seq;
-    launch_publish(g->sc, g->mb_dev, seq, g->st);
+    unsigned long long seq;
+    if (g->mb_prepublished && g->mb_prepublished == g->mb_seq) { seq = g->mb_seq; g->mb_prepublished = 0; }      // (k_ion_reduce_pick has published them)
+    else { seq = ++g->mb_seq; launch_publish(g->sc, g->mb_dev, seq, g->st); }
     volatile unsigned long long *stamp = &g->mb->seq;
     struct timespec t0; clock_gettime(CLOCK_MONOTONIC, &t0);
     for (unsigned spins = 1;; spins++) {
@@ -775,6 +776,7 @@ int aa_ion_pass(aa_grid *g, int update, int sweep, double *dev_words)
     return slabs_ion_pass(g, update, sweep);
   }
   if (!update && !sweep) return fail(-1, "[aa_ion_pass]: nothing to do");
+  g->mb_prepublished = 0;
   if (update) {
     // relying on the rates of the previous sweep makes that sweep the one that counts
     if (!g->ion_pending) return fail(-1, "[aa_ion_pass]: update without a preceding sweep");
@@ -823,7 +825,11 @@ int aa_ion_pick(aa_grid *g, const double *dev_words_all, int nranks, int first, 
     return fail(-1, "[aa_ion_pick]: limit %.17g, but aa_ion_speculate was told %.17g", limit, g->ion_spec_limit);
   if (g->ion_fuse_pick) {      // (ion_run_fused, one rank: the pass left its records unfolded)
     if (dev_words_all) return fail(-1, "[aa_ion_pick]: internal: a fused pick with gathered words");
-    launch_ion_reduce_pick(g->d, g->ion_part, g->ion_words, g->sc, first, limit, g->st, first ? (g->ion_spec_armed ? 1 : 0) : 0);
+    // (not the first pick of an ion step: aa_ion_fetch follows at once -- the kernel publishes the scalars itself)
+    const bool pub = !first && g->d.cfg.mailbox && g->mb_dev;
+    if (pub) g->mb_prepublished = ++g->mb_seq;
+    launch_ion_reduce_pick(g->d, g->ion_part, g->ion_words, g->sc, first, limit, g->st, first ? (g->ion_spec_armed ? 1 : 0) : 0,
+                           pub ? g->mb_dev : nullptr, pub ? g->mb_seq : 0ULL);
   } else
   launch_ion_pick2(dev_words_all ? dev_words_all : g->ion_words, dev_words_all ? nranks : 1, g->sc, first, limit, g->st,
                    first ? (g->ion_spec_armed ? 1 : 0) : 0);

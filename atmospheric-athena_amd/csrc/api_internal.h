@@ -25,6 +25,7 @@ struct aa_grid {
   aa::DevScalars *sc_host = nullptr;   // pinned (= &mb->s)
   aa::Mailbox *mb = nullptr, *mb_dev = nullptr;   // the pinned mailbox and its device address (grid.h Mailbox); mb_seq: stamps handed out
   unsigned long long mb_seq = 0;
+  unsigned long long mb_prepublished = 0;   // stamp of the scalars the last fused pick already put into the mailbox (0: none): the fetch right behind it only polls
   bool ion_fuse_pick = false;          // the pass just queued left its records unfolded: aa_ion_pick folds and picks in one launch (one rank)
   long long *pin_idx = nullptr; aa::Real *pin_val = nullptr; long long npin = 0;
   double *cfl_part = nullptr; long cfl_part_n = 0;   // the blocks' CFL maxima of k_update<CFL> (van Leer integrator), 3 x update_blocks

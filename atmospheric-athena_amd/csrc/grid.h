@@ -147,7 +147,8 @@ void launch_ion_pass(const HostGrid &g, const IonPar &p, bool update, bool sweep
                      const DevScalars *sc, int cur, IonPart *part, Real *words, hipStream_t st, Real spec_dt = -1.0, bool reduce = true);
 void launch_ion_pick2(const Real *words, int nranks, DevScalars *sc, int first, Real dt_limit, hipStream_t st, int spec_armed = 0);
 // one rank: the fold of the pass's records (k_ion_reduce) and the pick in ONE launch; launch_ion_pass(..., reduce = false) goes before it
-void launch_ion_reduce_pick(const HostGrid &g, const IonPart *part, Real *words, DevScalars *sc, int first, Real dt_limit, hipStream_t st, int spec_armed);
+void launch_ion_reduce_pick(const HostGrid &g, const IonPart *part, Real *words, DevScalars *sc, int first, Real dt_limit, hipStream_t st, int spec_armed,
+                            Mailbox *mb_dev = nullptr, unsigned long long seq = 0);      // mb_dev: also publish the scalars (stamp seq)
 void launch_ion_finish(const DevGrid &g, int cur, hipStream_t st);
 void launch_test_explog(int n, const Real *x, Real *ye, Real *yl, hipStream_t st);   // n a multiple of 4
 

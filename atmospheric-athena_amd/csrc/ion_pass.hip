@@ -551,7 +551,7 @@ AA_DEV void ion_pick_body(Real dt_chem, Real dt_therm, Real max_dti, Real count,
 // ... and, where ONE rank reduces alone, the pick of k_ion_pick2 by the same launch (the same fold, the same arithmetic): a sub-cycle
 // on a small Grid is a handful of launches and one read-back, and every launch less is ~5 us of 40
 __global__ void __launch_bounds__(256)
-k_ion_reduce_pick(const IonPart *part, int n, Real *words, DevScalars *sc, int first, Real dt_limit, int spec_armed)
+k_ion_reduce_pick(const IonPart *part, int n, Real *words, DevScalars *sc, int first, Real dt_limit, int spec_armed, Mailbox *mb, unsigned long long seq)
 {
   __shared__ Real red[5][256];
   Real a = DBL_MAX, b = DBL_MAX, c = 0.0, d = 0.0, e = 0.0;
@@ -575,6 +575,15 @@ k_ion_reduce_pick(const IonPart *part, int n, Real *words, DevScalars *sc, int f
   // (one rank: k_ion_pick2's fold over ranks is MIN / MAX / + of one operand with its neutral element: the operand itself)
   if (threadIdx.x == 0)
     ion_pick_body(rmin(DBL_MAX, red[0][0]), rmin(DBL_MAX, red[1][0]), rmax(0.0, red[2][0]), 0.0 + red[3][0], rmax(0.0, red[4][0]), sc, first, dt_limit, spec_armed);
+  if (mb) {      // ... and the scalars straight into the host's mailbox (grid.h Mailbox, k_publish): the read-back that follows needs no launch
+    __threadfence(); __syncthreads();
+    constexpr int nw = (int)(sizeof(DevScalars)/sizeof(unsigned long long));
+    const unsigned long long *src = (const unsigned long long*)sc;
+    unsigned long long *dst = (unsigned long long*)&mb->s;
+    if ((int)threadIdx.x < nw) dst[threadIdx.x] = __hip_atomic_load(src + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __threadfence_system(); __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(&mb->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
 }
 
 // ionrad_3d.c:941-967 on the device, over the words of all ranks (AA_ION_WORDS doubles each; one rank: the
@@ -681,8 +690,9 @@ int ion_pass_blocks(const HostGrid &g)
 void launch_ion_begin16(const DevGrid &g, const IonPar &p, hipStream_t st)
 { const long n = (long)g.Nx1*g.Nx2*g.Nx3; hipLaunchKernelGGL(k_ion_begin16, dim3(nblk(n, 256)), dim3(256), 0, st, g, p); }
 
-void launch_ion_reduce_pick(const HostGrid &g, const IonPart *part, Real *words, DevScalars *sc, int first, Real dt_limit, hipStream_t st, int spec_armed)
-{ hipLaunchKernelGGL(k_ion_reduce_pick, dim3(1), dim3(256), 0, st, part, ion_pass_blocks(g), words, sc, first, dt_limit, spec_armed); }
+void launch_ion_reduce_pick(const HostGrid &g, const IonPart *part, Real *words, DevScalars *sc, int first, Real dt_limit, hipStream_t st, int spec_armed,
+                            Mailbox *mb_dev, unsigned long long seq)
+{ hipLaunchKernelGGL(k_ion_reduce_pick, dim3(1), dim3(256), 0, st, part, ion_pass_blocks(g), words, sc, first, dt_limit, spec_armed, mb_dev, seq); }
 void launch_ion_pass(const HostGrid &g, const IonPar &p, bool update, bool sweep, bool begin, Real flux0, bool from_edgeflux,
                      const DevScalars *sc, int cur, IonPart *part, Real *words, hipStream_t st, Real spec_dt, bool reduce)
 {
