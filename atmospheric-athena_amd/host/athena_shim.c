@@ -29,10 +29,7 @@
  *   AA_COHERENCE=step  (default) the host block is refreshed after Integrate() (so that
  *                      Userwork_in_loop sees and may edit it; re-uploaded before new_dt) and
  *                      after the end-of-step bvals_mhd (so data_output sees ghost zones too).
- *                      Always correct, whatever the problem file does; costs three PCIe transfers of U per step -- two where
- *                      Userwork_in_loop does not write: between the refresh and new_dt the whole pages of the host block are
- *                      write-protected, the first store into them (SIGSEGV: the handler unprotects and notes it) marks the block
- *                      as changed, and an unchanged block is not uploaded again (AA_DIRTY_TRACK=0: always uploaded).
+ *                      Always correct, whatever the problem file does; costs three PCIe transfers of U per step.
  *   AA_COHERENCE=auto  (opt-in: a CONTRACT with the problem file) the first two steps run as `step` while the zones
  *                      Userwork_in_loop writes are recorded; if both steps wrote the same values into the same zones
  *                      (prob/ioniz_sphere.c:255-306 does; a problem without Userwork trivially does) they are re-imposed
@@ -59,8 +56,6 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
-#include <sys/mman.h>
-#include <unistd.h>
 #include "../../include/athena_compat.h"
 #include "../../include/athena_amd.h"
 
@@ -124,69 +119,6 @@ static size_t ncell[MAXLEV];
 static int integrated = 0;          /* Integrate ran since the last host refresh (SMR) */
 
 #define CHK(call) do { if ((call) != 0) ath_error("[athena_amd]: %s\n", aa_last_error()); } while (0)
-
-/* ---- did Userwork_in_loop write into the host block?  (`step` coherence: the upload before new_dt is only needed if it did) ----
- * The whole pages inside the block are made read-only when the block has been refreshed for Userwork_in_loop; a store into them
- * raises SIGSEGV, whose handler notes the level as written, gives the pages back and returns (the store then goes through).  The
- * partial pages at either end of the block cannot be protected: they are compared with a copy.  Exact: no contract with the problem
- * file.  Every path of the shim that writes the block itself (downloads) lifts the protection first. */
-static struct WriteTrack { char *lo, *hi; int armed, dirty; char *blk; size_t nhead, ntail; char *head, *tail; } wt[MAXLEV];
-static int dirty_track = -1;
-static long wt_uploads = 0, wt_skipped = 0;
-static struct sigaction wt_old;
-static int wt_hooked = 0;
-
-static void wt_on_segv(int sig, siginfo_t *si, void *uc)
-{
-  char *a = (char*)si->si_addr; int l, ours = 0;
-  (void)uc;
-  for (l = 0; l < MAXLEV; l++)
-    if (wt[l].armed && a >= wt[l].lo && a < wt[l].hi) {
-      wt[l].dirty = 1; wt[l].armed = 0;
-      mprotect(wt[l].lo, (size_t)(wt[l].hi - wt[l].lo), PROT_READ | PROT_WRITE);
-      ours = 1;
-    }
-  if (ours) return;
-  sigaction(sig, &wt_old, NULL);        /* not a store into a watched block: the fault repeats under whoever had the signal before */
-}
-
-static void wt_arm(int l, char *blk, size_t bytes)
-{
-  const long pg = sysconf(_SC_PAGESIZE);
-  struct WriteTrack *w = &wt[l];
-  if (dirty_track < 0) { const char *e = getenv("AA_DIRTY_TRACK"); dirty_track = !(e && atoi(e) == 0); }
-  w->armed = 0; w->dirty = 1;           /* (until armed: assume written) */
-  if (!dirty_track || pg <= 0) return;
-  w->blk = blk;
-  w->lo = (char*)(((size_t)blk + (size_t)pg - 1) & ~((size_t)pg - 1));
-  w->hi = (char*)(((size_t)blk + bytes) & ~((size_t)pg - 1));
-  if (w->hi <= w->lo) return;
-  w->nhead = (size_t)(w->lo - blk); w->ntail = (size_t)(blk + bytes - w->hi);
-  if (!w->head && !(w->head = (char*)malloc((size_t)pg))) return;
-  if (!w->tail && !(w->tail = (char*)malloc((size_t)pg))) return;
-  memcpy(w->head, blk, w->nhead); memcpy(w->tail, w->hi, w->ntail);
-  if (!wt_hooked) {
-    struct sigaction sa; memset(&sa, 0, sizeof sa);
-    sa.sa_sigaction = wt_on_segv; sa.sa_flags = SA_SIGINFO; sigemptyset(&sa.sa_mask);
-    if (sigaction(SIGSEGV, &sa, &wt_old) != 0) return;
-    wt_hooked = 1;
-  } else {      /* (the handler steps aside for a fault that is not ours: put it back) */
-    struct sigaction cur; sigaction(SIGSEGV, NULL, &cur);
-    if (cur.sa_sigaction != wt_on_segv) { struct sigaction sa; memset(&sa, 0, sizeof sa); sa.sa_sigaction = wt_on_segv; sa.sa_flags = SA_SIGINFO; sigemptyset(&sa.sa_mask); sigaction(SIGSEGV, &sa, &wt_old); }
-  }
-  w->dirty = 0;
-  if (mprotect(w->lo, (size_t)(w->hi - w->lo), PROT_READ) != 0) { w->dirty = 1; return; }
-  w->armed = 1;
-}
-/* lifts the protection; 1 = the block may have been written since wt_arm */
-static int wt_disarm(int l)
-{
-  struct WriteTrack *w = &wt[l];
-  if (w->armed) { mprotect(w->lo, (size_t)(w->hi - w->lo), PROT_READ | PROT_WRITE); w->armed = 0; }
-  else return 1;                        /* never armed for this refresh, or the handler saw a store */
-  if (w->dirty) return 1;
-  return memcmp(w->head, w->blk, w->nhead) != 0 || memcmp(w->tail, w->hi, w->ntail) != 0;
-}
 
 static double *host_block(int l) { return (double*)&(PG[l]->U[0][0][0]); }   /* ath_array.c:100-117 */
 #if AA_ION_RADPLANE
@@ -422,9 +354,6 @@ static void ensure_grid(MeshS *pM)
 static void to_device(int l)
 {
   if (!HAVE(l)) return;
-  if (host_newer[l] == 2) {            /* refreshed for Userwork_in_loop under write protection: was it written? */
-    if (wt_disarm(l)) { host_newer[l] = 1; wt_uploads++; } else { host_newer[l] = 0; wt_skipped++; }
-  }
   if (host_newer[l]) { CHK(aa_upload_cons(G[l], host_block(l))); host_newer[l] = 0; active_same[l] = 1; }
   CHK(aa_set_mesh_state(G[l], M->time, PG[l]->dt, M->nstep));
 }
@@ -433,9 +362,8 @@ static void to_device(int l)
  * travelled (active_same): then the ghost shell is all that differs */
 static void to_host_x(int l, int ghosts_only)
 {
-  static int shell_ok = -1;      /* AA_GHOST_REFRESH=0: always the whole block (A/B measurements) */
-  if (!HAVE(l)) return;
-  if (host_newer[l] == 2) host_newer[l] = wt_disarm(l) ? 1 : 0;      /* (a download writes the block: the protection goes first) */
+  static int shell_ok = -1;
+  if (!HAVE(l)) return;      /* AA_GHOST_REFRESH=0: always the whole block (A/B measurements) */
   if (shell_ok < 0) { const char *e = getenv("AA_GHOST_REFRESH"); shell_ok = !(e && atoi(e) == 0); }
   if (shell_ok && ghosts_only && active_same[l] && !host_newer[l]) CHK(aa_download_ghost_zones(G[l], host_block(l)));
   else CHK(aa_download_cons(G[l], host_block(l)));
@@ -458,7 +386,6 @@ static void refresh_for_userwork(int l)
   if (learn && learned && !(automode && verify_now)) { CHK(aa_apply_pinned_cells(G[l])); active_same[l] = 0; return; }
   to_host(l);
   host_newer[l] = 1;
-  if (!learn) { wt_arm(l, (char*)host_block(l), ncell[l]*sizeof(ConsS)); if (wt[l].armed) host_newer[l] = 2; }
   if (learn) {
     if (!snap[l]) snap[l] = (double*)malloc(ncell[l]*sizeof(ConsS));
     if (!snap[l]) ath_error("[athena_amd]: out of host memory for the snapshot of the host block\n");
@@ -491,9 +418,6 @@ VDFun_t integrate_init(MeshS *pM)
 void integrate_destruct(void)
 {
   int l;
-  for (l = 0; l < MAXLEV; l++) { if (wt[l].armed) (void)wt_disarm(l); free(wt[l].head); free(wt[l].tail); wt[l].head = wt[l].tail = NULL; }
-  if (wt_uploads + wt_skipped > 0)
-    fprintf(stderr, "[athena_amd] host blocks after Userwork_in_loop: %ld uploaded, %ld left alone (not written: no upload)\n", wt_uploads, wt_skipped);
 #ifdef AA_SMR
   if (MM) { aa_mesh_destroy(MM); MM = NULL; }
 #endif
@@ -599,7 +523,6 @@ void bvals_mhd(DomainS *pD)
         if (d > 0 && nb_lev[l][2*(d - 1) + side] >= 0) continue;     /* not a physical side of this Grid */
 #endif
         if (usr[2*d + side] == NULL) { CHK(aa_bvals_mhd_side(G[l], d, side)); continue; }
-        if (host_newer[l] == 2) host_newer[l] = wt_disarm(l) ? 1 : 0;
         CHK(aa_download_cons(G[l], host_block(l)));
         (*usr[2*d + side])(PG[l]);
         CHK(aa_upload_cons(G[l], host_block(l)));

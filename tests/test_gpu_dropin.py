@@ -289,24 +289,3 @@ def test_userwork_that_wakes_up_later():
     late, err8 = run("athena_userwork_amd", "blast", nx, nlim, {"AA_COHERENCE": "auto"})
     assert "coherence=auto" in err8 and "re-imposed on the device from now on" in err8
     assert "WARNING: Userwork_in_loop no longer writes the imprint" in err8 and "falls back to `step`" in err8
-
-
-def test_unwritten_host_block_is_not_uploaded_again():
-    """`step` coherence refreshes the host block for Userwork_in_loop after every Integrate and used to upload it again before new_dt
-    whatever happened.  The whole pages of the block are now write-protected in between; the first store into them (SIGSEGV: the shim's
-    handler unprotects and notes it) marks the block as written, and an unwritten block stays where it is -- exact, no contract with
-    the problem file.  blast (an empty Userwork_in_loop): no upload at all; ioniz_sphere and the late-waking fixture (they write every
-    step): every step; AA_DIRTY_TRACK=0: the round-3 behaviour; the dumps are the same bit for bit either way."""
-    if not os.path.exists(os.path.join(REFBIN, "athena_blast_amd")):
-        pytest.skip("oracle/_ref drop-in executables not built (make -C oracle ref)")
-    nx, nlim = (40, 24, 20), 5
-    on, err = run("athena_blast_amd", "blast", nx, nlim)
-    off, err0 = run("athena_blast_amd", "blast", nx, nlim, {"AA_DIRTY_TRACK": "0"})
-    assert f"0 uploaded, {nlim} left alone" in err, err[-600:]
-    assert "left alone" not in err0
-    assert np.array_equal(on["U"], off["U"]) and on["dt"] == off["dt"] and on["time"] == off["time"]
-    sph, errs = run("athena_ioniz_sphere_amd", "ioniz_sphere", (32, 32, 32), 3)
-    assert "3 uploaded, 0 left alone" in errs, errs[-600:]
-    if os.path.exists(os.path.join(REFBIN, "athena_userwork_amd")):
-        _, erru = run("athena_userwork_amd", "blast", (20, 16, 12), 6)
-        assert "6 uploaded, 0 left alone" in erru, erru[-600:]
