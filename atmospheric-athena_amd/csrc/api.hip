@@ -237,7 +237,7 @@ long long aa_device_bytes(const aa_grid *g) { return g->slab.empty() ? g->bytes 
 // ---- state transfer: staging through the (idle) face-state area ---------------------------
 int aa_upload_cons(aa_grid *g, const double *U)
 {
-  g->cfl_ready = false;
+  g->cfl_ready = false; g->active_dirty = false;      // (host and device agree on the active zones from here on)
   g->inner_swept = false;          // the state changes under a pending aa_integrate_begin: its sweeps are redone
   if (!g->slab.empty()) return slabs_upload_cons(g, U);
   const int nvar = 5 + g->p.nscal; const size_t n = (size_t)g->d.N1*g->d.N2*g->d.N3*nvar;
@@ -254,6 +254,7 @@ int aa_download_cons(aa_grid *g, double *U)
   launch_soa_to_aos(g->d, nvar, g->d.LR, g->st);
   HIPCHK(hipMemcpyAsync(U, g->d.LR, n*sizeof(Real), hipMemcpyDeviceToHost, g->st));
   HIPCHK(hipStreamSynchronize(g->st));
+  g->active_dirty = false;
   return 0;
 }
 // Only the GHOST zones of the host block [N3][N2][N1][nvar] (the caller knows its active zones are current: nothing but
@@ -262,6 +263,9 @@ int aa_download_cons(aa_grid *g, double *U)
 int aa_download_ghost_zones(aa_grid *g, double *U)
 {
   if (!g->slab.empty()) return slabs_download_cons(g, U);
+  // the caller says its active zones are current; the library knows whether any call since the last full transfer wrote active zones
+  // (the integrators, the ion step, pinned zones, restriction / flux correction): then the whole block travels
+  if (g->active_dirty) return aa_download_cons(g, U);
   g->inner_swept = false;
   const int nvar = 5 + g->p.nscal, N1 = g->d.N1, N2 = g->d.N2, N3 = g->d.N3, ng = AA_NGHOST;
   const size_t row = (size_t)N1*nvar*sizeof(Real), plane = row*N2;
@@ -383,7 +387,7 @@ int aa_set_pinned_cells(aa_grid *g, long long n, const long long *index, const d
   if (g->pin_val) { hipFree(g->pin_val); g->pin_val = nullptr; }
   if (g->pin_mask) { hipFree(g->pin_mask); g->pin_mask = nullptr; }
   g->npin = 0;
-  g->cfl_ready = false;
+  g->cfl_ready = false; g->active_dirty = true;
   if (n <= 0) return 0;
   const int nvar = 5 + g->p.nscal;
   HIPCHK(hipMalloc(&g->pin_idx, (size_t)n*sizeof(long long)));
@@ -583,7 +587,7 @@ static void no_h_correction(aa_grid *g)
 int aa_integrate_3d_ctu(aa_grid *g)
 {
   if (!g->slab.empty()) return slabs_integrate(g, 0);
-  g->cfl_ready = false;
+  g->cfl_ready = false; g->active_dirty = true;
   const HostGrid &d = g->d; const int ns = g->p.nscal; const Real dt = g->dt;
   if (g->inner_swept) {      // aa_integrate_begin did the planes ks .. ke: the two ghost planes either side remain
     if (g->inner_dt != dt) return fail(-1, "[aa_integrate_3d_ctu]: dt changed after aa_integrate_begin");
@@ -631,7 +635,7 @@ int aa_integrate_3d_ctu(aa_grid *g)
 int aa_integrate_3d_vl(aa_grid *g)
 {
   if (!g->slab.empty()) return slabs_integrate(g, 1);
-  g->cfl_ready = false;
+  g->cfl_ready = false; g->active_dirty = true;
   // integrate_3d_vl.c:96-: donor-cell fluxes -> U^{n+1/2} -> PLM or PPM (no tracing) + Roe -> update
   const HostGrid &d = g->d; const int ns = g->p.nscal; const Real dt = g->dt;
   // donor-cell fluxes + U^{n+1/2} in one marching kernel from 2^18 zones (512^3: 16.8 -> 9.7 ms; same at 80^3;
@@ -653,7 +657,7 @@ int aa_integrate_3d_vl(aa_grid *g)
       const long nb = update_blocks(d);
       if (g->cfl_part_n < 3*nb) {
         if (g->cfl_part) { (void)hipFree(g->cfl_part); g->cfl_part = nullptr; g->cfl_part_n = 0; }
-        if (hipMalloc(&g->cfl_part, (size_t)3*nb*sizeof(Real)) == hipSuccess) g->cfl_part_n = 3*nb; else g->cfl_ready = false;
+        if (hipMalloc(&g->cfl_part, (size_t)3*nb*sizeof(Real)) == hipSuccess) g->cfl_part_n = 3*nb; else g->cfl_ready = false; g->active_dirty = true;
       }
     }
     launch_update(d, ns, d.LR, dt, g->grav, g->st, g->cfl_ready ? g->sc : nullptr, g->cfl_part, g->pin_mask);   // d^{n+1/2} = Uhalf.d
@@ -664,7 +668,7 @@ int aa_integrate_3d_vl(aa_grid *g)
 
 int aa_ion_begin(aa_grid *g)
 {
-  g->cfl_ready = false;
+  g->cfl_ready = false; g->active_dirty = true;
   if (!g->p.ion) return fail(-1, "[ion_radtransfer]: ion radiation is off");
   if (!g->slab.empty()) return slabs_ion_begin(g);
   if (g->ion_fused) {
@@ -712,7 +716,7 @@ int aa_ion_rates(aa_grid *g, double *dt_chem, double *dt_therm)
 
 int aa_ion_update(aa_grid *g, double dt, long long *cellcount, double *dt_hydro)
 {
-  g->cfl_ready = false;
+  g->cfl_ready = false; g->active_dirty = true;
   if (!g->slab.empty()) return slabs_ion_update(g, dt, cellcount, dt_hydro);
   if (g->ion_fused) return fail(-1, "[aa_ion_update]: this Grid runs the one-kernel sub-cycle (aa_ion_pass / aa_ion_pick / aa_ion_fetch)");
   HIPCHK(hipMemsetAsync(&g->sc->max_dti, 0, 2*sizeof(unsigned long long), g->st));
@@ -738,7 +742,7 @@ int aa_ion_arm(aa_grid *g)
 int aa_ion_subcycle(aa_grid *g, double dt_done, double limit, double *dt, int *limit_hit, double *dt_chem,
                     double *dt_therm, long long *cellcount, double *dt_hydro)
 {
-  g->cfl_ready = false;
+  g->cfl_ready = false; g->active_dirty = true;
   if (!g->slab.empty()) return fail(-1, "[aa_ion_subcycle]: not available on a Grid cut into slabs (aa_ion_run / aa_ion_rates + aa_ion_update)");
   if (g->ion_fused) return fail(-1, "[aa_ion_subcycle]: this Grid runs the one-kernel sub-cycle");
   if (g->nradplane > 0) {
@@ -769,7 +773,7 @@ int aa_ion_is_fused(const aa_grid *g) { return g->ion_fused ? 1 : 0; }
 // Grid's words of the reduction go to dev_words (DEVICE, AA_ION_WORDS doubles; NULL: kept in the Grid)
 int aa_ion_pass(aa_grid *g, int update, int sweep, double *dev_words)
 {
-  g->cfl_ready = false;
+  g->cfl_ready = false; g->active_dirty = true;
   if (!g->ion_fused) return fail(-1, "[aa_ion_pass]: this Grid runs the two-kernel sub-cycle (aa_ion_rates / aa_ion_update)");
   if (!g->slab.empty()) {
     if (dev_words) return fail(-1, "[aa_ion_pass]: a Grid cut into slabs reduces over its slabs itself");
@@ -944,7 +948,7 @@ static int ion_run_phased(aa_grid *g, bool fine, double limit, int *niter_out, d
 
 int aa_ion_run(aa_grid *g, int finegrid, double limit, int *niter_out, double *dt_done_out)
 {
-  g->cfl_ready = false;
+  g->cfl_ready = false; g->active_dirty = true;
   if (!g->slab.empty() && !g->ion_fused) return slabs_ion_run_phased(g, limit, niter_out, dt_done_out);
   return g->ion_fused ? ion_run_fused(g, finegrid != 0, limit, niter_out, dt_done_out)
                       : ion_run_phased(g, finegrid != 0, limit, niter_out, dt_done_out);
@@ -964,7 +968,7 @@ int aa_ion_radtransfer_3d(aa_grid *g, int *niter_out)
 int aa_ion_radtransfer_3d_gather(aa_grid *g, double *dev_words, const double *dev_words_all, int nranks, aa_gather_fn gather,
                                  void *ctx, int *niter_out)
 {
-  g->cfl_ready = false;
+  g->cfl_ready = false; g->active_dirty = true;
   if (!g->slab.empty()) return fail(-1, "[aa_ion_radtransfer_3d_gather]: a Grid cut into slabs reduces over its slabs itself (aa_ion_radtransfer_3d)");
   if (!g->ion_fused) return fail(-1, "[aa_ion_radtransfer_3d_gather]: this Grid runs the two-kernel sub-cycle (aa_ion_rates / aa_ion_update)");
   if (gather && (!dev_words || !dev_words_all || nranks < 1)) return fail(-1, "[aa_ion_radtransfer_3d_gather]: word buffers");
@@ -1054,7 +1058,7 @@ int aa_pack_x2(aa_grid *g, int side, double *buf)
 int aa_unpack_x2(aa_grid *g, int side, const double *buf)
 {
   NO_SLABS("aa_unpack_x2");
-  g->inner_swept = false; g->cfl_ready = false;
+  g->inner_swept = false; g->cfl_ready = false;      // (ghost zones only: the host's active zones stay current)
   Scope s(g, "halo_unpack");
   const int j0 = side == 0 ? g->d.js - AA_NGHOST : g->d.je + 1;    // unpack_ix2 / unpack_ox2
   launch_unpack_x2(g->d, 5 + g->p.nscal, j0, buf, g->st);
@@ -1079,7 +1083,7 @@ int aa_halo_put(aa_grid *g, int dir, int side, const double *host_buf)
 {
   NO_SLABS("aa_halo_put");
   if ((dir != 1 && dir != 2) || side < 0 || side > 1 || !host_buf) return fail(-1, "[aa_halo_put]: dir=%d side=%d", dir, side);
-  g->inner_swept = false; g->cfl_ready = false;
+  g->inner_swept = false; g->cfl_ready = false;      // (ghost zones only: the host's active zones stay current)
   HIPCHK(hipMemcpyAsync(g->d.LR, host_buf, (size_t)aa_halo_doubles_dir(g, dir)*sizeof(Real), hipMemcpyHostToDevice, g->st));
   int rc = dir == 1 ? aa_unpack_x2(g, side, g->d.LR) : aa_unpack_x3(g, side, g->d.LR); if (rc) return rc;
   HIPCHK(hipStreamSynchronize(g->st));      // (host_buf and the staging area are the caller's again)

@@ -37,6 +37,7 @@ struct aa_grid {
   bool cfl_force = false;              // AA_CFL_FUSED=2: also in the strict build
   bool cfl_step = true;                // aa_step does so by itself (AA_CFL_FUSED=0: k_cfl)
   bool cfl_ready = false;              //   ... and has done so for the state as it is now
+  bool active_dirty = true;            // a call since the last full upload / download of U wrote ACTIVE zones on the device (aa_download_ghost_zones then moves the whole block)
   bool grav = false;
   int cool = 0;                        // aa_set_cooling: 1 = KoyInut; the integrator then launches the kernels of namespace aa_cool
   int rad_dir = 0, nradplane = 0; aa::Real flux_i = 0;

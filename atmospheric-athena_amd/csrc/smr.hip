@@ -440,6 +440,7 @@ int aa_mesh_set_state(aa_mesh *m, double time, double dt, int nstep)
 // flux correction adds q*(0-0); here the flux arrays are zero-initialised, to the same effect.
 int aa_mesh_restrict_correct_pair(aa_mesh *m, int l)      // level l+1 -> level l
 {
+  if (l >= 0 && l + 1 < m->nl) m->lev[m->par[l]]->active_dirty = true;
   if (l < 0 || l + 1 >= m->nl) return aa_fail(-1, "[aa_mesh_restrict_correct_pair]: pair %d", l);
   aa_grid *P = m->lev[m->par[l]], *C = m->lev[l + 1];       // link l: grid l+1 on its parent
   const Link &L = m->link[l];
@@ -468,6 +469,7 @@ int aa_mesh_restrict_correct(aa_mesh *m)
 // smr.c:85: E and s[0] only, after the radiation step
 int aa_mesh_ionrad_restrict_correct(aa_mesh *m)
 {
+  for (int l = 0; l < m->nl; l++) m->lev[l]->active_dirty = true;
   for (int q = 0; q + 1 < m->nl; q++) {
     const int l = m->f2c[q];
     aa_grid *P = m->lev[m->par[l]], *C = m->lev[l + 1];
@@ -557,6 +559,7 @@ int aa_flux_x3_export(aa_grid *child, int side, double *dev_buf)
 // ... and its application to the plane of the parent slab across the cut (Grid dt as in RestrictCorrect)
 int aa_flux_x3_apply(aa_grid *parent, int side, int i0, int j0, int n1, int n2, const double *dev_buf)
 {
+  parent->active_dirty = true;
   if (!parent->slab.empty()) return aa_fail(-1, "[aa_flux_x3_apply]: not available on a Grid cut into slabs");
   if (i0 < AA_NGHOST || j0 < AA_NGHOST || i0 + n1 > AA_NGHOST + parent->p.Nx[0] || j0 + n2 > AA_NGHOST + parent->p.Nx[1])
     return aa_fail(-1, "[aa_flux_x3_apply]: region outside the Grid");

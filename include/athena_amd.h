@@ -76,7 +76,9 @@ long long   aa_device_bytes(const aa_grid *g);
 int aa_upload_cons(aa_grid *g, const double *U_aos);      /* host ConsS block -> device SoA */
 int aa_download_cons(aa_grid *g, double *U_aos);
 /* Only the ghost zones of the block (its active zones are left alone): for a caller whose host copy of the active zones is
- * current, i.e. nothing but aa_bvals_* / aa_new_dt ran on the device since the block last travelled either way. */
+ * current, i.e. nothing but aa_bvals_* / aa_new_dt ran on the device since the block last travelled either way.  The library keeps
+ * track itself: if any call since the last aa_upload_cons / aa_download_cons wrote active zones (integrators, ion step, pinned
+ * zones, restriction / flux correction) the whole block is downloaded instead. */
 int aa_download_ghost_zones(aa_grid *g, double *U_aos);
 int aa_upload_edgeflux(aa_grid *g, const double *ef);
 int aa_download_edgeflux(aa_grid *g, double *ef);

@@ -268,3 +268,16 @@ def test_committed_traffic_profile_belongs_to_the_kernel_sources():
         tj = json.load(open(os.path.join(ROOT, "profiles", f)))
         assert tj["source_fingerprint"] == bench.source_fingerprint(), f"profiles/{f} was taken on other kernel sources: re-run profiles/prof_r04.sh"
         assert tj["workload"].startswith("ioniz_sphere 512x512x512")
+
+
+def test_bench_helpers_without_a_gpu():
+    """bench.py's CPU-side pieces: the rank grid of the CPU leg never cuts x1 and uses what divides; the kernel sources' fingerprint is
+    a function of the files' bytes."""
+    sys.path.insert(0, ROOT)
+    import bench
+    assert bench._rank_grid(16, 128) == (4, 4) and bench._rank_grid(1, 128) == (1, 1)
+    p2, p3 = bench._rank_grid(128, 256)
+    assert p2 * p3 <= 128 and 256 % p2 == 0 and 256 % p3 == 0 and p2 * p3 >= 64
+    fp = bench.source_fingerprint()
+    assert len(fp) == 16 and fp == bench.source_fingerprint()
+    assert bench.kernel_class("correct_all") == "hydro" and bench.kernel_class("ion_pass") == "subcycle" and bench.kernel_class("bvals_mhd") == "other"
