@@ -798,6 +798,9 @@ def main():
         try:
             import torch.distributed as dist1
             os.environ["AA_FORCE_DISTRIBUTED"] = "1"
+            if "MASTER_PORT" not in os.environ:      # a port of our own: another job on the host may hold the default one
+                import socket
+                sk = socket.socket(); sk.bind(("127.0.0.1", 0)); os.environ["MASTER_PORT"] = str(sk.getsockname()[1]); sk.close()
             init_pg(dist1, torch, 0, 1, local)
             cd = Ctx(a, aa, driver, torch, dist1, 0, 1, local, True)
             wd = run_window(cd, False, a.spinup, a.steps, a.warmup)
