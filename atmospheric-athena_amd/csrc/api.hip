@@ -560,13 +560,15 @@ static bool x3_fused(const aa_grid *g)      // default: always (round 3; until t
 // does not apply: composite Grids, third order (the slope arrays come first), the unfused correct / update chains, VL.
 // the kernels of a run with a cooling function are the second compilation of hydro_kernels.hip (namespace aa_cool)
 #define HL(f) (g->cool ? aa_cool::f : aa::f)
+// ... and with it the x1 first pass (round 4: hydro_kernels.hip CA_X1F): no k_sweep_x1_flat launch before k_correct_all
+static bool x1_fused(const aa_grid *g) { return g->correct_all && x3_fused(g) && HL(ca_x1_on_board)(); }
 int aa_integrate_begin(aa_grid *g)
 {
   if (!g->slab.empty() || g->p.integrator != 0 || g->d.slope || !g->correct_all || !g->fused_update || g->inner_swept) return 0;
   const HostGrid &d = g->d; const int ns = g->p.nscal; const Real dt = g->dt;
   const int nk = d.ke - d.ks + 1;
   { Scope s(g, "sweep_x2"); HL(launch_sweep)(d, ns, 1, dt, g->grav, g->st, 2, nk); }
-  { Scope s(g, "sweep_x1"); HL(launch_sweep)(d, ns, 0, dt, g->grav, g->st, 2, nk); }
+  if (!x1_fused(g)) { Scope s(g, "sweep_x1"); HL(launch_sweep)(d, ns, 0, dt, g->grav, g->st, 2, nk); }
   g->inner_swept = true;
   g->inner_dt = dt;
   HIPCHK(hipGetLastError());
@@ -594,7 +596,7 @@ int aa_integrate_3d_ctu(aa_grid *g)
     g->inner_swept = false;
     const int nk = d.ke - d.ks + 1;
     { Scope s(g, "sweep_x2"); HL(launch_sweep)(d, ns, 1, dt, g->grav, g->st, 0, 2); HL(launch_sweep)(d, ns, 1, dt, g->grav, g->st, 2 + nk, 2); }
-    { Scope s(g, "sweep_x1"); HL(launch_sweep)(d, ns, 0, dt, g->grav, g->st, 0, 2); HL(launch_sweep)(d, ns, 0, dt, g->grav, g->st, 2 + nk, 2); }
+    if (!x1_fused(g)) { Scope s(g, "sweep_x1"); HL(launch_sweep)(d, ns, 0, dt, g->grav, g->st, 0, 2); HL(launch_sweep)(d, ns, 0, dt, g->grav, g->st, 2 + nk, 2); }
     if (!x3_fused(g)) { Scope s(g, "sweep_x3"); HL(launch_sweep)(d, ns, 2, dt, g->grav, g->st, 0, -1); }
     { Scope s(g, "correct_all"); HL(launch_correct_all)(d, ns, dt, g->grav, x3_fused(g), g->st); }
     no_h_correction(g);
@@ -609,7 +611,7 @@ int aa_integrate_3d_ctu(aa_grid *g)
   { Scope s(g, "sweep_x2"); HL(launch_sweep)(d, ns, 1, dt, g->grav, g->st, 0, -1); }
   if (!(g->correct_all && x3_fused(g))) { Scope s(g, "sweep_x3"); HL(launch_sweep)(d, ns, 2, dt, g->grav, g->st, 0, -1); }
   if (g->correct_all) {
-    { Scope s(g, "sweep_x1"); HL(launch_sweep)(d, ns, 0, dt, g->grav, g->st, 0, -1); }
+    if (!x1_fused(g)) { Scope s(g, "sweep_x1"); HL(launch_sweep)(d, ns, 0, dt, g->grav, g->st, 0, -1); }
     { Scope s(g, "correct_all"); HL(launch_correct_all)(d, ns, dt, g->grav, x3_fused(g), g->st); }
   } else {
     { Scope s(g, "sweep_correct_x1"); HL(launch_sweep_correct_x1)(d, ns, dt, g->grav, g->st); }

@@ -681,9 +681,8 @@ struct CellFlux {            // first-pass fluxes across one zone
 // one zone along D, first half: reconstruction + gravity kick = the primitive states the FIRST pass solves its Riemann
 // problems with (face_work): the left state belongs to the zone's upper face, the right state to its lower one
 template <int NS, int D, bool GRAV, int ORD>
-AA_DEV void cell_recon(const DevGrid &g, long m, Real dt, const Real wm[6], const Real w[6], const Real wp[6], Real wl[6], Real wr[6])
+AA_DEV void cell_recon(const DevGrid &g, long m, Real dt, Real dtodx, const Real wm[6], const Real w[6], const Real wp[6], Real wl[6], Real wr[6])
 {
-  const Real dtodx = dt/g.dx[D];
   const long sD = stride<D>(g);
   recon_cell<NS, true, ORD, D>(g, m, wm, w, wp, dtodx, wl, wr);
   if (GRAV) {
@@ -695,13 +694,16 @@ AA_DEV void cell_recon(const DevGrid &g, long m, Real dt, const Real wm[6], cons
   cool_states(g, dt, wl, wr);
 #endif
 }
+template <int NS, int D, bool GRAV, int ORD>
+AA_DEV void cell_recon(const DevGrid &g, long m, Real dt, const Real wm[6], const Real w[6], const Real wp[6], Real wl[6], Real wr[6])
+{ cell_recon<NS, D, GRAV, ORD>(g, m, dt, dt/g.dx[D], wm, w, wp, wl, wr); }
 // the same with the kicks of the zone taken from its CellFlux (formed at the head of the iteration from the potential
 // values loaded there: a load inside the direction blocks would wait for the stores of the block before it)
 template <int NS, int D, bool GRAV, int ORD>
-AA_DEV void cell_recon(const DevGrid &g, long m, Real dt, const CellFlux &cf, const Real wm[6], const Real w[6], const Real wp[6],
+AA_DEV void cell_recon(const DevGrid &g, long m, Real dt, Real dtodx, const CellFlux &cf, const Real wm[6], const Real w[6], const Real wp[6],
                        Real wl[6], Real wr[6])
 {
-  recon_cell<NS, true, ORD, D>(g, m, wm, w, wp, dt/g.dx[D], wl, wr);
+  recon_cell<NS, true, ORD, D>(g, m, wm, w, wp, dtodx, wl, wr);
   if (GRAV) { wl[1] -= cf.kl[D]; wr[1] -= cf.kr[D]; }
 #if AA_COOLING
   cool_states(g, dt, wl, wr);
@@ -747,26 +749,67 @@ AA_DEV void cell_finish(const DevGrid &g, long m, const Real q[3], const CellFlu
   lam_l = lambda_face(sl, g.Gamma, g.Gamma_1, -1.0);
 }
 template <int NS, int D, bool GRAV, int ORD>
-AA_DEV void cell_states(const DevGrid &g, long m, Real dt, const Real q[3], const CellFlux &cf, const Real wm[6], const Real w[6],
+AA_DEV void cell_states(const DevGrid &g, long m, Real dt, Real dtodx, const Real q[3], const CellFlux &cf, const Real wm[6], const Real w[6],
                         const Real wp[6], bool store, Real &lam_l, Real &lam_r)
 {
   Real wl[6], wr[6];
-  cell_recon<NS, D, GRAV, ORD>(g, m, dt, cf, wm, w, wp, wl, wr);
+  cell_recon<NS, D, GRAV, ORD>(g, m, dt, dtodx, cf, wm, w, wp, wl, wr);
   cell_finish<NS, D, GRAV>(g, m, q, cf, wl, wr, store, lam_l, lam_r);
 }
 
 #ifndef CA_PARK
 #define CA_PARK 1
 #endif
+// dt/dx_d and half of it, formed by the launcher (the same IEEE quotient the kernels form): as kernel arguments they live in scalar
+// registers, formed in the kernel they took twelve vector registers through the whole march
+struct StepRatios { Real dtodx[3], q[3]; };
+// CA_X1F: with the x3 first pass on board (X3F), k_correct_all also does the x1 FIRST pass: a zone's reconstruction along x1 is the
+// same for the first pass and for the correct pass, the right state of its upper face is one lane away, and the first-pass
+// fluxes it needs are those of its own two faces.  k_sweep_x1_flat is not launched and its fluxes never reach HBM; what a tile
+// of 64 zones cannot do alone, the flux of the face it shares with the next tile, comes from k_x1_edge_flux (1/64 of the faces),
+// which keeps its result where the x1 flux array was: [variable][edge][k][j].  Same arithmetic, same bits.
+#ifndef CA_X1F
+#define CA_X1F 1
+#endif
+bool ca_x1_on_board() { return CA_X1F != 0; }
+__host__ __device__ static inline int x1_edges(const DevGrid &g) { return (g.ie + 2 - (g.is - 16))/64; }   // edge b = 1 .. : face is-16+64b <= ie+2
+AA_DEV long x1_edge_index(const DevGrid &g, int nbe, int v, int b, int j, int k) { return (((long)v*nbe + (b - 1))*g.N3 + k)*g.N2 + j; }
+template <int NS, bool GRAV, int ORD>
+__global__ void __launch_bounds__(64)
+k_x1_edge_flux(DevGrid g, Real dt)
+{
+  // lanes along j: the stores on whole lines (the loads are one sector per zone pair either way)
+  const int j = g.js - 1 + blockIdx.x*64 + threadIdx.x, k = g.ks - 1 + blockIdx.y, b = 1 + blockIdx.z;
+  if (j > g.je + 1) return;
+  const int nbe = x1_edges(g), i0 = g.is - 16 + 64*b;
+  const long m = (long)k*g.sK + (long)j*g.sJ + i0;
+  Real wa[6], wb[6], wc[6], wd[6], wl[6], wr[6], wx[6];
+  load_prim_sweep<NS, 0>(g, m - 2, wa); load_prim_sweep<NS, 0>(g, m - 1, wb);
+  load_prim_sweep<NS, 0>(g, m, wc);     load_prim_sweep<NS, 0>(g, m + 1, wd);
+  cell_recon<NS, 0, GRAV, ORD>(g, m - 1, dt, wa, wb, wc, wl, wx);      // zone i0-1: its left state belongs to face i0
+  cell_recon<NS, 0, GRAV, ORD>(g, m, dt, wb, wc, wd, wx, wr);          // zone i0: its right state
+  Real ul[6], ur[6], f[6];
+  prim_to_cons<NS>(wl, ul, g.Gamma_1, g.rGamma_1);
+  prim_to_cons<NS>(wr, ur, g.Gamma_1, g.rGamma_1);
+  flux_roe<NS>(ul, ur, wl, wr, 0.0, g.Gamma, g.Gamma_1, f);
+#pragma unroll
+  for (int n = 0; n < 5 + NS; n++) g.F[x1_edge_index(g, nbe, gv<0>(n), b, j, k)] = f[n];
+}
 template <int NS, bool GRAV, int ORD, bool X3F>
 __global__ void __launch_bounds__(64*CA_TJ, (X3F && NS && GRAV) ? 2 : 1)
-k_correct_all(DevGrid g, Real dt, int kchunk)
+k_correct_all(DevGrid g, Real dt, int kchunk, StepRatios sr)
 {
   __shared__ Real s_w[CA_TJ][6][64];
   __shared__ Real s_l[CA_TJ][64];
   // X3F: the x3 states of zone k+1 wait here while zone k is corrected (each thread its own slots, no barrier): 24
   // registers that the 6-variable gravity kernel does not have at 2 waves per SIMD (it spilled 16 to scratch)
-  __shared__ Real s_park[(X3F && CA_PARK) ? 12 : 1][CA_TJ][64];
+  // (CA_PARK3, with the x1 first pass on board: two sets of slots taken in turn, so that the states of zone k need no registers
+  //  between the iterations nor under the x1 Riemann problem: they are read where they are used)
+#ifndef CA_PARK3
+#define CA_PARK3 1
+#endif
+  constexpr bool PARK3 = X3F && (CA_X1F != 0) && (CA_PARK != 0) && (CA_PARK3 != 0);
+  __shared__ Real s_park[(X3F && CA_PARK) ? (PARK3 ? 24 : 12) : 1][CA_TJ][64];
   // ... and in the 6-variable gravity kernel, which spilled three registers, the x1 / x2 frame pressures of planes k+1 and k+2 wait
   // there too (each thread its own slots): no scratch, 18.53 -> 18.18 ms at 512^3 (same-box ABAB x 3; CA_PARK2=0: in registers)
 #ifndef CA_PARK2
@@ -778,7 +821,9 @@ k_correct_all(DevGrid g, Real dt, int kchunk)
   // upper x2 neighbour) are requested at the head of the iteration with everything else and wait here for their block: a load
   // issued inside a block would have to wait for the face-state stores of the block before it (loads and stores retire
   // through one counter).  s_h1: per wave, the 6 + 6 conserved variables of the two x1 neighbours, fetched by lanes 0..11.
-  __shared__ Real s_h1[CA_TJ][12];
+  // X1F: and behind them the first-pass x1 fluxes of the tile's two edge faces (lanes 12..23)
+  constexpr bool X1F = X3F && (CA_X1F != 0);
+  __shared__ Real s_h1[CA_TJ][X1F ? 24 : 12];
   __shared__ Real s_h2[2][6][64];
   constexpr int NV = 5 + NS;
   const int lane = threadIdx.x, row = threadIdx.y;
@@ -796,15 +841,18 @@ k_correct_all(DevGrid g, Real dt, int kchunk)
   int k1 = k0 + kchunk - 1; if (k1 > g.ke + 1) k1 = g.ke + 1;
   const int kstart = (blockIdx.z == 0) ? k0 : k0 - 1;          // one provider plane below a later chunk
   // idle threads beyond the Grid keep valid addresses (their neighbours may read what they load)
-  const int ic = (i <= g.ie + 2) ? (i < 0 ? 0 : i) : g.ie + 2, jc = (j <= g.je + 2) ? j : g.je + 2;
+  // (X1F: zone ie+2 gives its right state to the first-pass flux of face ie+2, so the lane of zone ie+3 holds that zone)
+  const int imax = g.ie + (X1F ? 3 : 2);
+  const int ic = (i <= imax) ? (i < 0 ? 0 : i) : imax, jc = (j <= g.je + 2) ? j : g.je + 2;
   const long mcol = (long)jc*g.sJ + ic;
   const int iW = i - lane, iE = i - lane + 63;                 // lane 0's and lane 63's zone, clamped like ic
-  const int icW = (iW <= g.ie + 2) ? (iW < 0 ? 0 : iW) : g.ie + 2, icE = (iE <= g.ie + 2) ? (iE < 0 ? 0 : iE) : g.ie + 2;
+  const int icW = (iW <= imax) ? (iW < 0 ? 0 : iW) : imax, icE = (iE <= imax) ? (iE < 0 ? 0 : iE) : imax;
+  const int nbe = x1_edges(g);
   const bool in = (i >= g.is - 1) && (i <= g.ie + 1) && (j <= g.je + 1);
   const bool do1 = in, do2 = in, do3 = in;
   Real q[3];
 #pragma unroll
-  for (int d = 0; d < 3; d++) q[d] = 0.5*(dt/g.dx[d]);
+  for (int d = 0; d < 3; d++) q[d] = sr.q[d];
 
   // X3F: the x3 FIRST pass rides on the march (k_sweep_march<2> is not launched, its fluxes never reach HBM): the
   // transverse differences a zone needs of the x3 first-pass flux are those of its own column, and the reconstruction
@@ -833,6 +881,7 @@ k_correct_all(DevGrid g, Real dt, int kchunk)
     long m = (long)k*g.sK + mcol;
     asm volatile("" : "+v"(m));                   // one index for all fields (see k_flux2_update)
     const bool full = (k >= k0);                  // block-uniform; the provider plane does x3 only
+    const int pk = (k & 1) ? 12 : 0;              // PARK3: the slots of zone k (those of zone k+1: 12 - pk)
     const bool zone = (k >= kstart);              // block-uniform; X3F: the two planes before do the first pass only
     Real f3n[6], wlN[6], wrN[6];
 #pragma unroll
@@ -842,6 +891,35 @@ k_correct_all(DevGrid g, Real dt, int kchunk)
 #pragma unroll
     for (int v = 0; v < 6; v++) { cf.dF[0][v] = 0.0; cf.dF[1][v] = 0.0; cf.dF[2][v] = 0.0; }
     Real mlo[3], mhi[3];
+    Real hv1 = 0.0;
+    // What the zone needs behind its x1 Riemann problem is requested in front of it where the registers allow: the wait would
+    // otherwise come behind it with nothing left to do.  CA_X1F_EARLY, bits: 1 potentials, 2 the x2 first-pass fluxes (the default:
+    // k_correct_all 22.6 -> 20.2 ms at 512^3, three registers in scratch), 4 the x2 neighbour rows.  (More than the default spills
+    // tens of registers and loses, also with the potentials parked in LDS: profiles/r04_x1f_ab.txt.)
+    // The scalar kernel without gravity (ifront) has no room at two waves per SIMD: CA_X1F_EARLY_NG, default 0.
+#ifndef CA_X1F_EARLY
+#define CA_X1F_EARLY 2
+#endif
+#ifndef CA_X1F_EARLY_NG
+#define CA_X1F_EARLY_NG 0
+#endif
+    constexpr int EMASK = (NS && !GRAV) ? CA_X1F_EARLY_NG : CA_X1F_EARLY;
+    constexpr bool EARLY_P = X1F && ((EMASK & 1) != 0), EARLY_F = X1F && ((EMASK & 2) != 0), EARLY_H = X1F && ((EMASK & 4) != 0);
+    Real hv2[6], eph[7];
+#pragma unroll
+    for (int v = 0; v < 6; v++) hv2[v] = 0.0;
+#pragma unroll
+    for (int v = 0; v < 7; v++) eph[v] = 0.0;
+    const bool edge_row = (row == 0) || (row == CA_TJ - 1);
+    if (X1F && zone) {      // requested here, used behind the x3 first pass (the provider plane too: its x3 states take x1 fluxes made here)
+      if (lane < 12) {
+        const int v = lane % 6, east = lane / 6;
+        if (v < NV) hv1 = Uf(g, v)[(long)k*g.sK + (long)jc*g.sJ + (east ? icE + 1 : icW - 1)];
+      } else if (lane < 24) {
+        const int v = (lane - 12) % 6, b = (int)blockIdx.x + (lane - 12)/6;      // the tile's lower edge face, then its upper one
+        if (v < NV && b >= 1 && b <= nbe) hv1 = g.F[x1_edge_index(g, nbe, v, b, jc, k)];
+      }
+    }
     if (X3F) {
 #pragma unroll
       for (int n = 0; n < 6; n++) { wc[n] = wn[n]; wn[n] = wn2[n]; }
@@ -853,10 +931,20 @@ k_correct_all(DevGrid g, Real dt, int kchunk)
         {   // (A) zone k+1 along x3
           Real wm[6], ws[6], wp[6];
           to_sweep<2>(wc, wc[4], wm); to_sweep<2>(wn, wn[4], ws); to_sweep<2>(wn2, wn2[4], wp);
-          cell_recon<NS, 2, GRAV, ORD>(g, m + g.sK, dt, wm, ws, wp, wlN, wrN);
+          cell_recon<NS, 2, GRAV, ORD>(g, m + g.sK, dt, sr.dtodx[2], wm, ws, wp, wlN, wrN);
         }
+#if CA_PARK
+        if (PARK3) {      // (the states of zone k+1 go to their slots before (B): the left one is not needed in it)
+#pragma unroll
+          for (int n = 0; n < NV; n++) { s_park[(PARK3 ? 12 - pk : 0) + n][row][lane] = wlN[n]; s_park[(PARK3 ? 12 - pk : 0) + 6 + n][row][lane] = wrN[n]; }
+        }
+#endif
         if (k >= kstart - 1) {   // (B) first-pass flux of face k+1 (face_work<MODE_FLUX1>), sweep frame -> global variables
           Real ul[6], ur[6], f[6];
+          if (PARK3) {
+#pragma unroll
+            for (int n = 0; n < 6; n++) wl3[n] = (n < NV) ? s_park[(PARK3 ? pk : 0) + n][row][lane] : 0.0;
+          }
           prim_to_cons<NS>(wl3, ul, g.Gamma_1, g.rGamma_1);
           prim_to_cons<NS>(wrN, ur, g.Gamma_1, g.rGamma_1);
           flux_roe<NS>(ul, ur, wl3, wrN, 0.0, g.Gamma, g.Gamma_1, f);
@@ -865,8 +953,10 @@ k_correct_all(DevGrid g, Real dt, int kchunk)
         }
       }
 #if CA_PARK
+      if (!PARK3 || !do3) {
 #pragma unroll
-      for (int n = 0; n < NV; n++) { s_park[n][row][lane] = wlN[n]; s_park[6 + n][row][lane] = wrN[n]; }
+        for (int n = 0; n < NV; n++) { s_park[(PARK3 ? 12 - pk : 0) + n][row][lane] = wlN[n]; s_park[(PARK3 ? 12 - pk : 0) + 6 + n][row][lane] = wrN[n]; }
+      }
 #endif
       __builtin_amdgcn_sched_barrier(0);
     } else {
@@ -875,15 +965,77 @@ k_correct_all(DevGrid g, Real dt, int kchunk)
       pc0 = pn0; pc1 = pn1;
       load_prim3<NS>(g, m + g.sK, wn, pn0, pn1);
     }
-    Real hv1 = 0.0, hv2[6];
-#pragma unroll
-    for (int v = 0; v < 6; v++) hv2[v] = 0.0;
-    const bool edge_row = (row == 0) || (row == CA_TJ - 1);
-    if (full) {
+    if (!X1F && full) {
       if (lane < 12) {
         const int v = lane % 6, east = lane / 6;
         if (v < NV) hv1 = Uf(g, v)[(long)k*g.sK + (long)jc*g.sJ + (east ? icE + 1 : icW - 1)];
       }
+    }
+    Real wl1[6], wr1[6];                          // X1F: the zone's kicked x1 states
+#pragma unroll
+    for (int v = 0; v < 6; v++) { wl1[v] = 1.0; wr1[v] = 1.0; }
+    // X1F: what the zone needs behind its x1 Riemann problem (x2 first-pass fluxes, potentials, the x2 neighbour rows) is requested
+    // in front of it -- the wait would otherwise come after it with nothing left to do (CA_X1F_EARLY=0: requested where it is used)
+    Real eb0[6], eb1[6];
+#pragma unroll
+    for (int v = 0; v < 6; v++) { eb0[v] = 0.0; eb1[v] = 0.0; }
+    if (X1F && zone) {
+      if (EARLY_P && GRAV) {
+        eph[0] = Pf(g, 0)[m];
+#pragma unroll
+        for (int e = 0; e < 3; e++) { eph[1 + 2*e] = Pf(g, 1 + e)[m + stride_rt(g, e)]; eph[2 + 2*e] = Pf(g, 1 + e)[m]; }
+      }
+      if (EARLY_F) {
+#pragma unroll
+        for (int v = 0; v < NV; v++) { eb0[v] = Ff(g, 1, v)[m]; eb1[v] = Ff(g, 1, v)[m + g.sJ]; }
+      }
+      if (EARLY_H && full && edge_row) {
+        const long m2 = (row == 0) ? m - g.sJ : m + g.sJ;
+#pragma unroll
+        for (int v = 0; v < NV; v++) hv2[v] = Uf(g, gv<1>(v))[m2];
+      }
+    }
+    if (X1F && zone) {   // ---- the x1 first pass, before anything else of the zone is formed: its fluxes correct the x2 and x3 states ----
+      if (lane < 24) s_h1[row][lane] = hv1;
+      __builtin_amdgcn_sched_barrier(0);
+      Real wm[6], wp[6], ws[6];
+      to_sweep<0>(wc, pc0, ws);
+#pragma unroll
+      for (int n = 0; n < 6; n++) { wm[n] = __shfl_up(ws[n], 1); wp[n] = __shfl_down(ws[n], 1); }
+      if (lane == 0 || lane == 63) {      // the neighbour zone of the tile before / after, exactly as the sweeps convert it
+        Real u[6];
+#pragma unroll
+        for (int v = 0; v < 6; v++) u[v] = (v < NV) ? s_h1[row][(lane ? 6 : 0) + v] : 0.0;
+        Real wh[6];
+        cons_to_prim<NS>(u, wh, g.Gamma_1);
+#pragma unroll
+        for (int v = 0; v < 6; v++) { if (lane == 0) wm[v] = wh[v]; else wp[v] = wh[v]; }
+      }
+      if (GRAV) {      // (the zone's kicks along x1; formed again with the others below)
+        const Real phic = EARLY_P ? eph[0] : Pf(g, 0)[m], phir = EARLY_P ? eph[1] : Pf(g, 1)[m + stride_rt(g, 0)];
+        const Real phil = EARLY_P ? eph[2] : Pf(g, 1)[m], dtodx = sr.dtodx[0];
+        cf.kl[0] = dtodx*(phir - phic); cf.kr[0] = dtodx*(phic - phil);
+      }
+      cell_recon<NS, 0, GRAV, ORD>(g, m, dt, sr.dtodx[0], cf, wm, ws, wp, wl1, wr1);
+      {   // first-pass flux of the zone's upper face (face_work<MODE_FLUX1>): its right state is the lane above's
+        Real wrE[6], ul[6], ur[6], f[6];
+#pragma unroll
+        for (int n = 0; n < 6; n++) wrE[n] = __shfl_down(wr1[n], 1);
+        prim_to_cons<NS>(wl1, ul, g.Gamma_1, g.rGamma_1);
+        prim_to_cons<NS>(wrE, ur, g.Gamma_1, g.rGamma_1);
+        flux_roe<NS>(ul, ur, wl1, wrE, 0.0, g.Gamma, g.Gamma_1, f);
+#pragma unroll
+        for (int n = 0; n < NV; n++) {
+          const Real fu = (lane == 63) ? s_h1[row][18 + gv<0>(n)] : f[n];      // the tile's edge faces: k_x1_edge_flux
+          Real flo = __shfl_up(fu, 1);
+          if (lane == 0) flo = s_h1[row][12 + gv<0>(n)];
+          cf.dF[0][gv<0>(n)] = fu - flo;
+          if (gv<0>(n) == 0) { mlo[0] = flo; mhi[0] = fu; }
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (full && !EARLY_H) {
       if (edge_row) {
         const long m2 = (row == 0) ? m - g.sJ : m + g.sJ;
 #pragma unroll
@@ -893,20 +1045,22 @@ k_correct_all(DevGrid g, Real dt, int kchunk)
     if (zone) {
 #pragma unroll
     for (int v = 0; v < NV; v++) {
-      const Real a0 = Ff(g, 0, v)[m], a1 = Ff(g, 0, v)[m + 1], b0 = Ff(g, 1, v)[m], b1 = Ff(g, 1, v)[m + g.sJ];
+      const Real a0 = X1F ? 0.0 : Ff(g, 0, v)[m], a1 = X1F ? 0.0 : Ff(g, 0, v)[m + 1];
+      const Real b0 = EARLY_F ? eb0[v] : Ff(g, 1, v)[m], b1 = EARLY_F ? eb1[v] : Ff(g, 1, v)[m + g.sJ];
       const Real c0 = f3[v], c1 = X3F ? f3n[v] : Ff(g, 2, v)[m + g.sK];
-      cf.dF[0][v] = a1 - a0; cf.dF[1][v] = b1 - b0; cf.dF[2][v] = c1 - c0;
-      if (v == 0) { mlo[0] = a0; mhi[0] = a1; mlo[1] = b0; mhi[1] = b1; mlo[2] = c0; mhi[2] = c1; }
+      if (!X1F) cf.dF[0][v] = a1 - a0;
+      cf.dF[1][v] = b1 - b0; cf.dF[2][v] = c1 - c0;
+      if (v == 0) { if (!X1F) { mlo[0] = a0; mhi[0] = a1; } mlo[1] = b0; mhi[1] = b1; mlo[2] = c0; mhi[2] = c1; }
       if (!X3F) f3[v] = c1;
     }
     if (GRAV) {
-      const Real dc = wc[0], phic = Pf(g, 0)[m];
+      const Real dc = wc[0], phic = EARLY_P ? eph[0] : Pf(g, 0)[m];
 #pragma unroll
       for (int e = 0; e < 3; e++) {
-        const Real phir = Pf(g, 1 + e)[m + stride_rt(g, e)], phil = Pf(g, 1 + e)[m];
+        const Real phir = EARLY_P ? eph[1 + 2*e] : Pf(g, 1 + e)[m + stride_rt(g, e)], phil = EARLY_P ? eph[2 + 2*e] : Pf(g, 1 + e)[m];
         cf.gm[e] = q[e]*(phir - phil)*dc;
         cf.ge[e] = q[e]*(mlo[e]*(phic - phil) + mhi[e]*(phir - phic));
-        const Real dtodx = dt/g.dx[e];
+        const Real dtodx = sr.dtodx[e];
         cf.kl[e] = dtodx*(phir - phic); cf.kr[e] = dtodx*(phic - phil);
       }
     }
@@ -917,20 +1071,35 @@ k_correct_all(DevGrid g, Real dt, int kchunk)
     //  the head of the NEXT iteration behind its loads, so that no load wait sits behind fresh stores: 18.6-18.9 / 19.5-19.7
     //  against 18.3-18.5 ms.  The write latency is not what this kernel waits for; it moves its 92 GB at 5 TB/s.)
     if (full) {
-      if (lane < 12) s_h1[row][lane] = hv1;
+      if (!X1F && lane < 12) s_h1[row][lane] = hv1;
       if (edge_row) {
 #pragma unroll
         for (int v = 0; v < NV; v++) s_h2[row ? 1 : 0][v][lane] = hv2[v];
       }
       __builtin_amdgcn_sched_barrier(0);
     }
+    if (X1F && full) {   // ---- x1: the states reconstructed above take their corrections ----
+      Real ll = 0.0, lr = 0.0;
+      if (do1) cell_finish<NS, 0, GRAV>(g, m, q, cf, wl1, wr1, true, ll, lr);
+      const Real lprev = __shfl_up(ll, 1);
+      if (do1) {
+        if (lane > 0) { if (i > g.is - 1) Ef(g, 0)[m] = 0.5*fabs(lr - lprev); }
+        else Ef(g, 0)[m] = lr;                        // tile edge: k_eta_edges finishes this face
+        if (lane == 63) Ef(g, 3)[m] = ll;
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
     if (do3) {   // ---- x3 first: what only this block needs (the plane below / the states zone k kept) is dead under x1 / x2 ----
       Real ll, lr;
+      if (PARK3) {
+#pragma unroll
+        for (int n = 0; n < 6; n++) { wl3[n] = (n < NV) ? s_park[(PARK3 ? pk : 0) + n][row][lane] : 0.0; wr3[n] = (n < NV) ? s_park[(PARK3 ? pk : 0) + 6 + n][row][lane] : 0.0; }
+      }
       if (X3F) cell_finish<NS, 2, GRAV>(g, m, q, cf, wl3, wr3, full, ll, lr);
       else {
         Real wm[6], ws[6], wp[6];
         to_sweep<2>(wm3, wm3[4], wm); to_sweep<2>(wc, wc[4], ws); to_sweep<2>(wn, wn[4], wp);
-        cell_states<NS, 2, GRAV, ORD>(g, m, dt, q, cf, wm, ws, wp, full, ll, lr);
+        cell_states<NS, 2, GRAV, ORD>(g, m, dt, sr.dtodx[2], q, cf, wm, ws, wp, full, ll, lr);
       }
       if (full && k > g.ks - 1) Ef(g, 2)[m] = 0.5*fabs(lr - lam3);      // lam3 = lambda_l the zone below gave to this zone's lower face
       lam3 = ll;
@@ -943,7 +1112,7 @@ k_correct_all(DevGrid g, Real dt, int kchunk)
       }
     }
     if (full) {
-      {   // ---- x1: neighbours by shuffle ----
+      if (!X1F) {   // ---- x1: neighbours by shuffle ----
         Real wm[6], wp[6], ws[6], ll = 0.0, lr = 0.0;
         to_sweep<0>(wc, pc0, ws);
 #pragma unroll
@@ -957,7 +1126,7 @@ k_correct_all(DevGrid g, Real dt, int kchunk)
 #pragma unroll
           for (int v = 0; v < 6; v++) { if (lane == 0) wm[v] = wh[v]; else wp[v] = wh[v]; }
         }
-        if (do1) cell_states<NS, 0, GRAV, ORD>(g, m, dt, q, cf, wm, ws, wp, true, ll, lr);
+        if (do1) cell_states<NS, 0, GRAV, ORD>(g, m, dt, sr.dtodx[0], q, cf, wm, ws, wp, true, ll, lr);
         const Real lprev = __shfl_up(ll, 1);
         if (do1) {
           if (lane > 0) { if (i > g.is - 1) Ef(g, 0)[m] = 0.5*fabs(lr - lprev); }
@@ -992,7 +1161,7 @@ k_correct_all(DevGrid g, Real dt, int kchunk)
           for (int n = 0; n < NV; n++) wp[n] = s_w[row + 1][n][lane];
           if (!NS) wp[5] = 0.0;
         }
-        if (do2) cell_states<NS, 1, GRAV, ORD>(g, m, dt, q, cf, wm, ws, wp, true, ll, lr);
+        if (do2) cell_states<NS, 1, GRAV, ORD>(g, m, dt, sr.dtodx[1], q, cf, wm, ws, wp, true, ll, lr);
         s_l[row][lane] = ll;
         __syncthreads();
         if (do2) {
@@ -1009,7 +1178,7 @@ k_correct_all(DevGrid g, Real dt, int kchunk)
 #pragma unroll
       for (int n = 0; n < 6; n++) {
 #if CA_PARK
-        wl3[n] = (n < NV) ? s_park[n][row][lane] : 0.0; wr3[n] = (n < NV) ? s_park[6 + n][row][lane] : 0.0;
+        if (!PARK3) { wl3[n] = (n < NV) ? s_park[n][row][lane] : 0.0; wr3[n] = (n < NV) ? s_park[6 + n][row][lane] : 0.0; }
 #else
         wl3[n] = wlN[n]; wr3[n] = wrN[n];
 #endif
@@ -2050,12 +2219,19 @@ static void correct_all_impl(const HostGrid &g, Real dt, bool x3f, hipStream_t s
   // with 8 planes, 1.30 against 1.65 ms at 192^3; 256^3 with 16, 2.80 against 3.09; 320^3 with 32; from 384^3 on with 64)
   if (kc_env <= 0) while (kc > 8 && (long)nblk(ni + 15, 64)*nblk(nj, CA_TJ)*((nk + kc - 1)/kc) < 4096) kc >>= 1;
   dim3 grid(nblk(ni + 15, 64), nblk(nj, CA_TJ), (nk + kc - 1)/kc), blk(64, CA_TJ);
+  if (x3f && CA_X1F && x1_edges(g) > 0) {      // the first-pass x1 fluxes of the faces between the tiles
+    dim3 ge(nblk(nj, 64), nk, x1_edges(g));
+    if (g.slope) hipLaunchKernelGGL((k_x1_edge_flux<NS, GRAV, 3>), ge, dim3(64), 0, st, g, dt);
+    else         hipLaunchKernelGGL((k_x1_edge_flux<NS, GRAV, 2>), ge, dim3(64), 0, st, g, dt);
+  }
+  StepRatios sr;
+  for (int d = 0; d < 3; d++) { sr.dtodx[d] = dt/g.dx[d]; sr.q[d] = 0.5*(dt/g.dx[d]); }
   if (x3f) {
-    if (g.slope) hipLaunchKernelGGL((k_correct_all<NS, GRAV, 3, true>), grid, blk, 0, st, g, dt, kc);
-    else         hipLaunchKernelGGL((k_correct_all<NS, GRAV, 2, true>), grid, blk, 0, st, g, dt, kc);
+    if (g.slope) hipLaunchKernelGGL((k_correct_all<NS, GRAV, 3, true>), grid, blk, 0, st, g, dt, kc, sr);
+    else         hipLaunchKernelGGL((k_correct_all<NS, GRAV, 2, true>), grid, blk, 0, st, g, dt, kc, sr);
   } else {
-    if (g.slope) hipLaunchKernelGGL((k_correct_all<NS, GRAV, 3, false>), grid, blk, 0, st, g, dt, kc);
-    else         hipLaunchKernelGGL((k_correct_all<NS, GRAV, 2, false>), grid, blk, 0, st, g, dt, kc);
+    if (g.slope) hipLaunchKernelGGL((k_correct_all<NS, GRAV, 3, false>), grid, blk, 0, st, g, dt, kc, sr);
+    else         hipLaunchKernelGGL((k_correct_all<NS, GRAV, 2, false>), grid, blk, 0, st, g, dt, kc, sr);
   }
   const long nb1 = (g.ie + 1 - (g.is - 16))/64, nb2 = (g.je + 1 - (g.js - 1))/CA_TJ;
   if (nb1 > 0) hipLaunchKernelGGL((k_eta_edges<0>), dim3(nblk(nb1*nj*nk, 256)), dim3(256), 0, st, g);

@@ -98,6 +98,7 @@ KERNEL_BYTES = {
     "bvals_mhd": 0, "new_dt": 8 * 5, "pinned_cells": 0, "ppm_slopes": 3 * 8 * (6 + 6), "no_h_correction": 8 * 3,
 }
 CORRECT_ALL_X3_BYTES = 8 * (6 + 12 + 4 + 36 + 3 + 1)   # k_correct_all with the x3 first pass inside (no x3 first-pass fluxes in HBM)
+CORRECT_ALL_X1X3_BYTES = 8 * (6 + 6 + 4 + 36 + 3 + 1)   # ... and the x1 first pass (round 4): only the x2 first-pass fluxes are read
 HYDRO_KERNELS = ("sweep_", "sweep_correct_x1", "correct_", "flux2_", "update", "vl_", "ppm_slopes", "no_h_correction")
 SUBCYCLE_KERNELS = ("ray_sweep", "ray_sweep_rates", "ion_rates", "ion_update", "ion_pass", "ion_pass_first", "ion_pass_last", "ion_pass_begin",
                     "ion_pick")
@@ -292,7 +293,7 @@ def bench_smr(a, aa, torch, rank, world, local):
                 ncell = cfg.Nx[0] * cfg.Nx[1] * cfg.Nx[2]
                 kb = KERNEL_BYTES.get(k, 0)
                 if k == "correct_all" and f"L{l}.sweep_x3" not in prof:
-                    kb = CORRECT_ALL_X3_BYTES
+                    kb = CORRECT_ALL_X3_BYTES if f"L{l}.sweep_x1" in prof else CORRECT_ALL_X1X3_BYTES
                 bpl = kb * ncell
                 ach = bpl / (ms / n * 1e-3) / 1e9
                 out["roofline"] = {"bound": "hbm", "kernel": f"L{l}.{k}", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -498,7 +499,7 @@ def pmc_passes(argv):
         k, targs = m.group(1), [x.strip() for x in m.group(2).split(",")]
         if k == "k_flux2_update":
             return "flux2_update"
-        if k in ("k_correct_all", "k_eta_edges"):
+        if k in ("k_correct_all", "k_eta_edges", "k_x1_edge_flux"):
             return "correct_all"
         if k in ("k_sweep_x1_flat", "k_sweep_x1"):         # <NS, GRAV, MODE, ORD>
             return {"0": "sweep_x1", "3": "sweep_correct_x1", "1": "correct_x1"}.get(targs[2])
@@ -626,7 +627,8 @@ def analyse(c, w):
                 scale = (nvar / 6.0) if kernel_class(dom) == "hydro" else 1.0
                 kb = KERNEL_BYTES[dom]
                 if dom == "correct_all" and "sweep_x3" not in prof:
-                    kb = CORRECT_ALL_X3_BYTES       # the x3 first pass rides along: its fluxes are neither written nor read
+                    # the x3 (and, without a sweep_x1 launch, the x1) first pass rides along: those fluxes are neither written nor read
+                    kb = CORRECT_ALL_X3_BYTES if "sweep_x1" in prof else CORRECT_ALL_X1X3_BYTES
                 own = kb * zones_gpu * scale / (ms / n * 1e-3) / 1e9
                 rf["dominant_kernel"] = dom
                 rf["dominant_kernel_avg_launch_ms"] = ms / n
