@@ -41,6 +41,11 @@ AA_DEV Real *LRf(const DevGrid &g, int d, int side, int v) { return g.LR + (long
 AA_DEV Real *Ff(const DevGrid &g, int d, int v) { return g.F + (long)(d*6 + v)*g.nc; }
 AA_DEV Real *Ef(const DevGrid &g, int d) { return g.eta + (long)d*g.nc; }
 AA_DEV Real *Pf(const DevGrid &g, int which) { return g.phi + (long)which*g.nc; }   // 0 centre, 1+d face
+// dt/dx_d and half of it, formed by the launcher (the same IEEE quotient the kernels form): as kernel arguments they live in scalar
+// registers; formed in the kernel they took twelve vector registers through the whole march of k_correct_all, six in k_flux2_update
+struct StepRatios { Real dtodx[3], q[3]; };
+static inline StepRatios step_ratios(const DevGrid &g, Real dt)
+{ StepRatios sr; for (int d = 0; d < 3; d++) { sr.dtodx[d] = dt/g.dx[d]; sr.q[d] = 0.5*(dt/g.dx[d]); } return sr; }
 
 #if AA_COOLING
 // microphysics/cool.c:48-86 KoyInut(): the cooling rate [erg cm^-3 s^-1] of the diffuse ISM (Koyama & Inutsuka 2002, eq. 4) from
@@ -760,9 +765,6 @@ AA_DEV void cell_states(const DevGrid &g, long m, Real dt, Real dtodx, const Rea
 #ifndef CA_PARK
 #define CA_PARK 1
 #endif
-// dt/dx_d and half of it, formed by the launcher (the same IEEE quotient the kernels form): as kernel arguments they live in scalar
-// registers, formed in the kernel they took twelve vector registers through the whole march
-struct StepRatios { Real dtodx[3], q[3]; };
 // CA_X1F: with the x3 first pass on board (X3F), k_correct_all also does the x1 FIRST pass: a zone's reconstruction along x1 is the
 // same for the first pass and for the correct pass, the right state of its upper face is one lane away, and the first-pass
 // fluxes it needs are those of its own two faces.  k_sweep_x1_flat is not launched and its fluxes never reach HBM; what a tile
@@ -911,15 +913,20 @@ k_correct_all(DevGrid g, Real dt, int kchunk, StepRatios sr)
 #pragma unroll
     for (int v = 0; v < 7; v++) eph[v] = 0.0;
     const bool edge_row = (row == 0) || (row == CA_TJ - 1);
-    if (X1F && zone) {      // requested here, used behind the x3 first pass (the provider plane too: its x3 states take x1 fluxes made here)
+    // the x1 neighbour zones and edge fluxes of plane kk (lanes 0..23 of every wave)
+    auto x1_halo = [&](int kk) -> Real {
+      Real h = 0.0;
       if (lane < 12) {
         const int v = lane % 6, east = lane / 6;
-        if (v < NV) hv1 = Uf(g, v)[(long)k*g.sK + (long)jc*g.sJ + (east ? icE + 1 : icW - 1)];
+        if (v < NV) h = Uf(g, v)[(long)kk*g.sK + (long)jc*g.sJ + (east ? icE + 1 : icW - 1)];
       } else if (lane < 24) {
         const int v = (lane - 12) % 6, b = (int)blockIdx.x + (lane - 12)/6;      // the tile's lower edge face, then its upper one
-        if (v < NV && b >= 1 && b <= nbe) hv1 = g.F[x1_edge_index(g, nbe, v, b, jc, k)];
+        if (v < NV && b >= 1 && b <= nbe) h = g.F[x1_edge_index(g, nbe, v, b, jc, kk)];
       }
-    }
+      return h;
+    };
+    // requested here, used behind the x3 first pass (the provider plane too: its x3 states take x1 fluxes made here)
+    if (X1F && zone) hv1 = x1_halo(k);
     if (X3F) {
 #pragma unroll
       for (int n = 0; n < 6; n++) { wc[n] = wn[n]; wn[n] = wn2[n]; }
@@ -1414,7 +1421,7 @@ AA_DEV bool on_plane(const KeepPlanes &kp, int d, int x)
 // has overwritten them (k_pinned_cfl).
 template <int NS, bool GRAV, bool KEEP, bool CFL>
 __global__ void __launch_bounds__(64*FU_TJ)
-k_flux2_update(DevGrid g, const Real *dhalf, Real dt, int kchunk, KeepPlanes kp, DevScalars *sc, const unsigned char *pinmask)
+k_flux2_update(DevGrid g, const Real *dhalf, Real dt, int kchunk, KeepPlanes kp, DevScalars *sc, const unsigned char *pinmask, StepRatios sr)
 {
   // (two copies of the exchange arrays, used in turn: ONE barrier per plane instead of a second one that only kept the
   //  next plane's writers off this plane's readers -- 8 wavefronts, a whole CU, wait at every barrier of this block)
@@ -1453,7 +1460,7 @@ k_flux2_update(DevGrid g, const Real *dhalf, Real dt, int kchunk, KeepPlanes kp,
   const long m1off = edge ? ((long)(j0 + lane)*g.sJ + (i0 + 64)) - mcol : 0L;
   Real dtodx[3];
 #pragma unroll
-  for (int d = 0; d < 3; d++) dtodx[d] = dt/g.dx[d];
+  for (int d = 0; d < 3; d++) dtodx[d] = sr.dtodx[d];
   // per direction: flux differences (hi - lo) of all components + the two mass fluxes (gravity)
   Real f3lo[6], d1[6], d2[6], d3[6], m1lo = 0.0, m1hi = 0.0, m2lo = 0.0, m2hi = 0.0, m3hi = 0.0;
   // CFL: the thread's running maxima live in LDS (its own three slots), not in registers carried round the loop: the
@@ -1531,6 +1538,27 @@ k_flux2_update(DevGrid g, const Real *dhalf, Real dt, int kchunk, KeepPlanes kp,
       }
     }
     __builtin_amdgcn_sched_barrier(0);
+    // FU_EARLY: the zone's own operands of the update are requested in front of the x3 Riemann problem instead of behind it
+    // (bits: 1 the conserved variables, 2 potentials + d^{n+1/2}; same-box, 512^3: 0 13.45, 1 13.26, 2 13.15 (the default), 3 14.57 ms
+    //  -- both together spill four registers)
+#ifndef FU_EARLY
+#define FU_EARLY 2
+#endif
+    Real eu[6], ep[7], edh = 0.0;
+#pragma unroll
+    for (int v = 0; v < 6; v++) eu[v] = 0.0;
+#pragma unroll
+    for (int v = 0; v < 7; v++) ep[v] = 0.0;
+    if (cell) {
+      if (FU_EARLY & 1) {
+#pragma unroll
+        for (int v = 0; v < NV; v++) eu[v] = Uf(g, v)[m];
+      }
+      if ((FU_EARLY & 2) && GRAV) {
+        ep[0] = Pf(g, 0)[m]; edh = dhalf[m];
+        ep[1] = Pf(g, 1)[m + 1]; ep[2] = Pf(g, 1)[m]; ep[3] = Pf(g, 2)[m + g.sJ]; ep[4] = Pf(g, 2)[m]; ep[5] = Pf(g, 3)[m + g.sK]; ep[6] = Pf(g, 3)[m];
+      }
+    }
     Real f3[6];
 #pragma unroll
     for (int n = 0; n < 6; n++) f3[n] = 0.0;
@@ -1548,20 +1576,21 @@ k_flux2_update(DevGrid g, const Real *dhalf, Real dt, int kchunk, KeepPlanes kp,
       for (int n = 0; n < NV; n++) { if (FPARK) s_f3[FPARK ? n : 0][FPARK ? row : 0][lane] = f3[n]; else f3lo[n] = f3[n]; }
       Real u[6];
 #pragma unroll
-      for (int v = 0; v < NV; v++) u[v] = Uf(g, v)[m];
+      for (int v = 0; v < NV; v++) u[v] = (FU_EARLY & 1) ? eu[v] : Uf(g, v)[m];
       // (the mask byte with the zone's other operands, not behind the stores of U: a load that is consumed at once waits
       //  for everything issued before it, i.e. the wave sat out the six stores' round trip in every plane)
       unsigned char pinned = 0;
       if (CFL && pinmask) pinned = pinmask[m];
       if (GRAV) {   // :2741-2782, with the mass fluxes (sweep component 0) of the faces just solved
-        const Real phic = Pf(g, 0)[m], dh = dhalf[m];
-        { const Real phir = Pf(g, 1)[m + 1], phil = Pf(g, 1)[m];
+        constexpr bool EP = (FU_EARLY & 2) != 0;
+        const Real phic = EP ? ep[0] : Pf(g, 0)[m], dh = EP ? edh : dhalf[m];
+        { const Real phir = EP ? ep[1] : Pf(g, 1)[m + 1], phil = EP ? ep[2] : Pf(g, 1)[m];
           u[1] -= dtodx[0]*(phir - phil)*dh;
           u[4] -= dtodx[0]*(m1lo*(phic - phil) + m1hi*(phir - phic)); }
-        { const Real phir = Pf(g, 2)[m + g.sJ], phil = Pf(g, 2)[m];
+        { const Real phir = EP ? ep[3] : Pf(g, 2)[m + g.sJ], phil = EP ? ep[4] : Pf(g, 2)[m];
           u[2] -= dtodx[1]*(phir - phil)*dh;
           u[4] -= dtodx[1]*(m2lo*(phic - phil) + m2hi*(phir - phic)); }
-        { const Real phir = Pf(g, 3)[m + g.sK], phil = Pf(g, 3)[m];
+        { const Real phir = EP ? ep[5] : Pf(g, 3)[m + g.sK], phil = EP ? ep[6] : Pf(g, 3)[m];
           u[3] -= dtodx[2]*(phir - phil)*dh;
           u[4] -= dtodx[2]*(m3lo*(phic - phil) + m3hi*(phir - phic)); }
       }
@@ -2224,8 +2253,7 @@ static void correct_all_impl(const HostGrid &g, Real dt, bool x3f, hipStream_t s
     if (g.slope) hipLaunchKernelGGL((k_x1_edge_flux<NS, GRAV, 3>), ge, dim3(64), 0, st, g, dt);
     else         hipLaunchKernelGGL((k_x1_edge_flux<NS, GRAV, 2>), ge, dim3(64), 0, st, g, dt);
   }
-  StepRatios sr;
-  for (int d = 0; d < 3; d++) { sr.dtodx[d] = dt/g.dx[d]; sr.q[d] = 0.5*(dt/g.dx[d]); }
+  const StepRatios sr = step_ratios(g, dt);
   if (x3f) {
     if (g.slope) hipLaunchKernelGGL((k_correct_all<NS, GRAV, 3, true>), grid, blk, 0, st, g, dt, kc, sr);
     else         hipLaunchKernelGGL((k_correct_all<NS, GRAV, 2, true>), grid, blk, 0, st, g, dt, kc, sr);
@@ -2320,11 +2348,11 @@ static void launch_fu(const DevGrid &g, Real dt, int kc, dim3 grid, dim3 blk, co
 {
   KeepPlanes none = {0, {{0}}};
   if (sc) {
-    if (keep && keep->n) hipLaunchKernelGGL((k_flux2_update<NS, GRAV, true, true>), grid, blk, 0, st, g, g.dhalf, dt, kc, *keep, sc, pinmask);
-    else                 hipLaunchKernelGGL((k_flux2_update<NS, GRAV, false, true>), grid, blk, 0, st, g, g.dhalf, dt, kc, none, sc, pinmask);
+    if (keep && keep->n) hipLaunchKernelGGL((k_flux2_update<NS, GRAV, true, true>), grid, blk, 0, st, g, g.dhalf, dt, kc, *keep, sc, pinmask, step_ratios(g, dt));
+    else                 hipLaunchKernelGGL((k_flux2_update<NS, GRAV, false, true>), grid, blk, 0, st, g, g.dhalf, dt, kc, none, sc, pinmask, step_ratios(g, dt));
   } else {
-    if (keep && keep->n) hipLaunchKernelGGL((k_flux2_update<NS, GRAV, true, false>), grid, blk, 0, st, g, g.dhalf, dt, kc, *keep, sc, pinmask);
-    else                 hipLaunchKernelGGL((k_flux2_update<NS, GRAV, false, false>), grid, blk, 0, st, g, g.dhalf, dt, kc, none, sc, pinmask);
+    if (keep && keep->n) hipLaunchKernelGGL((k_flux2_update<NS, GRAV, true, false>), grid, blk, 0, st, g, g.dhalf, dt, kc, *keep, sc, pinmask, step_ratios(g, dt));
+    else                 hipLaunchKernelGGL((k_flux2_update<NS, GRAV, false, false>), grid, blk, 0, st, g, g.dhalf, dt, kc, none, sc, pinmask, step_ratios(g, dt));
   }
 }
 void launch_pinned_cfl(const DevGrid &g, long long n, const long long *idx, DevScalars *sc, hipStream_t st)
