@@ -196,8 +196,8 @@ def test_the_two_builds_agree_at_256_cubed():
 
 def test_driver_path_agrees_with_aa_step_at_512():
     """bench.py's two N = 1 host paths at the headline size: ONE C call per step (aa_step) and the loop as the ranks of an N > 1
-    job run it (driver.Driver.step on a one-rank RCCL communicator).  Where the step takes ONE radiation sub-cycle they must agree
-    within 2 % (the kernels are the same; the rest is a dozen Python -> C crossings and two tiny collectives per step); the
+    job run it (driver.Driver.step on a one-rank RCCL communicator).  Where the step takes ONE radiation sub-cycle their host sides must
+    agree within 2 % of the step (the kernels are the same; the rest is a dozen Python -> C crossings and two tiny collectives per step); the
     burst-window difference (dozens of sub-cycles per step, one callback each) is reported."""
     import json
     import subprocess
@@ -213,5 +213,11 @@ def test_driver_path_agrees_with_aa_step_at_512():
           f"{p['burst']['nsub']:.1f} sub-cycles per step)")
     assert p["nsub"] == d["config"]["radiation_subcycles_per_step"]
     if p["nsub"] == 1.0:
-        assert abs(p["ms_per_step"] / d["ms_per_step"] - 1.0) < 0.02, (p["ms_per_step"], d["ms_per_step"])
+        # the HOST side of the two paths (step time minus the step's own kernel times, both from the same window) within 2 % of the step;
+        # the raw times within 3 %: the two windows run minutes apart in one process and the same kernels drift by up to 1.5 % between
+        # them at the socket's power limit (round 4, driver command: kernels 41.03 against 41.60 ms, host side +0.2 ms)
+        host_a = d["ms_per_step"] - sum(d["kernel_ms_per_step"].values())
+        host_p = p["ms_per_step"] - sum(p["kernel_ms_per_step"].values())
+        assert abs(host_p - host_a) < 0.02 * d["ms_per_step"], (host_a, host_p)
+        assert abs(p["ms_per_step"] / d["ms_per_step"] - 1.0) < 0.03, (p["ms_per_step"], d["ms_per_step"])
     assert p["burst"]["host_syncs_per_subcycle"] <= 1.0 + 1e-9
