@@ -109,10 +109,11 @@ int aa_create(const aa_params *p, aa_grid **out)
   d.sJ = pitch_align ? ((d.N1 + 15)/16)*16 : d.N1; d.sK = (long)d.sJ*d.N2; d.nc = d.sK*d.N3;
   if (p->level < 0 || p->level > 7) { delete g; return fail(-1, "[aa_create]: level %d out of range", p->level); }
   g->level = p->level;
-  // the one-kernel correct pass wins on big Grids (-4 % of a 512^3 step), the tile kernels on small ones
-  // (80^3: +7 %): same results bit for bit, so the choice follows the size unless AA_CORRECT_ALL forces it
+  // the one-kernel correct pass (with both first passes on board since round 4) wins from about 70^3 zones on, the tile kernels
+  // below (profiles/microbench/ca_threshold_r04.sh: 64^3 -11 %, 80^3 +20 %, 96^3 +21 %, 112^3 +21 %; until round 4 the
+  // limit was 2^21 zones): same results bit for bit, so the choice follows the size unless AA_CORRECT_ALL forces it
   { const char *e = getenv("AA_CORRECT_ALL");
-    g->correct_all = e ? atoi(e) != 0 : ((long long)p->Nx[0]*p->Nx[1]*p->Nx[2] >= (1LL << 21)); }
+    g->correct_all = e ? atoi(e) != 0 : ((long long)p->Nx[0]*p->Nx[1]*p->Nx[2] >= 400000LL); }
   // (k_correct_all also does the x3 first pass: see x3_fused below)
   { const char *e = getenv("AA_CFL_FUSED"); g->cfl_step = e ? atoi(e) != 0 : true; g->cfl_force = e && atoi(e) == 2; }     // aa_step: new_dt's maxima from the update kernel
   { const char *e = getenv("AA_X3_FUSED"); g->x3_fused_mode = e ? (atoi(e) != 0) : -1; }    // (the potential arrives after aa_create)

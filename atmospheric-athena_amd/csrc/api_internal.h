@@ -46,7 +46,7 @@ struct aa_grid {
   int x3_fused_mode = -1;              // k_correct_all also does the x3 first pass: -1 by configuration (api.hip), AA_X3_FUSED=0/1 forces
   bool inner_swept = false;            // aa_integrate_begin has done the first-pass x1 / x2 sweeps of the planes ks .. ke
   double inner_dt = 0.0;               //   ... with this dt
-  bool correct_all = false;            // the three correct passes in one kernel (k_correct_all): Grids of 2^21 zones or more, or AA_CORRECT_ALL
+  bool correct_all = false;            // the three correct passes in one kernel (k_correct_all): Grids of 4e5 zones or more (2^21 until round 4), or AA_CORRECT_ALL
   bool fused_rates = false;            // rates evaluated inside the ray sweep (k_ray_sweep<true>): 2^17 rays or more, or AA_FUSED_RATES
   bool ion_fused = false;              // one-kernel radiation sub-cycle with the scan sweep (ion_pass.hip): rays of 64 zones or more, or AA_ION_FUSED
   bool ion_begin_fused = true;         // the entry of the ion step rides on its first pass (AA_ION_BEGIN_FUSED=0: k_ion_begin16 on its own)

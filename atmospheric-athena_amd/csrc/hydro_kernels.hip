@@ -1472,7 +1472,11 @@ k_flux2_update(DevGrid g, const Real *dhalf, Real dt, int kchunk, KeepPlanes kp,
   const bool keep1 = KEEP && need1 && on_plane(kp, 0, edge ? i0 + 64 : i), keep2 = KEEP && need2 && on_plane(kp, 1, j);
   if (cell) {                                                                   // face k0
     face_flux2<NS, 2>(g, (long)k0*g.sK + mcol, f3lo);
-    if (KEEP && on_plane(kp, 2, k0)) store_sweep<2, NS>(Ff(g, 2, 0), g.nc, (long)k0*g.sK + mcol, f3lo);
+    // (only the first chunk keeps its face k0: every later chunk's is face k1+1 of the chunk below, kept there by the loop's instance of
+    //  the solver -- in the default build this instance may contract its multiply-adds differently, and two writers of one word with
+    //  last-bit-different values made the flux a level's parent reads depend on which block finished last: round 4, found as a
+    //  run-to-run difference of 1e-16 on the levels of a Mesh in the default build)
+    if (KEEP && blockIdx.z == 0 && on_plane(kp, 2, k0)) store_sweep<2, NS>(Ff(g, 2, 0), g.nc, (long)k0*g.sK + mcol, f3lo);
   }
   if (FPARK) {
 #pragma unroll

@@ -63,8 +63,11 @@ k_restrict(DevGrid f, DevGrid c, Link L, unsigned varmask)
 // ---- flux correction (smr.c:1277-1340) on the parent zones just outside the child, one side per
 // launch; the child's flux through a parent face is the average of its 2x2 faces (:1464-1640) ----
 __global__ void __launch_bounds__(256)
-k_flux_correct(DevGrid f, DevGrid c, Link L, int dim, int nvar, Real dt)
+k_flux_correct(DevGrid f, DevGrid c, Link L, int dim_arg, int nvar, Real dt)
 {
+  // dim_arg < 0: all sides in one launch, side = blockIdx.y (the sides correct disjoint parent zones: the zone outside each face)
+  const int dim = (dim_arg >= 0) ? dim_arg : (int)blockIdx.y;
+  if (dim_arg < 0 && !L.corr[dim]) return;
   const int d = dim >> 1, d1 = (d == 0) ? 1 : 0, d2 = (d == 2) ? 1 : 2;      // fast, slow transverse
   const long n = (long)L.n[d1]*L.n[d2];
   const long lin = (long)blockIdx.x*blockDim.x + threadIdx.x;
@@ -126,8 +129,12 @@ __device__ __forceinline__ Real mcd_slope(const Real vl, const Real vc, const Re
 // launch per boundary side, in the reference's order of sides (regions overlap at edges and
 // corners with identical values)
 __global__ void __launch_bounds__(128)
-k_prolong(DevGrid f, Link L, const Real *box, int dim, int nvar)
+k_prolong(DevGrid f, Link L, const Real *box, int dim_arg, int nvar)
 {
+  // dim_arg < 0: all sides in one launch, side = blockIdx.y (where two sides' regions overlap, at edges and corners, both write the
+  // same values: every ghost zone is a function of the snapshot `box` alone)
+  const int dim = (dim_arg >= 0) ? dim_arg : (int)blockIdx.y;
+  if (dim_arg < 0 && !L.prol[dim]) return;
   const int lo[3] = {f.is, f.js, f.ks}, hi[3] = {f.ie, f.je, f.ke};
   int ps[3], cnt[3];
   for (int d = 0; d < 3; d++) { ps[d] = lo[d] - NG; cnt[d] = (hi[d] - lo[d] + 1 + 2*NG)/2; }
@@ -249,6 +256,11 @@ struct aa_mesh {
   Link link[AA_MAXLEV];            // link[L]: grid L+1 on grid par[L]
   Real *box[AA_MAXLEV];            // prolongation snapshot of the parent's zones around grid L+1
   hipStream_t st = nullptr; bool own_stream = true;
+  // aa_mesh_step: the integrators of the levels read and write their own level only (main.c:572-585 calls them one after the other
+  // and couples the levels afterwards), and the Grids of the reference's decks are too small to fill the GPU alone: level l > 0
+  // integrates on side[l], forked from and joined to `st` by events (AA_MESH_OVERLAP=0: one after the other on `st`)
+  hipStream_t side[AA_MAXLEV] = {nullptr}; hipEvent_t ev_fork = nullptr, ev_join[AA_MAXLEV] = {nullptr}; bool overlap = true;
+  bool one_launch = true;          // the six sides of a flux correction / prolongation in one launch each
   double tcoarse = 0;              // ionrad_3d.c:44
   double time = 0, dt = 0; int nstep = 0;   // MeshS
 };
@@ -268,6 +280,16 @@ static int mesh_finish(aa_mesh *m, aa_grid **levels, aa_mesh **out)
   if (e == hipSuccess) e = hipStreamCreate(&m->st);
   if (e != hipSuccess) { mesh_drop(m); return aa_fail(-2, "[aa_mesh_create]: %s", hipGetErrorString(e)); }
   for (int l = 0; l < m->nl; l++) aa_set_stream(m->lev[l], (void*)m->st);
+  { const char *ev = getenv("AA_MESH_OVERLAP"); m->overlap = ev ? atoi(ev) != 0 : true; }
+  { const char *ev = getenv("AA_SMR_ONE_LAUNCH"); m->one_launch = ev ? atoi(ev) != 0 : true; }
+  if (m->overlap && m->nl > 1) {
+    e = hipEventCreateWithFlags(&m->ev_fork, hipEventDisableTiming);
+    for (int l = 1; l < m->nl && e == hipSuccess; l++) {
+      e = hipStreamCreateWithFlags(&m->side[l], hipStreamNonBlocking);
+      if (e == hipSuccess) e = hipEventCreateWithFlags(&m->ev_join[l], hipEventDisableTiming);
+    }
+    if (e != hipSuccess) { aa_mesh_destroy(m); return aa_fail(-2, "[aa_mesh_create]: %s", hipGetErrorString(e)); }
+  }
   for (int l = 0; l + 1 < m->nl; l++) {
     const Link &L = m->link[l];
     const size_t nb = (size_t)(L.n[0] + 6)*(L.n[1] + 6)*(L.n[2] + 6)*6;
@@ -418,6 +440,8 @@ void aa_mesh_destroy(aa_mesh *m)      // the levels stay alive and go back to th
     m->lev[l]->st = nullptr; m->lev[l]->own_stream = false; if (m->box[l]) hipFree(m->box[l]);
     m->lev[l]->keep_flux = false; m->lev[l]->keep = {0, {{0}}};      // no longer a level of a Mesh
   }
+  for (int l = 1; l < m->nl; l++) { if (m->side[l]) hipStreamDestroy(m->side[l]); if (m->ev_join[l]) hipEventDestroy(m->ev_join[l]); }
+  if (m->ev_fork) hipEventDestroy(m->ev_fork);
   if (m->own_stream) hipStreamDestroy(m->st);
   delete m;
 }
@@ -448,6 +472,14 @@ int aa_mesh_restrict_correct_pair(aa_mesh *m, int l)      // level l+1 -> level 
   Scope s(P, "smr_restrict_correct");
   hipLaunchKernelGGL(k_restrict, dim3(nblk((long)L.n[0]*L.n[1]*L.n[2], 256)), dim3(256), 0, m->st,
                      C->d, P->d, L, (1u << nvar) - 1u);
+  if (m->one_launch) {      // the six sides in ONE launch (AA_SMR_ONE_LAUNCH=0: one per side)
+    long nmax = 0; bool any = false;
+    for (int dim = 0; dim < 6; dim++) {
+      const int d = dim >> 1, d1 = (d == 0) ? 1 : 0, d2 = (d == 2) ? 1 : 2;
+      if (L.corr[dim]) { any = true; const long n = (long)L.n[d1]*L.n[d2]; if (n > nmax) nmax = n; }
+    }
+    if (any) hipLaunchKernelGGL(k_flux_correct, dim3(nblk(nmax, 256), 6), dim3(256), 0, m->st, C->d, P->d, L, -1, nvar, (Real)P->dt);
+  } else
   for (int dim = 0; dim < 6; dim++) {
     if (!L.corr[dim]) continue;
     const int d = dim >> 1, d1 = (d == 0) ? 1 : 0, d2 = (d == 2) ? 1 : 2;
@@ -497,6 +529,16 @@ int aa_mesh_prolongate(aa_mesh *m)
       const Link &L = m->link[l - 1];
       const int nvar = 5 + C->p.nscal;
       Scope s(C, "smr_prolongate");
+      if (m->one_launch) {
+        long nmax = 0;
+        for (int dim = 0; dim < 6; dim++) {
+          if (!L.prol[dim]) continue;
+          long cnt = 1;
+          for (int d = 0; d < 3; d++) cnt *= (d == (dim >> 1)) ? NG/2 : (C->p.Nx[d] + 2*NG)/2;
+          if (cnt > nmax) nmax = cnt;
+        }
+        if (nmax > 0) hipLaunchKernelGGL(k_prolong, dim3(nblk(nmax, 128), 6), dim3(128), 0, m->st, C->d, L, m->box[l - 1], -1, nvar);
+      } else
       for (int dim = 0; dim < 6; dim++) {
         if (!L.prol[dim]) continue;
         long cnt = 1;
@@ -617,10 +659,21 @@ int aa_mesh_step(aa_mesh *m, int *niter)
     }
     if ((rc = aa_mesh_ionrad_restrict_correct(m))) return rc;
   } else if (niter) for (int l = 0; l < m->nl; l++) niter[l] = 0;
-  for (int l = 0; l < m->nl; l++) {                                   // :572-585
-    aa_grid *g = m->lev[l];
-    if ((rc = (g->p.integrator == 1 ? aa_integrate_3d_vl(g) : aa_integrate_3d_ctu(g)))) return rc;
+  const bool fork = m->overlap && m->nl > 1 && m->side[1];
+  if (fork) {
+    HIPCHK(hipEventRecord(m->ev_fork, m->st));
+    for (int l = 1; l < m->nl; l++) HIPCHK(hipStreamWaitEvent(m->side[l], m->ev_fork, 0));
   }
+  rc = 0;
+  for (int l = 0; l < m->nl && !rc; l++) {                            // :572-585
+    aa_grid *g = m->lev[l];
+    if (fork && l > 0) g->st = m->side[l];
+    rc = (g->p.integrator == 1 ? aa_integrate_3d_vl(g) : aa_integrate_3d_ctu(g));
+    g->st = m->st;
+  }
+  if (fork)
+    for (int l = 1; l < m->nl; l++) { HIPCHK(hipEventRecord(m->ev_join[l], m->side[l])); HIPCHK(hipStreamWaitEvent(m->st, m->ev_join[l], 0)); }
+  if (rc) return rc;
   if ((rc = aa_mesh_restrict_correct(m))) return rc;                  // :591
   for (int l = 0; l < m->nl; l++)                                     // :597 Userwork_in_loop
     if (m->lev[l]->npin > 0 && (rc = aa_apply_pinned_cells(m->lev[l]))) return rc;

@@ -75,6 +75,32 @@ def test_blast_three_levels_vs_reference(aa, lib, name, strict):
         m.close()
 
 
+@pytest.mark.parametrize("name", ["smr_blast_3lev_edge_s8", "smr_blast_tree_s5"])
+@pytest.mark.parametrize("strict", [True, False])
+def test_one_launch_per_coupling_step_and_overlapped_levels_change_no_bit(aa, lib, name, strict, monkeypatch):
+    """Round 4: the six sides of a flux correction and of a prolongation are one launch each (the sides correct disjoint parent
+    zones; where two sides' ghost regions overlap both write the same values), and aa_mesh_step integrates the levels side by side on
+    streams of their own.  AA_SMR_ONE_LAUNCH=0 + AA_MESH_OVERLAP=0 is the round-3 schedule: every level's whole block, ghost zones
+    and corners included, must come out bit for bit, in both builds."""
+    g = np.load(os.path.join(GOLD, name + ".npz"))
+    out = []
+    for old in (False, True):
+        for k in ("AA_SMR_ONE_LAUNCH", "AA_MESH_OVERLAP"):
+            if old: monkeypatch.setenv(k, "0")
+            else: monkeypatch.delenv(k, raising=False)
+        m = make_gpu_mesh(aa, lib, "blast", [str(o) for o in g["overrides"]], strict, "ctu", 2, orc.deck_for("blast", g))
+        try:
+            m.start()
+            for _ in range(int(g["nstep"])):
+                m.step()
+            out.append(([lev.download() for lev in m.lev], m.time, m.dt))
+        finally:
+            m.close()
+    assert out[0][1:] == out[1][1:]
+    for a, b in zip(out[0][0], out[1][0]):
+        assert np.array_equal(a, b, equal_nan=True)
+
+
 def test_ghost_zones_after_prolongation_bitwise(aa, lib):
     """Prolongate alone: the ghost zones of the refined levels (incl. edges and corners, written by
     several sides) must equal the oracle's after start(), bit for bit."""
