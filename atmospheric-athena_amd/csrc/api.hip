@@ -96,7 +96,7 @@ int aa_create(const aa_params *p, aa_grid **out)
     c.ion_pass_cap = env("AA_ION_PASS_BLOCKS", 4096); if (c.ion_pass_cap < 1) c.ion_pass_cap = 1;
     c.pitch_align = env("AA_PITCH_ALIGN", 1);
     c.mailbox = env("AA_MAILBOX", 1); c.mailbox_spin_us = env("AA_MAILBOX_SPIN_US", 300);
-    c.bc_one = env("AA_BC_ONE", 1); c.fuse_pick = env("AA_ION_FUSE_PICK", 1);
+    c.bc_one = env("AA_BC_ONE", 1); c.fuse_pick = env("AA_ION_FUSE_PICK", 1); c.pin_one = env("AA_PIN_ONE", 1);
   }
   d.Nx1 = p->Nx[0]; d.Nx2 = p->Nx[1]; d.Nx3 = p->Nx[2];
   d.N1 = d.Nx1 + 2*AA_NGHOST; d.N2 = d.Nx2 + 2*AA_NGHOST; d.N3 = d.Nx3 + 2*AA_NGHOST;
@@ -405,8 +405,13 @@ int aa_apply_pinned_cells(aa_grid *g)
 {
   if (!g->slab.empty()) return slabs_apply_pinned_cells(g);
   Scope s(g, "pinned_cells");
-  launch_pinned(g->d, 5 + g->p.nscal, g->npin, g->pin_idx, g->pin_val, g->st);
-  if (g->cfl_ready) launch_pinned_cfl(g->d, g->npin, g->pin_idx, g->sc, g->st);     // they were left out of the integrator's maxima
+  // (cfl_ready: the zones were left out of the integrator's maxima and join them here, from the values written -- one launch;
+  //  AA_PIN_ONE=0: k_pinned + k_pinned_cfl, which reads them back)
+  if (g->cfl_ready && g->d.cfg.pin_one) launch_pinned(g->d, 5 + g->p.nscal, g->npin, g->pin_idx, g->pin_val, g->st, g->sc);
+  else {
+    launch_pinned(g->d, 5 + g->p.nscal, g->npin, g->pin_idx, g->pin_val, g->st);
+    if (g->cfl_ready) launch_pinned_cfl(g->d, g->npin, g->pin_idx, g->sc, g->st);
+  }
   return 0;
 }
 

@@ -1198,8 +1198,7 @@ k_correct_all(DevGrid g, Real dt, int kchunk, StepRatios sr)
 // eta of the faces on the tile edges of k_correct_all: the face's slot holds lambda_r of the zone above it, the edge
 // array lambda_l of the zone below (same expression as inside the tile: integrate_3d_ctu.c:2300-2343)
 template <int D>
-__global__ void __launch_bounds__(256)
-k_eta_edges(DevGrid g)
+AA_DEV void eta_edges(const DevGrid &g)
 {
   // faces along D at the tile origins after the first; all zones s-1 .. e+1 of the other two directions
   const int n1 = g.ie - g.is + 3, n2 = g.je - g.js + 3, n3 = g.ke - g.ks + 3;
@@ -1218,6 +1217,9 @@ k_eta_edges(DevGrid g)
   Real *e = Ef(g, D);
   e[m] = 0.5*fabs(e[m] - Ef(g, 3 + D)[m - sD]);
 }
+// both directions in one launch (blockIdx.y; they touch different arrays)
+__global__ void __launch_bounds__(256)
+k_eta_edges(DevGrid g) { if (blockIdx.y == 0) eta_edges<0>(g); else eta_edges<1>(g); }
 
 // ---- steps 9b-d: second-pass fluxes with the H-correction -----------------------------------
 template <int NS, int D>
@@ -2038,6 +2040,26 @@ __global__ void k_soa_to_aos(DevGrid g, int nvar, Real *aos)
   const long m = (long)k*g.sK + (long)j*g.sJ + i;
   for (int v = 0; v < nvar; v++) aos[lin*nvar + v] = Uf(g, v)[m];
 }
+// the same with the zones' contribution to new_dt's maxima from the values just written (what k_pinned_cfl reads back): one launch
+__global__ void k_pinned_with_cfl(DevGrid g, int nvar, long long n, const long long *idx, const Real *vals, DevScalars *sc)
+{
+  Real mx[3] = {0.0, 0.0, 0.0};
+  for (long lin = (long)blockIdx.x*blockDim.x + threadIdx.x; lin < n; lin += (long)gridDim.x*blockDim.x) {
+    const long long c = idx[lin];
+    const int i = (int)(c % g.N1), j = (int)((c / g.N1) % g.N2), k = (int)(c / ((long)g.N1*g.N2));
+    const long m = (long)k*g.sK + (long)j*g.sJ + i;
+    const Real *q = vals + lin*nvar;
+    for (int v = 0; v < nvar; v++) Uf(g, v)[m] = q[v];
+    if (i >= g.is && i <= g.ie && j >= g.js && j <= g.je && k >= g.ks && k <= g.ke)      // new_dt looks at active zones only
+      cfl_zone(q[0], q[1], q[2], q[3], q[4], g.Gamma, g.Gamma_1, mx);
+  }
+#pragma unroll
+  for (int d = 0; d < 3; d++) {
+    Real v = mx[d];
+    for (int o = 32; o > 0; o >>= 1) { const Real w = __shfl_xor(v, o); v = (w > v || v != v) ? w : v; }
+    if ((threadIdx.x & 63) == 0) atomic_max_pos(&sc->max_v[d], v);
+  }
+}
 __global__ void k_pinned(DevGrid g, int nvar, long long n, const long long *idx, const Real *vals)
 {
   const long lin = (long)blockIdx.x*blockDim.x + threadIdx.x;
@@ -2266,8 +2288,10 @@ static void correct_all_impl(const HostGrid &g, Real dt, bool x3f, hipStream_t s
     else         hipLaunchKernelGGL((k_correct_all<NS, GRAV, 2, false>), grid, blk, 0, st, g, dt, kc, sr);
   }
   const long nb1 = (g.ie + 1 - (g.is - 16))/64, nb2 = (g.je + 1 - (g.js - 1))/CA_TJ;
-  if (nb1 > 0) hipLaunchKernelGGL((k_eta_edges<0>), dim3(nblk(nb1*nj*nk, 256)), dim3(256), 0, st, g);
-  if (nb2 > 0) hipLaunchKernelGGL((k_eta_edges<1>), dim3(nblk((long)ni*nb2*nk, 256)), dim3(256), 0, st, g);
+  {
+    const long c0 = nb1 > 0 ? nb1*nj*nk : 0, c1 = nb2 > 0 ? (long)ni*nb2*nk : 0;      // (a direction without inner tile edges returns at once)
+    if (c0 > 0 || c1 > 0) hipLaunchKernelGGL(k_eta_edges, dim3(nblk(c0 > c1 ? c0 : c1, 256), 2), dim3(256), 0, st, g);
+  }
 }
 void launch_correct_all(const HostGrid &g, int nscal, Real dt, bool grav, bool x3f, hipStream_t st)
 {
@@ -2441,8 +2465,13 @@ void launch_aos_to_soa(const DevGrid &g, int nvar, const Real *aos, hipStream_t 
 { const long n = (long)g.N1*g.N2*g.N3; hipLaunchKernelGGL(k_aos_to_soa, dim3(nblk(n, 256)), dim3(256), 0, st, g, nvar, aos); }
 void launch_soa_to_aos(const DevGrid &g, int nvar, Real *aos, hipStream_t st)
 { const long n = (long)g.N1*g.N2*g.N3; hipLaunchKernelGGL(k_soa_to_aos, dim3(nblk(n, 256)), dim3(256), 0, st, g, nvar, aos); }
-void launch_pinned(const DevGrid &g, int nvar, long long n, const long long *idx, const Real *vals, hipStream_t st)
-{ if (n > 0) hipLaunchKernelGGL(k_pinned, dim3(nblk(n, 256)), dim3(256), 0, st, g, nvar, n, idx, vals); }
+void launch_pinned(const DevGrid &g, int nvar, long long n, const long long *idx, const Real *vals, hipStream_t st, DevScalars *sc)
+{
+  if (n <= 0) return;
+  if (sc) { unsigned nb = nblk(n, 256*8); if (nb > 256) nb = 256; if (nb < 1) nb = 1;
+            hipLaunchKernelGGL(k_pinned_with_cfl, dim3(nb), dim3(256), 0, st, g, nvar, n, idx, vals, sc); }
+  else hipLaunchKernelGGL(k_pinned, dim3(nblk(n, 256)), dim3(256), 0, st, g, nvar, n, idx, vals);
+}
 void launch_pack_x3(const DevGrid &g, int nvar, int k0, Real *buf, hipStream_t st)
 { const long n = (long)g.N1*g.N2*4; hipLaunchKernelGGL(k_pack_x3, dim3(nblk(n, 256)), dim3(256), 0, st, g, nvar, k0, buf); }
 void launch_unpack_x3(const DevGrid &g, int nvar, int k0, const Real *buf, hipStream_t st)

@@ -31,7 +31,7 @@ int  launch_history(const DevGrid &g, int nscal, Real *partial, hipStream_t st);
 void launch_aos_to_soa(const DevGrid &g, int nvar, const Real *aos, hipStream_t st);
 void launch_soa_to_aos(const DevGrid &g, int nvar, Real *aos, hipStream_t st);
 void launch_pinned(const DevGrid &g, int nvar, long long n, const long long *idx, const Real *vals,
-                   hipStream_t st);
+                   hipStream_t st, DevScalars *sc = nullptr);      // sc: and the zones' share of new_dt's maxima, from the values written
 void launch_pack_x3(const DevGrid &g, int nvar, int k0, Real *buf, hipStream_t st);
 void launch_unpack_x3(const DevGrid &g, int nvar, int k0, const Real *buf, hipStream_t st);
 void launch_pack_x2(const DevGrid &g, int nvar, int j0, Real *buf, hipStream_t st);      // pencils: the x2 halo (bvals_mhd.c:2462)

@@ -493,10 +493,10 @@ def pmc_passes(argv):
 
     def bench_name(n):
         """rocprofv3's kernel name -> the name bench.py's event profiler books the launch under (hydro chain of the CTU integrator)"""
-        m = re.search(r"(k_\w+)<([^>]*)>", n)
+        m = re.search(r"(k_\w+)(?:<([^>]*)>)?", n)
         if not m:
             return None
-        k, targs = m.group(1), [x.strip() for x in m.group(2).split(",")]
+        k, targs = m.group(1), [x.strip() for x in (m.group(2) or "").split(",")]
         if k == "k_flux2_update":
             return "flux2_update"
         if k in ("k_correct_all", "k_eta_edges", "k_x1_edge_flux"):

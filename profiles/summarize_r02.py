@@ -35,7 +35,7 @@ ALIAS = [(r"k_ion_pass<true, true, false>", "ion_pass"), (r"k_ion_pass<true, fal
          (r"k_ion_begin16", "ion_begin"), (r"k_ion_finish", "ion_finish"), (r"k_ion_reduce", "ion_pass"), (r"k_ion_pick2", "ion_pass"),
          (r"k_ion_update", "ion_update"), (r"k_ion_rates", "ion_rates"), (r"k_ray_sweep<true>", "ray_sweep_rates"),
          (r"k_ray_sweep<false>", "ray_sweep"), (r"k_ion_begin", "ion_begin"), (r"k_cfl", "new_dt"), (r"k_update<", "update"),
-         (r"k_flux2_update<", "flux2_update"), (r"k_correct_all<", "correct_all"), (r"k_eta_edges<", "correct_all"), (r"k_x1_edge_flux<", "correct_all"),
+         (r"k_flux2_update<", "flux2_update"), (r"k_correct_all<", "correct_all"), (r"k_eta_edges", "correct_all"), (r"k_x1_edge_flux<", "correct_all"),
          (r"k_sweep_x1<1, true, 0", "sweep_x1"), (r"k_sweep_x1_flat<1, true, 0", "sweep_x1"), (r"k_sweep_march<1, 1, true, 0", "sweep_x2"), (r"k_sweep_march<1, 2, true, 0", "sweep_x3"),
          (r"k_bc", "bvals_mhd"), (r"k_pinned", "pinned_cells")]
 

@@ -53,9 +53,9 @@ def test_fewer_launches_same_bits(case, ov, strict, tmp_path):
     """Round 4, for the small Grids of the reference's own decks (a step there is a few dozen launches and 2 + N_sub read-backs):
     bvals_mhd's three passes as ONE launch over the ghost shell (k_bc_shell; AA_BC_ONE=0: the passes), the scalars back through a
     polled mailbox in pinned memory (AA_MAILBOX=0: copy + stream wait), the sub-cycle's fold and pick in one launch where one rank
-    reduces alone (AA_ION_FUSE_PICK=0).  Copies, sign flips and the same arithmetic: the whole block incl. every ghost zone and corner
+    reduces alone (AA_ION_FUSE_PICK=0), the pinned zones' share of new_dt's maxima taken by the kernel that pins them (AA_PIN_ONE=0).  Copies, sign flips and the same arithmetic: the whole block incl. every ghost zone and corner
     must come out bit for bit, in both builds -- with periodic, outflow and reflecting sides mixed."""
     new = _run(case, {"LAYOUT_OV": ov}, str(tmp_path / "new.npy"), strict)
-    old = _run(case, {"LAYOUT_OV": ov, "AA_BC_ONE": "0", "AA_MAILBOX": "0", "AA_ION_FUSE_PICK": "0"}, str(tmp_path / "old.npy"), strict)
+    old = _run(case, {"LAYOUT_OV": ov, "AA_BC_ONE": "0", "AA_MAILBOX": "0", "AA_ION_FUSE_PICK": "0", "AA_PIN_ONE": "0"}, str(tmp_path / "old.npy"), strict)
     assert np.isfinite(new).all() or case[0] == "ioniz_sphere"
     assert np.array_equal(new, old, equal_nan=True)
