@@ -1096,7 +1096,7 @@ k_correct_all(DevGrid g, Real dt, int kchunk, StepRatios sr)
       }
       __builtin_amdgcn_sched_barrier(0);
     }
-    if (do3) {   // ---- x3 first: what only this block needs (the plane below / the states zone k kept) is dead under x1 / x2 ----
+    if (do3) {   // ---- x3 in front of x2 (and of x1 where the x1 first pass is not on board): what only this block needs (the plane below / the states zone k kept) is dead under the others ----
       Real ll, lr;
       if (PARK3) {
 #pragma unroll
