@@ -75,6 +75,25 @@ def test_blast_three_levels_vs_reference(aa, lib, name, strict):
         m.close()
 
 
+@pytest.mark.parametrize("name", ["smr_blast_3lev_s6", "smr_blast_3lev_edge_s8", "smr_blast_2dom_s6", "smr_blast_tree_s5"])
+def test_levels_on_the_big_grid_kernels_vs_reference(aa, lib, name, monkeypatch):
+    """The levels of the fixtures are small enough for the tile kernels; Grids of 4e5 zones or more (the 80^3 root of the reference's own
+    deck since round 4) take k_correct_all with the x1 / x3 first passes on board, whose second-pass fluxes on the level boundaries
+    (KeepPlanes) feed the flux correction.  Forced here (AA_CORRECT_ALL=1): strict build, every level bit for bit the reference's."""
+    monkeypatch.setenv("AA_CORRECT_ALL", "1")
+    g = np.load(os.path.join(GOLD, name + ".npz"))
+    m = make_gpu_mesh(aa, lib, "blast", [str(o) for o in g["overrides"]], True, "ctu", 2, orc.deck_for("blast", g))
+    try:
+        m.start()
+        for _ in range(int(g["nstep"])):
+            m.step()
+        assert m.time == float(g["time"]) and m.dt == float(g["dt"])
+        for l, lev in enumerate(m.lev):
+            assert np.array_equal(lev.download()[4:-4, 4:-4, 4:-4, :5], g[f"U{l}"][..., :5]), f"level {l}"
+    finally:
+        m.close()
+
+
 @pytest.mark.parametrize("name", ["smr_blast_3lev_edge_s8", "smr_blast_tree_s5"])
 @pytest.mark.parametrize("strict", [True, False])
 def test_one_launch_per_coupling_step_and_overlapped_levels_change_no_bit(aa, lib, name, strict, monkeypatch):
@@ -141,8 +160,13 @@ def test_sphere_two_domains_on_a_level_vs_reference(aa, lib, strict):
         m.close()
 
 
+@pytest.mark.parametrize("chain", ["by size", "correct_all"])
 @pytest.mark.parametrize("strict", [True, False])
-def test_sphere_two_levels_vs_reference(aa, lib, strict):
+def test_sphere_two_levels_vs_reference(aa, lib, strict, chain, monkeypatch):
+    """(chain "correct_all": AA_CORRECT_ALL=1, the kernels the 80^3 root of the reference's own deck takes since round 4 -- gravity,
+    scalar, radiation and the kept level-boundary fluxes together)"""
+    if chain == "correct_all":
+        monkeypatch.setenv("AA_CORRECT_ALL", "1")
     g = np.load(os.path.join(GOLD, "smr_ioniz_sphere_2lev_s4.npz"))
     m = make_gpu_mesh(aa, lib, "ioniz_sphere", [str(o) for o in g["overrides"]], strict)
     try:
