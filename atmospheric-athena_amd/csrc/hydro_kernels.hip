@@ -895,23 +895,20 @@ k_correct_all(DevGrid g, Real dt, int kchunk, StepRatios sr)
     Real mlo[3], mhi[3];
     Real hv1 = 0.0;
     // What the zone needs behind its x1 Riemann problem is requested in front of it where the registers allow: the wait would
-    // otherwise come behind it with nothing left to do.  CA_X1F_EARLY, bits: 1 potentials, 2 the x2 first-pass fluxes (the default:
-    // k_correct_all 22.6 -> 20.2 ms at 512^3, three registers in scratch), 4 the x2 neighbour rows.  (More than the default spills
-    // tens of registers and loses, also with the potentials parked in LDS: profiles/r04_x1f_ab.txt.)
-    // The scalar kernel without gravity (ifront) has no room at two waves per SIMD: CA_X1F_EARLY_NG, default 0.
+    // otherwise come behind it with nothing left to do.  CA_X1F_EARLY=1 (the default): the x2 first-pass fluxes -- k_correct_all 22.6 ->
+    // 20.2 ms at 512^3, three registers in scratch.  (The potentials and the x2 neighbour rows as well: tens of registers in scratch, a
+    // loss -- also with the potentials parked in LDS; profiles/r04_x1f_ab.txt.)  The scalar kernel without gravity (ifront) has no room
+    // at two waves per SIMD: CA_X1F_EARLY_NG, default 0.
 #ifndef CA_X1F_EARLY
-#define CA_X1F_EARLY 2
+#define CA_X1F_EARLY 1
 #endif
 #ifndef CA_X1F_EARLY_NG
 #define CA_X1F_EARLY_NG 0
 #endif
-    constexpr int EMASK = (NS && !GRAV) ? CA_X1F_EARLY_NG : CA_X1F_EARLY;
-    constexpr bool EARLY_P = X1F && ((EMASK & 1) != 0), EARLY_F = X1F && ((EMASK & 2) != 0), EARLY_H = X1F && ((EMASK & 4) != 0);
-    Real hv2[6], eph[7];
+    constexpr bool EARLY_F = X1F && (((NS && !GRAV) ? CA_X1F_EARLY_NG : CA_X1F_EARLY) != 0);
+    Real hv2[6];
 #pragma unroll
     for (int v = 0; v < 6; v++) hv2[v] = 0.0;
-#pragma unroll
-    for (int v = 0; v < 7; v++) eph[v] = 0.0;
     const bool edge_row = (row == 0) || (row == CA_TJ - 1);
     // the x1 neighbour zones and edge fluxes of plane kk (lanes 0..23 of every wave)
     auto x1_halo = [&](int kk) -> Real {
@@ -986,21 +983,9 @@ k_correct_all(DevGrid g, Real dt, int kchunk, StepRatios sr)
     Real eb0[6], eb1[6];
 #pragma unroll
     for (int v = 0; v < 6; v++) { eb0[v] = 0.0; eb1[v] = 0.0; }
-    if (X1F && zone) {
-      if (EARLY_P && GRAV) {
-        eph[0] = Pf(g, 0)[m];
+    if (EARLY_F && zone) {
 #pragma unroll
-        for (int e = 0; e < 3; e++) { eph[1 + 2*e] = Pf(g, 1 + e)[m + stride_rt(g, e)]; eph[2 + 2*e] = Pf(g, 1 + e)[m]; }
-      }
-      if (EARLY_F) {
-#pragma unroll
-        for (int v = 0; v < NV; v++) { eb0[v] = Ff(g, 1, v)[m]; eb1[v] = Ff(g, 1, v)[m + g.sJ]; }
-      }
-      if (EARLY_H && full && edge_row) {
-        const long m2 = (row == 0) ? m - g.sJ : m + g.sJ;
-#pragma unroll
-        for (int v = 0; v < NV; v++) hv2[v] = Uf(g, gv<1>(v))[m2];
-      }
+      for (int v = 0; v < NV; v++) { eb0[v] = Ff(g, 1, v)[m]; eb1[v] = Ff(g, 1, v)[m + g.sJ]; }
     }
     if (X1F && zone) {   // ---- the x1 first pass, before anything else of the zone is formed: its fluxes correct the x2 and x3 states ----
       if (lane < 24) s_h1[row][lane] = hv1;
@@ -1019,8 +1004,7 @@ k_correct_all(DevGrid g, Real dt, int kchunk, StepRatios sr)
         for (int v = 0; v < 6; v++) { if (lane == 0) wm[v] = wh[v]; else wp[v] = wh[v]; }
       }
       if (GRAV) {      // (the zone's kicks along x1; formed again with the others below)
-        const Real phic = EARLY_P ? eph[0] : Pf(g, 0)[m], phir = EARLY_P ? eph[1] : Pf(g, 1)[m + stride_rt(g, 0)];
-        const Real phil = EARLY_P ? eph[2] : Pf(g, 1)[m], dtodx = sr.dtodx[0];
+        const Real phic = Pf(g, 0)[m], phir = Pf(g, 1)[m + stride_rt(g, 0)], phil = Pf(g, 1)[m], dtodx = sr.dtodx[0];
         cf.kl[0] = dtodx*(phir - phic); cf.kr[0] = dtodx*(phic - phil);
       }
       cell_recon<NS, 0, GRAV, ORD>(g, m, dt, sr.dtodx[0], cf, wm, ws, wp, wl1, wr1);
@@ -1042,7 +1026,7 @@ k_correct_all(DevGrid g, Real dt, int kchunk, StepRatios sr)
       }
       __builtin_amdgcn_sched_barrier(0);
     }
-    if (full && !EARLY_H) {
+    if (full) {
       if (edge_row) {
         const long m2 = (row == 0) ? m - g.sJ : m + g.sJ;
 #pragma unroll
@@ -1061,10 +1045,10 @@ k_correct_all(DevGrid g, Real dt, int kchunk, StepRatios sr)
       if (!X3F) f3[v] = c1;
     }
     if (GRAV) {
-      const Real dc = wc[0], phic = EARLY_P ? eph[0] : Pf(g, 0)[m];
+      const Real dc = wc[0], phic = Pf(g, 0)[m];
 #pragma unroll
       for (int e = 0; e < 3; e++) {
-        const Real phir = EARLY_P ? eph[1 + 2*e] : Pf(g, 1 + e)[m + stride_rt(g, e)], phil = EARLY_P ? eph[2 + 2*e] : Pf(g, 1 + e)[m];
+        const Real phir = Pf(g, 1 + e)[m + stride_rt(g, e)], phil = Pf(g, 1 + e)[m];
         cf.gm[e] = q[e]*(phir - phil)*dc;
         cf.ge[e] = q[e]*(mlo[e]*(phic - phil) + mhi[e]*(phir - phic));
         const Real dtodx = sr.dtodx[e];
@@ -1544,26 +1528,19 @@ k_flux2_update(DevGrid g, const Real *dhalf, Real dt, int kchunk, KeepPlanes kp,
       }
     }
     __builtin_amdgcn_sched_barrier(0);
-    // FU_EARLY: the zone's own operands of the update are requested in front of the x3 Riemann problem instead of behind it
-    // (bits: 1 the conserved variables, 2 potentials + d^{n+1/2}; same-box, 512^3: 0 13.45, 1 13.26, 2 13.15 (the default), 3 14.57 ms
-    //  -- both together spill four registers)
+    // FU_EARLY=1 (the default): the potentials and d^{n+1/2} of the zone's update are requested in front of the x3 Riemann problem
+    // instead of behind it (same-box, 512^3: 13.45 -> 13.15 ms; the conserved variables instead 13.26, both 14.57: four registers in
+    // scratch -- profiles/r04_x1f_ab.txt item 7)
 #ifndef FU_EARLY
-#define FU_EARLY 2
+#define FU_EARLY 1
 #endif
-    Real eu[6], ep[7], edh = 0.0;
-#pragma unroll
-    for (int v = 0; v < 6; v++) eu[v] = 0.0;
+    constexpr bool EP = GRAV && (FU_EARLY != 0);
+    Real ep[7], edh = 0.0;
 #pragma unroll
     for (int v = 0; v < 7; v++) ep[v] = 0.0;
-    if (cell) {
-      if (FU_EARLY & 1) {
-#pragma unroll
-        for (int v = 0; v < NV; v++) eu[v] = Uf(g, v)[m];
-      }
-      if ((FU_EARLY & 2) && GRAV) {
-        ep[0] = Pf(g, 0)[m]; edh = dhalf[m];
-        ep[1] = Pf(g, 1)[m + 1]; ep[2] = Pf(g, 1)[m]; ep[3] = Pf(g, 2)[m + g.sJ]; ep[4] = Pf(g, 2)[m]; ep[5] = Pf(g, 3)[m + g.sK]; ep[6] = Pf(g, 3)[m];
-      }
+    if (EP && cell) {
+      ep[0] = Pf(g, 0)[m]; edh = dhalf[m];
+      ep[1] = Pf(g, 1)[m + 1]; ep[2] = Pf(g, 1)[m]; ep[3] = Pf(g, 2)[m + g.sJ]; ep[4] = Pf(g, 2)[m]; ep[5] = Pf(g, 3)[m + g.sK]; ep[6] = Pf(g, 3)[m];
     }
     Real f3[6];
 #pragma unroll
@@ -1582,13 +1559,12 @@ k_flux2_update(DevGrid g, const Real *dhalf, Real dt, int kchunk, KeepPlanes kp,
       for (int n = 0; n < NV; n++) { if (FPARK) s_f3[FPARK ? n : 0][FPARK ? row : 0][lane] = f3[n]; else f3lo[n] = f3[n]; }
       Real u[6];
 #pragma unroll
-      for (int v = 0; v < NV; v++) u[v] = (FU_EARLY & 1) ? eu[v] : Uf(g, v)[m];
+      for (int v = 0; v < NV; v++) u[v] = Uf(g, v)[m];
       // (the mask byte with the zone's other operands, not behind the stores of U: a load that is consumed at once waits
       //  for everything issued before it, i.e. the wave sat out the six stores' round trip in every plane)
       unsigned char pinned = 0;
       if (CFL && pinmask) pinned = pinmask[m];
       if (GRAV) {   // :2741-2782, with the mass fluxes (sweep component 0) of the faces just solved
-        constexpr bool EP = (FU_EARLY & 2) != 0;
         const Real phic = EP ? ep[0] : Pf(g, 0)[m], dh = EP ? edh : dhalf[m];
         { const Real phir = EP ? ep[1] : Pf(g, 1)[m + 1], phil = EP ? ep[2] : Pf(g, 1)[m];
           u[1] -= dtodx[0]*(phir - phil)*dh;
