@@ -546,12 +546,9 @@ static void cfl_arm(aa_grid *g)
 int aa_cfl_in_update(aa_grid *g, int on)
 {
   if (!g->slab.empty()) return 0;      // (composite Grids keep k_cfl)
-#if !defined(AA_FAST_DIV) || !AA_FAST_DIV
-  // the strict build keeps k_cfl: with -ffp-contract=off its 6-variable update kernel spills 15 registers with the CFL
-  // epilogue (17.0 against 14.9 ms at 512^3) -- more than the sweep it would save (AA_CFL_FUSED=2 forces it: the tests'
-  // bit-for-bit comparison of the two ways)
-  if (!g->cfl_force) on = 0;
-#endif
+  // (until round 4 the strict build kept k_cfl: with -ffp-contract=off its 6-variable update kernel spilled 15 registers with the
+  //  CFL epilogue; with the lower x3 flux parked in LDS and dt/dx in scalar registers it holds 250 without scratch, and the strict
+  //  step is 48.1 -> 47.1 ms at 512^3 with the maxima from the update kernel.  AA_CFL_FUSED=0: k_cfl; =2: as 1, kept for the tests)
   g->cfl_in_update = on != 0; g->cfl_ready = false;
   return 0;
 }
@@ -1013,11 +1010,7 @@ int aa_step(aa_grid *g, int *niter_out)
   }
   // (between the integrator and new_dt this loop only pins zones: the integrator may leave new_dt's maxima behind)
   const bool keep_opt = g->cfl_in_update;
-#if defined(AA_FAST_DIV) && AA_FAST_DIV
-  if (g->slab.empty() && g->cfl_step) g->cfl_in_update = true;
-#else
-  if (g->slab.empty() && g->cfl_step && g->cfl_force) g->cfl_in_update = true;
-#endif
+  if (g->slab.empty() && g->cfl_step) g->cfl_in_update = true;      // (both builds since round 4: aa_cfl_in_update)
   rc = (g->p.integrator == 1 ? aa_integrate_3d_vl(g) : aa_integrate_3d_ctu(g));                    // :572-585
   g->cfl_in_update = keep_opt;
   if (rc) return rc;

@@ -34,7 +34,7 @@ struct aa_grid {
   bool ion_spec_on = true;             // AA_ION_SPECULATE=0: the first pass of an ion step never applies an update
   double ion_spec_dt = -1.0, ion_spec_limit = 0.0;   // aa_ion_speculate: armed for the next first pass / what it was told
   bool ion_spec_armed = false;         //   ... the first pass has speculated: aa_ion_pick(first) settles it
-  bool cfl_force = false;              // AA_CFL_FUSED=2: also in the strict build
+  bool cfl_force = false;              // AA_CFL_FUSED=2 (until round 4: the way to have it in the strict build too; now the same as 1)
   bool cfl_step = true;                // aa_step does so by itself (AA_CFL_FUSED=0: k_cfl)
   bool cfl_ready = false;              //   ... and has done so for the state as it is now
   bool active_dirty = true;            // a call since the last full upload / download of U wrote ACTIVE zones on the device (aa_download_ghost_zones then moves the whole block)
