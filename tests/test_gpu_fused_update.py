@@ -159,12 +159,12 @@ def test_new_dt_maxima_from_the_update_kernel(problem, ov, nstep, strict, integr
 
 @pytest.mark.parametrize("order", [2, 3])
 @pytest.mark.parametrize("problem,nx1", [("blast", 46), ("blast", 47), ("blast", 48), ("ioniz_sphere", 110), ("ioniz_sphere", 111),
-                                         ("ifront", 130)])
+                                         ("ifront", 130), ("blast", 520), ("ioniz_sphere", 1039)])
 def test_x1_first_pass_inside_correct_all_at_the_tile_edges(problem, nx1, order, monkeypatch):
     """Round 4: with the x3 first pass on board k_correct_all also does the x1 first pass (hydro_kernels.hip CA_X1F): the right state
     of a zone's upper face comes from the lane above, the flux of the face between two 64-zone tiles (zone is - 16 + 64 b) from
     k_x1_edge_flux.  Sizes that put the last face the kernel needs (ie + 2) exactly on such an edge (Nx1 = 47, 111), one zone
-    before it (46, 110) and one behind (48), and three tiles (130): bit for bit the chain of separate kernels, strict build, both
+    before it (46, 110) and one behind (48), three tiles (130), nine (520) and seventeen with the last face on an edge (1039): bit for bit the chain of separate kernels, strict build, both
     reconstructions; AA_X3_FUSED=0 runs the same kernel WITHOUT either first pass on board."""
     ov = [f"domain1/Nx1={nx1}", "domain1/Nx2=9", "domain1/Nx3=11"]
     if problem == "ioniz_sphere":
