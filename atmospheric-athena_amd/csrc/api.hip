@@ -97,6 +97,7 @@ int aa_create(const aa_params *p, aa_grid **out)
     c.pitch_align = env("AA_PITCH_ALIGN", 1);
     c.mailbox = env("AA_MAILBOX", 1); c.mailbox_spin_us = env("AA_MAILBOX_SPIN_US", 300);
     c.bc_one = env("AA_BC_ONE", 1); c.fuse_pick = env("AA_ION_FUSE_PICK", 1); c.pin_one = env("AA_PIN_ONE", 1);
+    c.edge_overlap = env("AA_EDGE_OVERLAP", 1);
   }
   d.Nx1 = p->Nx[0]; d.Nx2 = p->Nx[1]; d.Nx3 = p->Nx[2];
   d.N1 = d.Nx1 + 2*AA_NGHOST; d.N2 = d.Nx2 + 2*AA_NGHOST; d.N3 = d.Nx3 + 2*AA_NGHOST;
@@ -220,6 +221,9 @@ void aa_destroy(aa_grid *g)
   if (g->pin_mask) hipFree(g->pin_mask);
   if (g->cfl_part) hipFree(g->cfl_part);
   if (g->d.phalf) hipFree(g->d.phalf);
+  if (g->side) hipStreamDestroy(g->side);
+  if (g->ev_fork) hipEventDestroy(g->ev_fork);
+  if (g->ev_join) hipEventDestroy(g->ev_join);
   if (g->own_stream) hipStreamDestroy(g->st);
   delete g;
 }
@@ -601,7 +605,7 @@ int aa_integrate_3d_ctu(aa_grid *g)
     { Scope s(g, "sweep_x2"); HL(launch_sweep)(d, ns, 1, dt, g->grav, g->st, 0, 2); HL(launch_sweep)(d, ns, 1, dt, g->grav, g->st, 2 + nk, 2); }
     if (!x1_fused(g)) { Scope s(g, "sweep_x1"); HL(launch_sweep)(d, ns, 0, dt, g->grav, g->st, 0, 2); HL(launch_sweep)(d, ns, 0, dt, g->grav, g->st, 2 + nk, 2); }
     if (!x3_fused(g)) { Scope s(g, "sweep_x3"); HL(launch_sweep)(d, ns, 2, dt, g->grav, g->st, 0, -1); }
-    { Scope s(g, "correct_all"); HL(launch_correct_all)(d, ns, dt, g->grav, x3_fused(g), g->st); }
+    { Scope s(g, "correct_all"); HL(launch_correct_all)(d, ns, dt, g->grav, x3_fused(g), g->st, false); }
     no_h_correction(g);
     Scope s(g, "flux2_update");
     cfl_arm(g);
@@ -610,12 +614,28 @@ int aa_integrate_3d_ctu(aa_grid *g)
     return 0;
   }
   if (d.slope) { Scope s(g, "ppm_slopes"); for (int dir = 0; dir < 3; dir++) HL(launch_slopes)(d, ns, dir, g->st, nullptr); }
+  // the tile-edge x1 fluxes k_correct_all needs (k_x1_edge_flux: a few bytes per zone, bound by its strided loads) beside the x2 sweep
+  // (bound by its arithmetic) on a stream of their own; both read U only
+  bool edges_aside = false;
+  if (x1_fused(g) && d.cfg.edge_overlap) {
+    if (!g->side) {
+      HIPCHK(hipStreamCreateWithFlags(&g->side, hipStreamNonBlocking));
+      HIPCHK(hipEventCreateWithFlags(&g->ev_fork, hipEventDisableTiming));
+      HIPCHK(hipEventCreateWithFlags(&g->ev_join, hipEventDisableTiming));
+    }
+    HIPCHK(hipEventRecord(g->ev_fork, g->st));
+    HIPCHK(hipStreamWaitEvent(g->side, g->ev_fork, 0));
+    HL(launch_x1_edges)(d, ns, dt, g->grav, g->side);
+    HIPCHK(hipEventRecord(g->ev_join, g->side));
+    edges_aside = true;
+  }
   // x2 and x3 first, so that the x1 sweep can do its first pass and its correct pass in one go
   { Scope s(g, "sweep_x2"); HL(launch_sweep)(d, ns, 1, dt, g->grav, g->st, 0, -1); }
+  if (edges_aside) HIPCHK(hipStreamWaitEvent(g->st, g->ev_join, 0));
   if (!(g->correct_all && x3_fused(g))) { Scope s(g, "sweep_x3"); HL(launch_sweep)(d, ns, 2, dt, g->grav, g->st, 0, -1); }
   if (g->correct_all) {
     if (!x1_fused(g)) { Scope s(g, "sweep_x1"); HL(launch_sweep)(d, ns, 0, dt, g->grav, g->st, 0, -1); }
-    { Scope s(g, "correct_all"); HL(launch_correct_all)(d, ns, dt, g->grav, x3_fused(g), g->st); }
+    { Scope s(g, "correct_all"); HL(launch_correct_all)(d, ns, dt, g->grav, x3_fused(g), g->st, edges_aside); }
   } else {
     { Scope s(g, "sweep_correct_x1"); HL(launch_sweep_correct_x1)(d, ns, dt, g->grav, g->st); }
     { Scope s(g, "correct_x2"); HL(launch_correct)(d, ns, 1, dt, g->grav, g->st); }

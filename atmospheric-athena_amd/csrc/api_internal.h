@@ -20,6 +20,7 @@ struct aa_grid {
   aa::HostGrid d;
   aa::IonPar ion;
   hipStream_t st = nullptr; bool own_stream = false;
+  hipStream_t side = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr;      // aa_integrate_3d_ctu: the tile-edge x1 fluxes beside the x2 sweep
   aa::Real *pool = nullptr; size_t pool_doubles = 0;
   aa::DevScalars *sc = nullptr;        // device
   aa::DevScalars *sc_host = nullptr;   // pinned (= &mb->s)

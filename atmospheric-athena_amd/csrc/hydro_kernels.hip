@@ -2236,8 +2236,23 @@ static void slopes_impl(const HostGrid &g, int dir, hipStream_t st, const Real *
   else hipLaunchKernelGGL((k_slopes<NS, 2>), grid, blk, 0, st, g, src);
 }
 // the correct passes of all three directions in one kernel (after the three first passes)
+// the first-pass x1 fluxes of the faces between the tiles of k_correct_all (needs U only: the caller may run it beside the x2 sweep)
 template <int NS, bool GRAV>
-static void correct_all_impl(const HostGrid &g, Real dt, bool x3f, hipStream_t st)
+static void x1_edges_impl(const HostGrid &g, Real dt, hipStream_t st)
+{
+  if (!CA_X1F || x1_edges(g) <= 0) return;
+  const int nj = g.je - g.js + 3, nk = g.ke - g.ks + 3;
+  dim3 ge(nblk(nj, 64), nk, x1_edges(g));
+  if (g.slope) hipLaunchKernelGGL((k_x1_edge_flux<NS, GRAV, 3>), ge, dim3(64), 0, st, g, dt);
+  else         hipLaunchKernelGGL((k_x1_edge_flux<NS, GRAV, 2>), ge, dim3(64), 0, st, g, dt);
+}
+void launch_x1_edges(const HostGrid &g, int nscal, Real dt, bool grav, hipStream_t st)
+{
+  if (nscal) { if (grav) x1_edges_impl<1, true>(g, dt, st); else x1_edges_impl<1, false>(g, dt, st); }
+  else       { if (grav) x1_edges_impl<0, true>(g, dt, st); else x1_edges_impl<0, false>(g, dt, st); }
+}
+template <int NS, bool GRAV>
+static void correct_all_impl(const HostGrid &g, Real dt, bool x3f, hipStream_t st, bool edges_done)
 {
   const int ni = g.ie - g.is + 3, nj = g.je - g.js + 3, nk = g.ke - g.ks + 3;    // zones s-1 .. e+1
   // planes per block: with the x3 first pass on board a chunk starts three planes early (two of first-pass work only and the
@@ -2250,11 +2265,7 @@ static void correct_all_impl(const HostGrid &g, Real dt, bool x3f, hipStream_t s
   // with 8 planes, 1.30 against 1.65 ms at 192^3; 256^3 with 16, 2.80 against 3.09; 320^3 with 32; from 384^3 on with 64)
   if (kc_env <= 0) while (kc > 8 && (long)nblk(ni + 15, 64)*nblk(nj, CA_TJ)*((nk + kc - 1)/kc) < 4096) kc >>= 1;
   dim3 grid(nblk(ni + 15, 64), nblk(nj, CA_TJ), (nk + kc - 1)/kc), blk(64, CA_TJ);
-  if (x3f && CA_X1F && x1_edges(g) > 0) {      // the first-pass x1 fluxes of the faces between the tiles
-    dim3 ge(nblk(nj, 64), nk, x1_edges(g));
-    if (g.slope) hipLaunchKernelGGL((k_x1_edge_flux<NS, GRAV, 3>), ge, dim3(64), 0, st, g, dt);
-    else         hipLaunchKernelGGL((k_x1_edge_flux<NS, GRAV, 2>), ge, dim3(64), 0, st, g, dt);
-  }
+  if (x3f && !edges_done) x1_edges_impl<NS, GRAV>(g, dt, st);
   const StepRatios sr = step_ratios(g, dt);
   if (x3f) {
     if (g.slope) hipLaunchKernelGGL((k_correct_all<NS, GRAV, 3, true>), grid, blk, 0, st, g, dt, kc, sr);
@@ -2269,10 +2280,10 @@ static void correct_all_impl(const HostGrid &g, Real dt, bool x3f, hipStream_t s
     if (c0 > 0 || c1 > 0) hipLaunchKernelGGL(k_eta_edges, dim3(nblk(c0 > c1 ? c0 : c1, 256), 2), dim3(256), 0, st, g);
   }
 }
-void launch_correct_all(const HostGrid &g, int nscal, Real dt, bool grav, bool x3f, hipStream_t st)
+void launch_correct_all(const HostGrid &g, int nscal, Real dt, bool grav, bool x3f, hipStream_t st, bool edges_done)
 {
-  if (nscal) { if (grav) correct_all_impl<1, true>(g, dt, x3f, st); else correct_all_impl<1, false>(g, dt, x3f, st); }
-  else       { if (grav) correct_all_impl<0, true>(g, dt, x3f, st); else correct_all_impl<0, false>(g, dt, x3f, st); }
+  if (nscal) { if (grav) correct_all_impl<1, true>(g, dt, x3f, st, edges_done); else correct_all_impl<1, false>(g, dt, x3f, st, edges_done); }
+  else       { if (grav) correct_all_impl<0, true>(g, dt, x3f, st, edges_done); else correct_all_impl<0, false>(g, dt, x3f, st, edges_done); }
 }
 
 void launch_slopes(const HostGrid &g, int nscal, int dir, hipStream_t st, const Real *src)

@@ -8,7 +8,10 @@ void launch_sweep(const HostGrid &g, int nscal, int dir, Real dt, bool grav, hip
 void launch_correct(const HostGrid &g, int nscal, int dir, Real dt, bool grav, hipStream_t st);
 void launch_sweep_correct_x1(const HostGrid &g, int nscal, Real dt, bool grav, hipStream_t st);
 // the three correct passes in one kernel; x3f: and the x3 first pass (then launch_sweep(.., 2, ..) is not needed)
-void launch_correct_all(const HostGrid &g, int nscal, Real dt, bool grav, bool x3f, hipStream_t st);
+void launch_correct_all(const HostGrid &g, int nscal, Real dt, bool grav, bool x3f, hipStream_t st, bool edges_done = false);
+// the tile-edge x1 fluxes launch_correct_all(x3f) otherwise starts with (edges_done): they need U only, so a caller may run them on
+// another stream beside the x2 sweep
+void launch_x1_edges(const HostGrid &g, int nscal, Real dt, bool grav, hipStream_t st);
 bool ca_x1_on_board();     // with x3f, launch_correct_all also does the x1 first pass (then launch_sweep(.., 0, ..) is not needed)
 void launch_flux2(const HostGrid &g, int nscal, int dir, hipStream_t st);
 void launch_update(const HostGrid &g, int nscal, const Real *dhalf, Real dt, bool grav, hipStream_t st, DevScalars *sc = nullptr,
