@@ -97,7 +97,7 @@ int aa_create(const aa_params *p, aa_grid **out)
     c.pitch_align = env("AA_PITCH_ALIGN", 1);
     c.mailbox = env("AA_MAILBOX", 1); c.mailbox_spin_us = env("AA_MAILBOX_SPIN_US", 300);
     c.bc_one = env("AA_BC_ONE", 1); c.fuse_pick = env("AA_ION_FUSE_PICK", 1); c.pin_one = env("AA_PIN_ONE", 1);
-    c.edge_overlap = env("AA_EDGE_OVERLAP", 1);
+    c.edge_overlap = env("AA_EDGE_OVERLAP", 0);
   }
   d.Nx1 = p->Nx[0]; d.Nx2 = p->Nx[1]; d.Nx3 = p->Nx[2];
   d.N1 = d.Nx1 + 2*AA_NGHOST; d.N2 = d.Nx2 + 2*AA_NGHOST; d.N3 = d.Nx3 + 2*AA_NGHOST;
@@ -614,8 +614,10 @@ int aa_integrate_3d_ctu(aa_grid *g)
     return 0;
   }
   if (d.slope) { Scope s(g, "ppm_slopes"); for (int dir = 0; dir < 3; dir++) HL(launch_slopes)(d, ns, dir, g->st, nullptr); }
-  // the tile-edge x1 fluxes k_correct_all needs (k_x1_edge_flux: a few bytes per zone, bound by its strided loads) beside the x2 sweep
-  // (bound by its arithmetic) on a stream of their own; both read U only
+  // AA_EDGE_OVERLAP=1: the tile-edge x1 fluxes k_correct_all needs (k_x1_edge_flux: a few bytes per zone, bound by its strided loads)
+  // beside the x2 sweep (bound by its arithmetic) on a stream of their own; both read U only.  -0.27 ms of a 41.4 ms step at 512^3
+  // (profiles/r04_x1f_ab.txt item 11) -- off by default: it is inside the box-to-box spread, and with two kernels in flight at once the
+  // per-kernel durations a profiler reports are no longer each kernel's own
   bool edges_aside = false;
   if (x1_fused(g) && d.cfg.edge_overlap) {
     if (!g->side) {

@@ -105,7 +105,7 @@ struct LaunchCfg {
   int mailbox = 1;           // AA_MAILBOX=0: scalars come back by hipMemcpyAsync + hipStreamSynchronize instead of the polled mailbox
   int mailbox_spin_us = 300; // AA_MAILBOX_SPIN_US: how long the host polls before it falls back to hipStreamSynchronize
   int bc_one = 1;            // AA_BC_ONE=0: bvals_mhd as one launch per direction instead of one for the whole ghost shell
-  int edge_overlap = 1;      // AA_EDGE_OVERLAP=0: k_x1_edge_flux in front of k_correct_all on the Grid's stream instead of beside the x2 sweep on a side stream
+  int edge_overlap = 0;      // AA_EDGE_OVERLAP=1: k_x1_edge_flux beside the x2 sweep on a side stream instead of in front of k_correct_all on the Grid's stream
   int pin_one = 1;           // AA_PIN_ONE=0: the pinned zones' share of new_dt's maxima by a kernel of its own behind k_pinned
   int fuse_pick = 1;         // AA_ION_FUSE_PICK=0: k_ion_reduce and k_ion_pick2 as two launches also where one rank reduces alone
 };

@@ -172,5 +172,7 @@ def test_x1_first_pass_inside_correct_all_at_the_tile_edges(problem, nx1, order,
     a, ia, sa = run_gpu(problem, ov, True, False, 2, monkeypatch, order)
     b, ib, sb = run_gpu(problem, ov, True, "all+x3", 2, monkeypatch, order)
     c, ic, sc = run_gpu(problem, ov, True, "all", 2, monkeypatch, order)
-    assert ia == ib == ic and sa == sb == sc
-    assert np.array_equal(a, b, equal_nan=True) and np.array_equal(a, c, equal_nan=True)
+    monkeypatch.setenv("AA_EDGE_OVERLAP", "1")          # k_x1_edge_flux on a side stream beside the x2 sweep (api.hip; off by default)
+    d, id_, sd = run_gpu(problem, ov, True, "all+x3", 2, monkeypatch, order)
+    assert ia == ib == ic == id_ and sa == sb == sc == sd
+    assert np.array_equal(a, b, equal_nan=True) and np.array_equal(a, c, equal_nan=True) and np.array_equal(a, d, equal_nan=True)
